@@ -1,0 +1,261 @@
+/*
+ * vipe_amd.h - C ABI of libvipe_amd.so, the MI355X (gfx950) backend for the ViPE dense-SLAM
+ * update iteration.  One entry point per function the reference binds through pybind11 in
+ * csrc/bind.cpp:28-49 (submodules droid_net_ext, slam_ext, lietorch_ext, scatter_ext, corr_ext),
+ * plus the fused entry points the MI355X-first design adds (marked [fused]).
+ *
+ * Conventions
+ *   - every pointer named d_* is DEVICE memory (hipMalloc / torch CUDA tensor .data_ptr());
+ *     h_* is host memory.  All tensors are contiguous row-major with the shapes given.
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream; 0 = null stream).
+ *     Nothing here synchronises the host, allocates device memory or copies D2H: callers pass
+ *     workspaces (sizes from the *_workspace_bytes functions), so every call is graph-capturable.
+ *   - return value: 0 on success, a negative VIPE_E* code on argument errors (no launch made),
+ *     or a positive hipError_t if a launch failed.
+ *   - dtype codes: VIPE_F16 / VIPE_F32 / VIPE_F64 (the reference's AT_DISPATCH_FLOATING_TYPES_AND_HALF).
+ */
+#ifndef VIPE_AMD_H
+#define VIPE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIPE_F16 0
+#define VIPE_F32 1
+#define VIPE_F64 2
+
+#define VIPE_OK 0
+#define VIPE_EINVAL (-1)   /* bad shape / null pointer / unsupported dtype */
+#define VIPE_ENOSPACE (-2) /* workspace too small */
+#define VIPE_EUNSUPPORTED (-3)
+
+#define VIPE_CAM_PINHOLE 0 /* vipe/utils/cameras.py:123 */
+#define VIPE_CAM_MEI 1     /* vipe/utils/cameras.py:220 */
+
+/* library / build identification ("gfx950", ABI version) */
+const char* vipe_amd_version(void);
+int vipe_amd_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * droid_net_ext  (csrc/droid_net_ext/droid.cpp:57-63)
+ * ------------------------------------------------------------------------------------------- */
+
+/* corr_index_forward: replaces corr_index_cuda_forward, correlation_kernels.cu:115-136.
+ * volume [B,h1,w1,h2,w2] dtype; coords [B,2,h1,w1] f32; corr [B,2r+1,2r+1,h1,w1] dtype (fully written). */
+int vipe_corr_index_forward(const void* d_volume, const float* d_coords, void* d_corr, int B, int h1, int w1,
+                            int h2, int w2, int radius, int dtype, void* stream);
+
+/* corr_index_backward: replaces corr_index_cuda_backward, correlation_kernels.cu:138-159.
+ * corr_grad [B,2r+1,2r+1,h1,w1]; volume_grad [B,h1,w1,h2,w2] (fully written, zero outside the windows). */
+int vipe_corr_index_backward(const float* d_coords, const void* d_corr_grad, void* d_volume_grad, int B, int h1,
+                             int w1, int h2, int w2, int radius, int dtype, void* stream);
+
+/* [fused] CorrBlock.__call__ (droid_net.py:71-82): all pyramid levels in one launch.
+ * h_levels: host array of num_levels device pointers, level i is [B,h1,w1,h2>>i,w2>>i];
+ * coords [B,h1,w1,2] f32 (level i uses coords / 2^i); out [B,num_levels*(2r+1)^2,h1,w1]. */
+int vipe_corr_pyramid_lookup(const void* const* h_levels, const float* d_coords, void* d_out, int B, int h1, int w1,
+                             int h2, int w2, int num_levels, int radius, int dtype, void* stream);
+
+/* [fused] CorrBlock.corr + pyramid (droid_net.py:56-69,94-102): volume = (f1/4)^T (f2/4) on MFMA (fp16 in,
+ * fp32 accumulate, stored as dtype), then 2x2 average pooling of the target dims for levels 1..num_levels-1.
+ * fmap1, fmap2 [B,C,h,w] f16; h_levels: host array of num_levels device pointers (outputs). C % 32 == 0. */
+int vipe_corr_pyramid_build(const void* d_fmap1, const void* d_fmap2, void* const* h_levels, int B, int C, int h,
+                            int w, int num_levels, void* stream);
+
+/* altcorr_forward: replaces altcorr_cuda_forward, altcorr_kernel.cu:266-290.
+ * fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C] dtype (f16/f32); coords [B,N,H1,W1,2] f32; corr [B,N,(2r+1)^2,H1,W1]. */
+int vipe_altcorr_forward(const void* d_fmap1, const void* d_fmap2, const float* d_coords, void* d_corr, int B,
+                         int H1, int W1, int H2, int W2, int N, int C, int radius, int dtype, void* stream);
+
+/* altcorr_backward: replaces altcorr_cuda_backward, altcorr_kernel.cu:292-320 (float32 only).
+ * fmap1_grad / fmap2_grad are accumulated into (caller zero-initialises), coords receive no gradient. */
+int vipe_altcorr_backward(const float* d_fmap1, const float* d_fmap2, const float* d_coords,
+                          const float* d_corr_grad, float* d_fmap1_grad, float* d_fmap2_grad, int B, int H1, int W1,
+                          int H2, int W2, int N, int C, int radius, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * lietorch_ext  (csrc/lietorch_ext/lietorch.cpp:305-336).  group_id 1=SO3 2=RxSO3 3=SE3 4=Sim3
+ * (dispatch.h:18-40); dtype VIPE_F32 / VIPE_F64.  `on_device` 0 runs the same closed forms on the
+ * host (the reference's lietorch_cpu.cpp path), 1 launches on `stream`.
+ * Rows: X [n,N] (N = 4,5,7,8), tangent a [n,K] (K = 3,4,6,7).
+ * ------------------------------------------------------------------------------------------- */
+int vipe_lie_expm(int group_id, const void* a, void* X, int64_t n, int dtype, int on_device, void* stream);
+int vipe_lie_logm(int group_id, const void* X, void* a, int64_t n, int dtype, int on_device, void* stream);
+int vipe_lie_inv(int group_id, const void* X, void* Y, int64_t n, int dtype, int on_device, void* stream);
+int vipe_lie_mul(int group_id, const void* X, const void* Y, void* Z, int64_t n, int dtype, int on_device,
+                 void* stream);
+int vipe_lie_adj(int group_id, const void* X, const void* a, void* b, int64_t n, int dtype, int on_device,
+                 void* stream);
+int vipe_lie_adjT(int group_id, const void* X, const void* a, void* b, int64_t n, int dtype, int on_device,
+                  void* stream);
+int vipe_lie_act(int group_id, const void* X, const void* p, void* q, int64_t n, int dtype, int on_device,
+                 void* stream); /* p,q [n,3] */
+int vipe_lie_act4(int group_id, const void* X, const void* p, void* q, int64_t n, int dtype, int on_device,
+                  void* stream); /* p,q [n,4] */
+int vipe_lie_as_matrix(int group_id, const void* X, void* T, int64_t n, int dtype, int on_device,
+                       void* stream); /* T [n,4,4] */
+int vipe_lie_projector(int group_id, const void* X, void* P, int64_t n, int dtype, int on_device,
+                       void* stream); /* P [n,N,N] */
+int vipe_lie_jinv(int group_id, const void* X, const void* a, void* b, int64_t n, int dtype, int on_device,
+                  void* stream);
+/* [fused] broadcast forms: one group element per `rows_per_elem` consecutive rows of a/p (the Python
+ * wrapper in the reference replicates X per row, broadcasting.py:32-35). */
+int vipe_lie_adjT_bcast(int group_id, const void* X, const void* a, void* b, int64_t n_elem, int64_t rows_per_elem,
+                        int dtype, void* stream);
+int vipe_lie_act4_bcast(int group_id, const void* X, const void* p, void* q, int64_t n_elem, int64_t rows_per_elem,
+                        int dtype, void* stream);
+/* backward passes (lietorch.cpp:317-331): grad wrt the op's inputs */
+int vipe_lie_expm_backward(int group_id, const void* grad, const void* a, void* da, int64_t n, int dtype,
+                           int on_device, void* stream);
+int vipe_lie_logm_backward(int group_id, const void* grad, const void* X, void* dX, int64_t n, int dtype,
+                           int on_device, void* stream);
+int vipe_lie_inv_backward(int group_id, const void* grad, const void* X, void* dX, int64_t n, int dtype,
+                          int on_device, void* stream);
+int vipe_lie_mul_backward(int group_id, const void* grad, const void* X, const void* Y, void* dX, void* dY,
+                          int64_t n, int dtype, int on_device, void* stream);
+int vipe_lie_adj_backward(int group_id, const void* grad, const void* X, const void* a, void* dX, void* da,
+                          int64_t n, int dtype, int on_device, void* stream);
+int vipe_lie_adjT_backward(int group_id, const void* grad, const void* X, const void* a, void* dX, void* da,
+                           int64_t n, int dtype, int on_device, void* stream);
+int vipe_lie_act_backward(int group_id, const void* grad, const void* X, const void* p, void* dX, void* dp,
+                          int64_t n, int dtype, int on_device, void* stream);
+int vipe_lie_act4_backward(int group_id, const void* grad, const void* X, const void* p, void* dX, void* dp,
+                           int64_t n, int dtype, int on_device, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * slam_ext  (csrc/slam_ext/slam.cpp:31-37) and the live dense BA it stands behind
+ * ------------------------------------------------------------------------------------------- */
+
+/* [fused] GraphBuffer.reproject_dense_disp (buffer.py:527-548 -> geom.py:187-263, jacobian=False).
+ * poses [n_poses,7] world->cam; disps [n_poses*V,ht,wd]; intrinsics [V,4+D] FULL-RES (scaled by
+ * 1/intr_factor inside, terms.py:182); rig [V,7]; pi,qi,pj,qj,di [M] int64 (expand_edge_multiview).
+ * coords [M,ht,wd,2], valid [M,ht,wd] f32 (valid may be NULL). */
+int vipe_reproject(const float* d_poses, const float* d_disps, const float* d_intrinsics, const float* d_rig,
+                   const int64_t* d_pi, const int64_t* d_qi, const int64_t* d_pj, const int64_t* d_qj,
+                   const int64_t* d_di, float* d_coords, float* d_valid, int M, int ht, int wd, int n_views,
+                   int camera, float intr_factor, void* stream);
+
+/* [fused] FactorGraph.update motion features (factor_graph.py:253-261): coords1 = reproject(ii,jj) and
+ * motn = clamp(cat[coords1 - grid, target - coords1], +-64) written as [M,4,ht,wd] in `motn_dtype`. */
+int vipe_reproject_motion(const float* d_poses, const float* d_disps, const float* d_intrinsics, const float* d_rig,
+                          const int64_t* d_pi, const int64_t* d_qi, const int64_t* d_pj, const int64_t* d_qj,
+                          const int64_t* d_di, const float* d_target, float* d_coords, void* d_motn, int M, int ht,
+                          int wd, int n_views, int camera, float intr_factor, int motn_dtype, void* stream);
+
+/* Dense bundle adjustment with the LIVE semantics of GraphBuffer.bundle_adjustment (buffer.py:373-525,
+ * solver.py:117-197, terms.py:94-303): Gauss-Newton on SE3 (+) per-pixel inverse depth (+ optional
+ * focal/distortion), Schur reduction over the depths, dense block Cholesky (fp64) of the reduced system,
+ * back-substitution and retraction, n_iters times, entirely on `stream`.
+ *   poses [n_poses,7] (updated in place), disps [n_poses*V,ht,wd] (in place; finally clamped >= 1e-3 over
+ *   all n_disp_frames), disps_sens like disps, intrinsics [V,4+D] (in place when optimize_intrinsics),
+ *   rig [V,7], target/weight [M,ht*wd,2], disp_damping [n_poses*V,ht,wd] (GraphAgg eta),
+ *   pi,qi,pj,qj,di [M] int64.  Pose p is fixed iff it occurs in pi and (p < t0 or p >= t1)
+ *   (buffer.py:462-465); t0 == t1 fixes every pose.
+ *   d_workspace: vipe_dense_ba_workspace_bytes(...) bytes, contents need not be initialised.
+ *   d_info (optional, 4 ints): [n_free_poses, n_free_disp_frames, cholesky_failures, n_regular_unknowns]. */
+typedef struct {
+  int n_poses;       /* rows of poses; disps has n_poses*n_views frames */
+  int n_views;
+  int ht, wd;
+  int M;             /* number of terms (edges * views) */
+  int t0, t1;
+  int n_iters;
+  float pose_damping, pose_ep;
+  int motion_only;
+  int limited_disp;
+  int optimize_intrinsics;
+  int optimize_rig_rotation; /* must be 0 for n_views == 1 (rig 0 is always fixed, buffer.py:506) */
+  int camera;        /* VIPE_CAM_* */
+  float alpha;       /* ba.dense_disp_alpha, configs/slam/default.yaml:48-49 */
+  float weight_scale;/* 0.001, buffer.py:396 */
+  float intr_factor; /* 8.0, buffer.py:415 */
+} vipe_ba_params;
+
+int64_t vipe_dense_ba_workspace_bytes(const vipe_ba_params* p);
+int vipe_dense_ba(const vipe_ba_params* p, float* d_poses, float* d_disps, const float* d_disps_sens,
+                  float* d_intrinsics, float* d_rig, const float* d_target, const float* d_weight,
+                  const float* d_disp_damping, const int64_t* d_pi, const int64_t* d_qi, const int64_t* d_pj,
+                  const int64_t* d_qj, const int64_t* d_di, void* d_workspace, int64_t workspace_bytes,
+                  int* d_info, void* stream);
+
+/* slam_ext.ba with the DROID signature (slam.cpp:31, geom_kernels.cu:1273-1404; dormant in the reference):
+ * single pinhole intrinsics[4] at 1/8 scale, targets/weights [E,2,ht,wd], eta [t1-t0... see file], poses/disps
+ * updated in place; dx [t1-t0,6], dz [K,ht*wd] written for the last iteration. */
+int64_t vipe_ba_workspace_bytes(int n_poses, int ht, int wd, int E);
+int vipe_ba(float* d_poses, float* d_disps, const float* d_intrinsics, const float* d_disps_sens,
+            const float* d_targets, const float* d_weights, const float* d_eta, const int64_t* d_ii,
+            const int64_t* d_jj, int n_poses, int ht, int wd, int E, int n_eta, int t0, int t1, int iterations,
+            float lm, float ep, int motion_only, float* d_dx, float* d_dz, void* d_workspace,
+            int64_t workspace_bytes, void* stream);
+
+/* frame_distance: replaces frame_distance_cuda, geom_kernels.cu:1406-1434 (kernel :521-676).
+ * poses [NV,7], disps [NV,ht,wd], intrinsics [V,4] (pinhole, 1/8 scale), pi,pj,qi,qj,di [M] int64, dist [M]. */
+int vipe_frame_distance(const float* d_poses, const float* d_disps, const float* d_intrinsics, const int64_t* d_pi,
+                        const int64_t* d_pj, const int64_t* d_qi, const int64_t* d_qj, const int64_t* d_di,
+                        float* d_dist, int M, int ht, int wd, float beta, void* stream);
+
+/* depth_filter: replaces depth_filter_cuda, geom_kernels.cu:1462-1486 (kernel :678-793).
+ * poses [n,7], disps [n,ht,wd], intrinsics [4], inds [num] int64, thresh [num] f32, counter [num,ht,wd] f32. */
+int vipe_depth_filter(const float* d_poses, const float* d_disps, const float* d_intrinsics, const int64_t* d_inds,
+                      const float* d_thresh, float* d_counter, int n, int num, int ht, int wd, void* stream);
+
+/* projmap: replaces projmap_cuda, geom_kernels.cu:1436-1460 (kernel :434-519). coords [E,ht,wd,3], valid [E,ht,wd,1]. */
+int vipe_projmap(const float* d_poses, const float* d_disps, const float* d_intrinsics, const int64_t* d_ii,
+                 const int64_t* d_jj, float* d_coords, float* d_valid, int E, int ht, int wd, void* stream);
+
+/* iproj: replaces iproj_cuda, geom_kernels.cu:1488-1507 (kernel :795-861). points [n,ht,wd,3]. */
+int vipe_iproj(const float* d_poses, const float* d_disps, const float* d_intrinsics, float* d_points, int n, int ht,
+               int wd, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * scatter_ext  (csrc/scatter_ext/scatter.cpp:232-238, cuda/scatter_cuda.cu:57-131)
+ * src viewed as [outer, src_dim, inner], out as [outer, out_dim, inner], index broadcast to src's shape
+ * (int64, same layout as src).  reduce: 0 sum, 1 mul, 2 mean (sum only - caller divides), 3 min, 4 max.
+ * For min/max, d_arg_out [outer,out_dim,inner] int64 receives the arg index (src_dim where none).
+ * ------------------------------------------------------------------------------------------- */
+int vipe_scatter(const void* d_src, const int64_t* d_index, void* d_out, int64_t* d_arg_out, int64_t outer,
+                 int64_t src_dim, int64_t inner, int64_t out_dim, int reduce, int dtype, void* stream);
+
+/* [fused] segmented mean of per-edge feature maps onto source nodes (GraphAgg, droid_net.py:420-421):
+ * src [E,inner] f16, ix [E] int64 sorted or not, out [n_out,inner] f16 = mean over edges with ix == k. */
+int vipe_scatter_mean_rows_f16(const void* d_src, const int64_t* d_ix, void* d_out, int E, int n_out, int64_t inner,
+                               void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * corr_ext  (csrc/corr_ext/correlation_sampler.cpp:82-85, correlation_cuda_kernel.cu:216-330)
+ * in1,in2 [B,C,H,W]; out [B,patchH,patchW,oH,oW]; dtype f16/f32.
+ * ------------------------------------------------------------------------------------------- */
+int vipe_corr_sampler_forward(const void* d_in1, const void* d_in2, void* d_out, int B, int C, int H, int W, int kH,
+                              int kW, int patchH, int patchW, int padH, int padW, int dilH, int dilW,
+                              int dil_patchH, int dil_patchW, int dH, int dW, int dtype, void* stream);
+int vipe_corr_sampler_backward(const void* d_in1, const void* d_in2, const void* d_grad_out, void* d_grad1,
+                               void* d_grad2, int B, int C, int H, int W, int kH, int kW, int patchH, int patchW,
+                               int padH, int padW, int dilH, int dilW, int dil_patchH, int dil_patchW, int dH,
+                               int dW, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * [fused] flow-update operator convolutions (UpdateModule, droid_net.py:432-499): NHWC fp16
+ * implicit-GEMM convolution on MFMA, fp32 accumulate, fused bias + activation.
+ *   x [B,H,W,Cin_total] f16, reads channels [cin_off, cin_off+Cin); w packed [KH*KW, Cin, Cout] f16
+ *   (vipe_conv_pack_weights from the OIHW checkpoint layout); bias [Cout] f32;
+ *   y [B,H,W,Cout_total] f16, writes channels [cout_off, cout_off+Cout).
+ *   act: 0 none, 1 relu, 2 sigmoid, 3 tanh.  Stride 1, "same" padding.
+ *   extra [B,Cout] f32 (optional, NULL = none): per-image additive term (the *_glo 1x1 of the GRU).
+ * ------------------------------------------------------------------------------------------- */
+#define VIPE_ACT_NONE 0
+#define VIPE_ACT_RELU 1
+#define VIPE_ACT_SIGMOID 2
+#define VIPE_ACT_TANH 3
+int vipe_conv_pack_weights(const void* d_w_oihw, void* d_w_packed, int Cout, int Cin, int KH, int KW, int src_dtype,
+                           void* stream);
+int vipe_conv2d_nhwc_f16(const void* d_x, const void* d_w_packed, const float* d_bias, const float* d_extra,
+                         void* d_y, int B, int H, int W, int Cin, int cin_total, int cin_off, int Cout,
+                         int cout_total, int cout_off, int KH, int KW, int act, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIPE_AMD_H */

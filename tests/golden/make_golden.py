@@ -1,0 +1,290 @@
+"""Generate golden fixtures from the reference's own Python files (build container only).
+
+Run:  python tests/golden/make_golden.py  [/root/reference]
+
+The reference package cannot be imported as a whole (omegaconf/hydra/cv2 absent, and
+`vipe.ext` would JIT-compile CUDA sources), so the individual hot-path files are
+loaded by path under their dotted names with `vipe.ext`'s NATIVE modules stubbed:
+  * vipe.ext.lietorch_ext  -> oracle.se3 closed forms (SE3 only).  The reference's
+    pure-Python lietorch wrapper (vipe/ext/lietorch/*.py) is the real one.
+  * vipe.ext.{scatter_ext,droid_net_ext,slam_ext} -> empty namespaces (never called:
+    scatter_add/scatter_mean go through torch.scatter_add_, vipe/ext/scatter.py:24-53).
+Only DATA (inputs + outputs) is written, as .npz next to this script.
+"""
+
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import se3 as ose3  # noqa: E402
+from vipe_amd.synth import make_graph  # noqa: E402
+
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _wrap(fn):
+    def f(gid, *args):
+        assert gid == 3, "only SE3 is stubbed"
+        out = fn(*[_np(a) for a in args])
+        return torch.from_numpy(np.ascontiguousarray(out)).to(args[0].dtype)
+    return f
+
+
+def _load(name, relpath):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    parent, _, child = name.rpartition(".")
+    if parent in sys.modules:
+        setattr(sys.modules[parent], child, mod)
+    return mod
+
+
+def load_reference():
+    for pkg in ["vipe", "vipe.ext", "vipe.ext.lietorch", "vipe.utils", "vipe.slam", "vipe.slam.maths",
+                "vipe.slam.ba", "vipe.slam.networks"]:
+        m = types.ModuleType(pkg)
+        m.__path__ = []
+        sys.modules[pkg] = m
+        parent, _, child = pkg.rpartition(".")
+        if parent:
+            setattr(sys.modules[parent], child, m)
+    ext = sys.modules["vipe.ext"]
+    for n in ["scatter_ext", "droid_net_ext", "slam_ext"]:
+        setattr(ext, n, types.SimpleNamespace())
+    lie = types.SimpleNamespace(
+        expm=_wrap(ose3.se3_exp), logm=_wrap(ose3.se3_log), inv=_wrap(ose3.se3_inv), mul=_wrap(ose3.se3_mul),
+        adj=_wrap(ose3.se3_adj), adjT=_wrap(ose3.se3_adjT), act=_wrap(ose3.se3_act3), act4=_wrap(ose3.se3_act4),
+    )
+    def _absent(*a, **k):
+        raise NotImplementedError("backward / auxiliary lietorch ops are not needed under torch.no_grad")
+
+    for n in ["expm", "logm", "inv", "mul", "adj", "adjT", "act", "act4"]:
+        setattr(lie, n + "_backward", _absent)
+    lie.Jinv = lie.projector = _absent
+    lie.as_matrix = _wrap(ose3.se3_matrix)
+    ext.lietorch_ext = lie
+    sys.modules["vipe.ext.lietorch_ext"] = lie
+    _load("vipe.ext.lietorch.broadcasting", "vipe/ext/lietorch/broadcasting.py")
+    _load("vipe.ext.lietorch.group_ops", "vipe/ext/lietorch/group_ops.py")
+    g = _load("vipe.ext.lietorch.groups", "vipe/ext/lietorch/groups.py")
+    lt = sys.modules["vipe.ext.lietorch"]
+    for n in ["SE3", "SO3", "Sim3", "RxSO3", "cat", "stack"]:
+        setattr(lt, n, getattr(g, n))
+    R = types.SimpleNamespace()
+    R.scatter = _load("vipe.ext.scatter", "vipe/ext/scatter.py")
+    R.cameras = _load("vipe.utils.cameras", "vipe/utils/cameras.py")
+    R.vector = _load("vipe.slam.maths.vector", "vipe/slam/maths/vector.py")
+    R.matrix = _load("vipe.slam.maths.matrix", "vipe/slam/maths/matrix.py")
+    R.geom = _load("vipe.slam.maths.geom", "vipe/slam/maths/geom.py")
+    R.retractor = _load("vipe.slam.maths.retractor", "vipe/slam/maths/retractor.py")
+    R.kernel = _load("vipe.slam.ba.kernel", "vipe/slam/ba/kernel.py")
+    R.terms = _load("vipe.slam.ba.terms", "vipe/slam/ba/terms.py")
+    R.solver = _load("vipe.slam.ba.solver", "vipe/slam/ba/solver.py")
+    R.droid_net = _load("vipe.slam.networks.droid_net", "vipe/slam/networks/droid_net.py")
+    R.SE3 = g.SE3
+    return R
+
+
+def reference_ba(R, poses, disps, disps_sens, intrinsics, target, weight, eta, ii, jj, t0, t1, n_iters,
+                 pose_damping, pose_ep, motion_only, limited_disp, optimize_intrinsics, camera="pinhole",
+                 alpha=0.001):
+    """Drive the reference Solver exactly as GraphBuffer.bundle_adjustment does (buffer.py:396-525), mono rig."""
+    Solver, SparseBlockVector = R.solver.Solver, R.vector.SparseBlockVector
+    T, RT = R.terms, R.retractor
+    cam = R.cameras.CameraType.PINHOLE if camera == "pinhole" else R.cameras.CameraType.MEI
+    poses = torch.tensor(poses).float().clone()
+    N, ht, wd = disps.shape
+    dis = torch.tensor(disps).float().clone().view(N, 1, ht, wd)
+    sens = torch.tensor(disps_sens).float().view(N, ht * wd)
+    intr = torch.tensor(intrinsics).float().clone()
+    rig = torch.tensor([[0, 0, 0, 0, 0, 0, 1.0]])
+    ii_t, jj_t = torch.tensor(ii), torch.tensor(jj)
+    pi, pj = ii_t, jj_t
+    qi = qj = torch.zeros_like(ii_t)
+    di = pi
+    di_unique, pi_unique = torch.unique(di), torch.unique(ii_t)
+    E = len(ii)
+    solver = Solver(compute_energy=True)
+    solver.add_term(T.DenseDepthFlowTerm(
+        pose_i_inds=pi, pose_j_inds=pj, rig_i_inds=qi, rig_j_inds=qj, dense_disp_i_inds=di,
+        target=torch.tensor(target).float().reshape(E, ht * wd, 2),
+        weight=0.001 * torch.tensor(weight).float().reshape(E, ht * wd, 2),
+        intrinsics=None, intrinsics_factor=8.0, rig=None, image_size=(ht, wd), camera_type=cam))
+    solver.set_fixed("pose", torch.cat([pi_unique[pi_unique < t0], pi_unique[pi_unique >= t1]]) if t0 < t1 else None)
+    solver.set_retractor("pose", RT.PoseRetractor())
+    solver.set_damping("pose", damping=pose_damping, ep=pose_ep)
+    if not motion_only:
+        sens_i = di_unique[sens[di_unique].sum(1) > 0.0]
+        if len(sens_i) > 0:
+            solver.add_term(T.DispSensRegularizationTerm(i_inds=sens_i, alpha=alpha, disps_sens=sens))
+        solver.set_retractor("dense_disp", RT.DenseDispRetractor())
+        damp = torch.tensor(eta).float().view(N, ht * wd)
+        solver.set_damping("dense_disp", damping=SparseBlockVector(inds=di_unique, data=0.2 * damp[di_unique] + 1e-7),
+                           ep=1e-7)
+        if limited_disp:
+            solver.set_fixed("dense_disp", torch.cat([di[pi < t0], di[pi >= t1]]))
+    else:
+        solver.set_fixed("dense_disp")
+    solver.set_marginilized("dense_disp")
+    solver.set_retractor("intrinsics", RT.IntrinsicsRetractor(cam))
+    solver.set_damping("intrinsics", damping=1e-6, ep=1e-6)
+    if not optimize_intrinsics:
+        solver.set_fixed("intrinsics")
+    solver.set_retractor("rig", RT.RigRotationOnlyRetractor())
+    solver.set_damping("rig", damping=1e-4, ep=1e-4)
+    solver.set_fixed("rig")
+    flat = dis.view(N, ht * wd)
+    energies = []
+    for _ in range(n_iters):
+        energies.append(solver.run_inplace({"pose": R.SE3(poses), "dense_disp": flat, "intrinsics": intr,
+                                            "rig": R.SE3(rig)}))
+    dis.clamp_(min=0.001)
+    return _np(poses), _np(dis.view(N, ht, wd)), _np(intr), np.asarray(energies, dtype=np.float64)
+
+
+BA_CASES = {
+    # name: (graph kwargs, BA kwargs)
+    "cfg1_pose_only": (dict(n=2, height=96, width=128, radius=1, seed=7),
+                       dict(t0=1, t1=2, n_iters=3, pose_damping=1e-3, pose_ep=0.1, motion_only=True,
+                            limited_disp=False, optimize_intrinsics=False)),
+    "n5_frontend": (dict(n=5, height=96, width=128, radius=3, seed=11),
+                    dict(t0=1, t1=5, n_iters=3, pose_damping=1e-3, pose_ep=0.1, motion_only=False,
+                         limited_disp=False, optimize_intrinsics=False)),
+    "n6_window_prior": (dict(n=6, height=96, width=128, radius=2, seed=13, depth_prior=True),
+                        dict(t0=3, t1=6, n_iters=2, pose_damping=1e-3, pose_ep=0.1, motion_only=False,
+                             limited_disp=False, optimize_intrinsics=False)),
+    "n5_backend_intr": (dict(n=5, height=96, width=128, radius=3, seed=17),
+                        dict(t0=1, t1=5, n_iters=2, pose_damping=1e-5, pose_ep=1e-2, motion_only=False,
+                             limited_disp=False, optimize_intrinsics=True)),
+    "n5_fixed_motion": (dict(n=5, height=96, width=128, radius=2, seed=19),
+                        dict(t0=2, t1=2, n_iters=2, pose_damping=1e-3, pose_ep=0.1, motion_only=False,
+                             limited_disp=False, optimize_intrinsics=False)),
+    "n6_infill_motion_limited": (dict(n=6, height=96, width=128, radius=2, seed=23),
+                                 dict(t0=4, t1=6, n_iters=2, pose_damping=1e-3, pose_ep=0.1, motion_only=True,
+                                      limited_disp=True, optimize_intrinsics=False)),
+    "n5_mei": (dict(n=5, height=96, width=128, radius=3, seed=29),
+               dict(t0=1, t1=5, n_iters=2, pose_damping=1e-3, pose_ep=0.1, motion_only=False,
+                    limited_disp=False, optimize_intrinsics=False, camera="mei", k1=0.35)),
+    "n5_mei_intr": (dict(n=5, height=96, width=128, radius=3, seed=37),
+                    dict(t0=1, t1=5, n_iters=2, pose_damping=1e-5, pose_ep=1e-2, motion_only=False,
+                         limited_disp=False, optimize_intrinsics=True, camera="mei", k1=0.05)),
+}
+
+
+def gen_ba(R):
+    out = {}
+    for name, (gk, bk) in BA_CASES.items():
+        g = make_graph(**gk)
+        intr = g.intrinsics
+        bk = dict(bk)
+        k1 = bk.pop("k1", None)
+        if bk.get("camera") == "mei":
+            intr = np.concatenate([intr, np.array([[k1]], dtype=np.float32)], axis=1)
+        p, d, k, en = reference_ba(R, g.poses, g.disps, g.disps_sens, intr, g.target, g.weight, g.eta, g.ii,
+                                   g.jj, **bk)
+        out[name + "/poses"] = p
+        out[name + "/disps"] = d
+        out[name + "/intrinsics"] = k
+        out[name + "/energy"] = en
+        print(name, "energy", en)
+    np.savez_compressed(os.path.join(HERE, "ba_reference.npz"), **out)
+
+
+def gen_reproject(R):
+    """geom.iproj_i_proj_j_disp values + Jacobians, pinhole and MEI (geom.py:187-298)."""
+    out = {}
+    for cam_name in ["pinhole", "mei"]:
+        g = make_graph(n=4, height=64, width=96, radius=2, seed=31)
+        cam = R.cameras.CameraType.PINHOLE if cam_name == "pinhole" else R.cameras.CameraType.MEI
+        intr = torch.tensor(g.intrinsics).float()
+        if cam_name == "mei":
+            intr = torch.cat([intr, torch.tensor([[0.35]])], 1)
+        intr8 = cam.build_camera_model(intr).scaled(1 / 8.0).intrinsics
+        ii, jj = torch.tensor(g.ii), torch.tensor(g.jj)
+        z = torch.zeros_like(ii)
+        x1, valid, (Ji, Jj, Jz), (Jfi, Jfj), _ = R.geom.iproj_i_proj_j_disp(
+            R.SE3(torch.tensor(g.poses)), torch.tensor(g.disps), None, intr8, cam,
+            R.SE3(torch.tensor([[0, 0, 0, 0, 0, 0, 1.0]])), ii, jj, z, z, ii,
+            jacobian_p_d=True, jacobian_f=True, jacobian_r=False)
+        for k, v in dict(coords=x1, valid=valid, Ji=Ji, Jj=Jj, Jz=Jz, Jfi=Jfi, Jfj=Jfj).items():
+            out[f"{cam_name}/{k}"] = _np(v)
+        out[f"{cam_name}/intr"] = _np(intr)
+    np.savez_compressed(os.path.join(HERE, "reproject_reference.npz"), **out)
+
+
+def gen_update_module(R):
+    """UpdateModule forward with seeded default-init weights (droid_net.py:432-499), fp32 CPU."""
+    torch.manual_seed(0)
+    um = R.droid_net.UpdateModule().eval()
+    E, ht, wd = 5, 12, 16
+    gen = torch.Generator().manual_seed(1)
+    net = torch.randn(1, E, 128, ht, wd, generator=gen).tanh()
+    inp = torch.randn(1, E, 128, ht, wd, generator=gen).relu()
+    corr = torch.randn(1, E, 196, ht, wd, generator=gen)
+    flow = torch.randn(1, E, 4, ht, wd, generator=gen) * 4
+    ix = torch.tensor([0, 0, 1, 2, 2])
+    with torch.no_grad():
+        net2, delta, weight, eta, upmask = um(net, inp, corr, flow, ix)
+    # weights and inputs are re-created from the seeds by the tests (same torch build); the fixture
+    # keeps per-tensor checksums of them plus the outputs (hidden state subsampled 1:4 in channels)
+    sd = {"sdsum/" + k: np.array([float(v.double().sum()), float(v.double().abs().sum())])
+          for k, v in um.state_dict().items()}
+    insum = np.array([float(t.double().sum()) for t in (net, inp, corr, flow)])
+    np.savez_compressed(os.path.join(HERE, "update_module_reference.npz"), input_sums=insum, ix=_np(ix),
+                        out_net_sub=_np(net2[:, :, ::4]), out_delta=_np(delta), out_weight=_np(weight),
+                        out_eta=_np(eta), out_upmask_sub=_np(upmask[:, :, ::16]), **sd)
+
+
+def gen_corr(R):
+    """CorrBlock volume + pyramid (droid_net.py:56-69,94-102) and AltCorrBlock pyramid (:130-142), fp32 CPU."""
+    gen = torch.Generator().manual_seed(2)
+    fmap1 = torch.randn(1, 1, 128, 16, 16, generator=gen)
+    fmap2 = torch.randn(1, 1, 128, 16, 16, generator=gen)
+    cb = R.droid_net.CorrBlock(fmap1, fmap2)  # 4 levels need H2, W2 >= 16 (the loop pools once more after the last level)
+    out = {"fmap1": _np(fmap1), "fmap2": _np(fmap2)}
+    for i, lvl in enumerate(cb.corr_pyramid):
+        out[f"level{i}"] = _np(lvl)
+    fm = torch.randn(1, 2, 128, 16, 16, generator=gen)
+    ab = R.droid_net.AltCorrBlock(fm)
+    out["alt_fmaps"] = _np(fm)
+    for i, lvl in enumerate(ab.pyramid):
+        out[f"alt_level{i}"] = _np(lvl)
+    np.savez_compressed(os.path.join(HERE, "corr_reference.npz"), **out)
+
+
+def gen_lie_wrapper(R):
+    """The reference's Python LieGroup wrapper over the (stubbed) backend: retr/adjT broadcasting semantics."""
+    rng = np.random.default_rng(5)
+    xi = torch.tensor(rng.normal(0, 0.3, (6, 6))).float()
+    X = R.SE3.exp(xi)
+    a = torch.tensor(rng.normal(0, 1, (6, 3, 2, 6))).float()
+    out = {"xi": _np(xi), "X": _np(X.data), "a": _np(a),
+           "adjT": _np(X[:, None, None].adjT(a)), "retr": _np(X.retr(xi * 0.1).data),
+           "inv": _np(X.inv().data), "mul": _np((X * X.inv()).data), "log": _np(X.log()),
+           "matrix": _np(X.matrix())}
+    np.savez_compressed(os.path.join(HERE, "lie_wrapper_reference.npz"), **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    R = load_reference()
+    gen_lie_wrapper(R)
+    gen_reproject(R)
+    gen_ba(R)
+    gen_update_module(R)
+    gen_corr(R)
+    print("golden fixtures written to", HERE)

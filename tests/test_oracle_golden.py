@@ -1,0 +1,212 @@
+"""Pin the CPU oracle against outputs of the reference's own Python (tests/golden/*.npz).
+
+The fixtures were produced by tests/golden/make_golden.py in the build container from
+/root/reference (loaded by path).  Nothing here reads /root/reference.
+"""
+
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ba, corr, geom, se3, update_module
+from vipe_amd.synth import make_graph
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+def _ba_cases():
+    src = open(os.path.join(GOLD, "make_golden.py")).read()
+    ns = {}
+    exec(src[src.index("BA_CASES = {"):src.index("def gen_ba")], ns)
+    return ns["BA_CASES"]
+
+
+BA_CASES = _ba_cases()
+
+
+def run_oracle_ba(name, dtype):
+    gk, bk = BA_CASES[name]
+    bk = dict(bk)
+    cam = bk.pop("camera", "pinhole")
+    k1 = bk.pop("k1", None)
+    g = make_graph(**gk)
+    intr = g.intrinsics
+    if cam == "mei":
+        intr = np.concatenate([intr, np.array([[k1]], dtype=np.float32)], axis=1)
+    E = len(g.ii)
+    return ba.bundle_adjustment(
+        g.poses, g.disps[:, None], g.disps_sens[:, None], intr, se3.se3_identity(1), g.target.reshape(E, -1, 2),
+        g.weight.reshape(E, -1, 2), g.eta[:, None], g.ii, g.jj, model=cam, dtype=dtype, **bk), g
+
+
+@pytest.mark.parametrize("name", sorted(BA_CASES))
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_ba_matches_reference_solver(name, dtype):
+    """north_star tolerance: 1e-4 relative on poses and inverse depth; the oracle sits ~1e-6 from the reference."""
+    G = np.load(os.path.join(GOLD, "ba_reference.npz"))
+    (p, d, k, _), g = run_oracle_ba(name, dtype)
+    rp, rd, rk = G[name + "/poses"], G[name + "/disps"], G[name + "/intrinsics"]
+    tol = 2e-5 if "mei_intr" not in name else 1e-4
+    assert np.abs(p - rp).max() <= tol * max(1.0, np.abs(rp).max())
+    assert np.abs(d[:, 0] - rd).max() <= tol * np.abs(rd).max()
+    assert np.abs(k - rk).max() <= 1e-4 * np.abs(rk).max()
+    # the step actually moved something (guards against a vacuous comparison)
+    assert np.abs(rp - g.poses).max() + np.abs(rd - g.disps).max() > 1e-3
+
+
+def test_ba_energy_decreases():
+    G = np.load(os.path.join(GOLD, "ba_reference.npz"))
+    for name in BA_CASES:
+        e = G[name + "/energy"]
+        assert e[-1] < e[0]
+    (p, d, k, r), g = run_oracle_ba("n5_frontend", np.float64)
+    e0 = ba.energy(g.poses, g.disps[:, None], g.intrinsics, se3.se3_identity(1), g.target, g.weight, g.ii, g.jj)
+    e1 = ba.energy(p, d, k, r, g.target, g.weight, g.ii, g.jj)
+    assert e1 < e0
+    # reference energy at the first iteration equals the oracle's initial energy (solver.py:133-134)
+    assert abs(e0 - G["n5_frontend/energy"][0]) < 1e-5 * e0
+
+
+@pytest.mark.parametrize("cam", ["pinhole", "mei"])
+def test_reproject_and_jacobians_match_reference(cam):
+    G = np.load(os.path.join(GOLD, "reproject_reference.npz"))
+    g = make_graph(n=4, height=64, width=96, radius=2, seed=31)
+    intr8 = geom.scaled_intrinsics(G[cam + "/intr"], 1 / 8.0, cam)
+    z = np.zeros_like(g.ii)
+    for dt, tol in ((np.float32, 1e-6), (np.float64, 2e-6)):
+        o = geom.reproject(g.poses.astype(dt), g.disps.astype(dt), intr8.astype(dt), se3.se3_identity(1, dt),
+                           g.ii, g.jj, z, z, g.ii, cam, True, True)
+        for key in ["coords", "valid", "Ji", "Jj", "Jz", "Jfi", "Jfj"]:
+            ref = G[cam + "/" + key]
+            assert np.abs(o[key].reshape(ref.shape) - ref).max() <= tol * (np.abs(ref).max() + 1e-30), key
+
+
+def test_lie_wrapper_semantics():
+    """Reference LieGroup wrapper (groups.py) over the oracle backend: retr = Exp(a)*X, adjT broadcasting."""
+    G = np.load(os.path.join(GOLD, "lie_wrapper_reference.npz"))
+    X, xi, a = G["X"], G["xi"], G["a"]
+    assert np.allclose(se3.se3_exp(xi), X, atol=1e-6)
+    assert np.allclose(se3.se3_adjT(X[:, None, None], a), G["adjT"], atol=1e-5)
+    assert np.allclose(se3.se3_retr(X, xi * np.float32(0.1)), G["retr"], atol=1e-6)
+    assert np.allclose(se3.se3_inv(X), G["inv"], atol=1e-6)
+    assert np.allclose(se3.se3_log(X), G["log"], atol=1e-5)
+    assert np.allclose(se3.se3_log(X), xi, atol=1e-5)
+    assert np.allclose(se3.se3_matrix(X), G["matrix"], atol=1e-6)
+    ident = se3.se3_mul(X, se3.se3_inv(X))
+    assert np.allclose(ident, G["mul"], atol=1e-6)
+    assert np.allclose(ident, se3.se3_identity(len(X)), atol=1e-6)
+
+
+def test_se3_fp64_identities():
+    """SE3 closed forms are pinned by group identities in fp64 (no reference binary exists)."""
+    rng = np.random.default_rng(0)
+    xi = rng.normal(0, 1.0, (1000, 6))
+    xi[:, 3:] *= np.minimum(1.0, 3.0 / np.linalg.norm(xi[:, 3:], axis=-1, keepdims=True))  # |phi| < pi
+    xi[:10, 3:] *= 1e-9  # theta < EPS Taylor branch (so3.h:139-146)
+    xi[10:20, 3:] *= np.pi / np.linalg.norm(xi[10:20, 3:], axis=-1, keepdims=True) * 0.999999  # theta ~ pi
+    X = se3.se3_exp(xi)
+    assert np.allclose(se3.se3_log(X), xi, atol=1e-6)
+    Y = se3.se3_exp(rng.normal(0, 1.0, (1000, 6)))
+    p = rng.normal(0, 1, (1000, 4))
+    lhs = se3.se3_act4(se3.se3_mul(X, Y), p)
+    rhs = se3.se3_act4(X, se3.se3_act4(Y, p))
+    assert np.allclose(lhs, rhs, atol=1e-9)
+    assert np.allclose(se3.se3_act4(se3.se3_inv(X), se3.se3_act4(X, p)), p, atol=1e-9)
+    # Adj(X) a = log(X exp(eps a) X^-1)/eps
+    a = rng.normal(0, 1, (1000, 6))
+    eps = 1e-6
+    conj = se3.se3_mul(se3.se3_mul(X, se3.se3_exp(eps * a)), se3.se3_inv(X))
+    assert np.allclose(se3.se3_log(conj) / eps, se3.se3_adj(X, a), atol=1e-4)
+    # adjT is the transpose
+    b = rng.normal(0, 1, (1000, 6))
+    assert np.allclose(np.sum(se3.se3_adjT(X, b) * a, -1), np.sum(b * se3.se3_adj(X, a), -1), atol=1e-9)
+    # homogeneous matrix agrees with the action
+    T = se3.se3_matrix(X)
+    p1 = np.concatenate([p[:, :3], np.ones((1000, 1))], -1)
+    assert np.allclose(np.einsum("nij,nj->ni", T, p1), se3.se3_act4(X, p1), atol=1e-9)
+
+
+def test_corr_pyramid_matches_reference():
+    G = np.load(os.path.join(GOLD, "corr_reference.npz"))
+    pyr = corr.corr_pyramid(torch.from_numpy(G["fmap1"]), torch.from_numpy(G["fmap2"]))
+    for i, lvl in enumerate(pyr):
+        assert np.allclose(lvl.numpy(), G[f"level{i}"], atol=1e-4, rtol=1e-5)
+    alt = corr.alt_pyramid(torch.from_numpy(G["alt_fmaps"]))
+    for i, lvl in enumerate(alt):
+        assert np.allclose(lvl.numpy(), G[f"alt_level{i}"], atol=1e-6)
+
+
+def test_corr_index_against_grid_sample():
+    """corr_index_forward == bilinear sampling (zero padding) of each [h2,w2] slab on a 7x7 window,
+    output index [i][j] = (x offset, y offset)  (correlation_kernels.cu:50-62)."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(3)
+    B, h1, w1, h2, w2, r = 2, 5, 6, 9, 11, 3
+    vol = rng.normal(0, 1, (B, h1, w1, h2, w2)).astype(np.float32)
+    coords = np.stack([rng.uniform(-4, w2 + 3, (B, h1, w1)), rng.uniform(-4, h2 + 3, (B, h1, w1))], 1).astype(np.float32)
+    out = corr.corr_index_forward(vol, coords, r)
+    v = torch.from_numpy(vol).reshape(B * h1 * w1, 1, h2, w2)
+    x0 = torch.from_numpy(coords[:, 0]).reshape(-1, 1, 1)
+    y0 = torch.from_numpy(coords[:, 1]).reshape(-1, 1, 1)
+    off = torch.arange(-r, r + 1).float()
+    gx = (x0 + off.view(1, -1, 1)).expand(-1, 7, 7)  # dim1 <-> x offset (i)
+    gy = (y0 + off.view(1, 1, -1)).expand(-1, 7, 7)  # dim2 <-> y offset (j)
+    grid = torch.stack([2 * gx / (w2 - 1) - 1, 2 * gy / (h2 - 1) - 1], -1)
+    ref = F.grid_sample(v, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+    ref = ref.reshape(B, h1, w1, 7, 7).permute(0, 3, 4, 1, 2).numpy()
+    assert np.allclose(out, ref, atol=2e-5)
+
+
+def test_corr_index_half_is_half_rounded_chain():
+    rng = np.random.default_rng(4)
+    vol = rng.normal(0, 1, (1, 3, 4, 8, 8)).astype(np.float16)
+    coords = np.stack([rng.uniform(0, 7, (1, 3, 4)), rng.uniform(0, 7, (1, 3, 4))], 1).astype(np.float32)
+    o16 = corr.corr_index_forward(vol, coords, 3)
+    o32 = corr.corr_index_forward(vol.astype(np.float32), coords, 3)
+    assert o16.dtype == np.float16
+    assert np.abs(o16.astype(np.float32) - o32).max() < 1e-2
+    assert np.abs(o16.astype(np.float32) - o32).max() > 0  # rounding order is observable
+
+
+def test_altcorr_equals_volume_lookup():
+    """altcorr_forward (no volume) == corr_index_forward on the explicit volume (fp32)."""
+    rng = np.random.default_rng(5)
+    B, H, W, C, r = 2, 4, 8, 64, 3
+    f1 = rng.normal(0, 1, (B, H, W, C)).astype(np.float32)
+    f2 = rng.normal(0, 1, (B, H, W, C)).astype(np.float32)
+    coords = np.stack([rng.uniform(-2, W + 1, (B, 1, H, W)), rng.uniform(-2, H + 1, (B, 1, H, W))], -1).astype(np.float32)
+    a = corr.altcorr_forward(f1, f2, coords, r)  # [B,1,49,H,W]
+    vol = np.einsum("bhwc,byxc->bhwyx", f1, f2)
+    c = corr.corr_index_forward(vol, np.ascontiguousarray(np.transpose(coords[:, 0], (0, 3, 1, 2))), r)
+    assert np.allclose(a[:, 0], c.reshape(B, 49, H, W), atol=1e-4)
+
+
+def test_update_module_matches_reference():
+    from vipe_amd.slam.networks import UpdateModule
+    G = np.load(os.path.join(GOLD, "update_module_reference.npz"))
+    torch.manual_seed(0)
+    um = UpdateModule().eval()
+    sd = um.state_dict()
+    for k, v in sd.items():
+        ref = G["sdsum/" + k]
+        assert abs(float(v.double().sum()) - ref[0]) < 1e-6 * max(1, ref[1]), k
+    E, ht, wd = 5, 12, 16
+    gen = torch.Generator().manual_seed(1)
+    net = torch.randn(1, E, 128, ht, wd, generator=gen).tanh()
+    inp = torch.randn(1, E, 128, ht, wd, generator=gen).relu()
+    cor = torch.randn(1, E, 196, ht, wd, generator=gen)
+    flow = torch.randn(1, E, 4, ht, wd, generator=gen) * 4
+    for t, s in zip((net, inp, cor, flow), G["input_sums"]):
+        assert abs(float(t.double().sum()) - s) < 1e-6 * t.numel()
+    ix = torch.from_numpy(G["ix"])
+    with torch.no_grad():
+        n2, delta, weight, eta, upmask = update_module.update_forward(sd, net, inp, cor, flow, ix)
+    assert np.allclose(n2[:, :, ::4].numpy(), G["out_net_sub"], atol=2e-5)
+    assert np.allclose(delta.numpy(), G["out_delta"], atol=2e-5)
+    assert np.allclose(weight.numpy(), G["out_weight"], atol=2e-5)
+    assert np.allclose(eta.numpy(), G["out_eta"], atol=2e-6)
+    assert np.allclose(upmask[:, :, ::16].numpy(), G["out_upmask_sub"], atol=2e-5)

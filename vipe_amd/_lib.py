@@ -1,0 +1,116 @@
+"""ctypes binding of libvipe_amd.so (the C ABI declared in include/vipe_amd.h).
+
+The prototypes are parsed from the header itself, so the Python side cannot drift from the ABI.
+There is NO fallback: if the library is missing, `lib()` raises with the build command.
+"""
+
+import ctypes
+import os
+import re
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(HERE), "include", "vipe_amd.h")
+LIB_PATH = os.path.join(HERE, "lib", "libvipe_amd.so")
+
+F16, F32, F64 = 0, 1, 2
+DTYPE_CODE = {torch.float16: F16, torch.float32: F32, torch.float64: F64}
+CAMERA_CODE = {"pinhole": 0, "mei": 1}
+
+
+class BAParams(ctypes.Structure):
+    """vipe_ba_params (include/vipe_amd.h)."""
+
+    _fields_ = [
+        ("n_poses", ctypes.c_int), ("n_views", ctypes.c_int), ("ht", ctypes.c_int), ("wd", ctypes.c_int),
+        ("M", ctypes.c_int), ("t0", ctypes.c_int), ("t1", ctypes.c_int), ("n_iters", ctypes.c_int),
+        ("pose_damping", ctypes.c_float), ("pose_ep", ctypes.c_float), ("motion_only", ctypes.c_int),
+        ("limited_disp", ctypes.c_int), ("optimize_intrinsics", ctypes.c_int),
+        ("optimize_rig_rotation", ctypes.c_int), ("camera", ctypes.c_int), ("alpha", ctypes.c_float),
+        ("weight_scale", ctypes.c_float), ("intr_factor", ctypes.c_float),
+    ]
+
+
+_SCALARS = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "double": ctypes.c_double}
+
+
+def _ctype_of(decl):
+    decl = decl.strip()
+    if "*" in decl:
+        if "vipe_ba_params" in decl:
+            return ctypes.POINTER(BAParams)
+        return ctypes.c_void_p  # every other pointer (device or host array) is passed as an address
+    base = decl.replace("const", "").split()[0]
+    return _SCALARS[base]
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [argtypes])} for every function declared in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    src = re.sub(r"typedef\s+struct\s*\{.*?\}\s*\w+\s*;", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int64_t|int|const char\*)\s+(vipe_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.groups()
+        args = args.strip()
+        argtypes = [] if args in ("", "void") else [_ctype_of(a) for a in args.split(",")]
+        restype = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "const char*": ctypes.c_char_p}[ret]
+        protos[name] = (restype, argtypes)
+    return protos
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing - the HIP backend is mandatory (there is no CPU fallback). "
+                "Build it with `python -m vipe_amd.build` (hipcc --offload-arch=gfx950).")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in parse_header().items():
+            fn = getattr(L, name)  # AttributeError here means header and library disagree
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _LIB = L
+    return _LIB
+
+
+class VipeError(RuntimeError):
+    pass
+
+
+def check(code, what):
+    if code == 0:
+        return
+    names = {-1: "VIPE_EINVAL (bad argument)", -2: "VIPE_ENOSPACE (workspace too small)",
+             -3: "VIPE_EUNSUPPORTED (not implemented in this build)"}
+    if code == -3:
+        raise NotImplementedError(f"{what}: {names[code]}")
+    raise VipeError(f"{what}: {names.get(code, f'hipError_t {code}')}")
+
+
+def stream_ptr(t=None):
+    """hipStream_t of torch's current stream on the tensor's device."""
+    dev = t.device if t is not None else None
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def require(cond, msg):
+    """TORCH_CHECK equivalent (the reference raises RuntimeError, droid.cpp:10-11)."""
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def check_gpu_contig(*tensors):
+    for t in tensors:
+        require(t.is_cuda, "tensor must be a CUDA (HIP) tensor")
+        require(t.is_contiguous(), "tensor must be contiguous")

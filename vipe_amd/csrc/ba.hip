@@ -1,0 +1,787 @@
+// Dense bundle adjustment on SE3 (+) per-pixel inverse depth (+ focal / distortion), Gauss-Newton with
+// Schur reduction and a dense block Cholesky, entirely on the device.
+//
+// Replaces the reference's LIVE Python solver: GraphBuffer.bundle_adjustment (components/buffer.py:373-525)
+// -> Solver.run_inplace (ba/solver.py:117-197) -> DenseDepthFlowTerm / DispSensRegularizationTerm
+// (ba/terms.py:94-303) -> geom.iproj_i_proj_j_disp (maths/geom.py:187-298) -> block-sparse products with
+// host round trips (maths/matrix.py:66-81) -> scipy spsolve on the CPU (solver.py:33-44).
+//
+// MI355X design (one GN iteration = 3 launches, no host sync):
+//   ba_accum_kernel   grid (pixel tiles, source frames).  One lane owns pixel p of source frame k and walks
+//                     ALL terms (edges) whose source is k (device-built CSR), so the per-pixel quantities
+//                     C_k, w_k, E_kk stay in registers and are final when the walk ends; Jacobians never
+//                     touch memory.  J^T W J blocks are reduced with wave shuffles (64 lanes), combined
+//                     across the block's 4 waves in LDS and added to the dense reduced system in fp64.
+//                     The Schur complement of frame k (all member pairs of k) is formed by the same lanes
+//                     right after the walk, from registers + the term's E_j rows it just wrote.
+//   ba_solve_kernel   one workgroup: LM damping, blocked (6-wide) right-looking Cholesky in fp64 with the
+//                     rhs carried as an extra matrix row (forward substitution for free), blocked backward
+//                     substitution, pose / intrinsics retraction.
+//   ba_retract_kernel per pixel dz = (w - sum_a E_ak^T dx_a)/C, d += dz (dz > 10 rejected).
+#include "term_geom.cuh"
+
+namespace {
+
+constexpr int TILE = 256;   // lanes per workgroup = pixels per tile
+constexpr int NWAVE = TILE / WAVE;
+constexpr int TCHUNK = 8;   // terms whose transforms are staged in LDS at a time
+
+struct BAWs {
+  int* rowptr;      // [nF+1] CSR over source disparity frames
+  int* order;       // [M] term ids sorted by source frame (stable)
+  int* pose_slot;   // [nP] slot in the reduced system or -1
+  int* slot_pose;   // [nP] inverse map
+  int* fflags;      // [nF] bit0 source, bit1 disparity free, bit2 sensor prior
+  int* scratch;     // [2*nP + nF]
+  int* info;        // [8] n_free, n_free_disp, chol_fail, n_unknowns
+  float* sens_sum;  // [nF]
+  float* C;         // [nF,P] damped disparity diagonal
+  float* wv;        // [nF,P]
+  float* Ekk;       // [nF,6,P]
+  float* Ef;        // [nF,2,P]
+  float* Ej;        // [M,6,P]
+  double* S;        // [(nmax+1),(nmax+1)] lower triangle + rhs row
+  double* Hd;       // [nmax] undamped diagonal of H (for lambda * diag)
+  float* dx;        // [nmax]
+  int ld;           // nmax + 1
+};
+
+struct BAArgs {
+  vipe_ba_params p;
+  float *poses, *disps, *intr, *rig;
+  const float *sens, *target, *weight, *eta;
+  const int64_t *pi, *qi, *pj, *qj, *di;
+  BAWs w;
+  int P, nF, D;
+};
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+size_t carve(const vipe_ba_params& p, char* base, BAWs* out) {
+  const size_t nP = p.n_poses, nF = (size_t)p.n_poses * p.n_views, P = (size_t)p.ht * p.wd, M = p.M;
+  const size_t nmax = 6 * nP + 2;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* ptr = base ? base + off : nullptr;
+    off += align_up(bytes);
+    return ptr;
+  };
+  BAWs w;
+  w.rowptr = (int*)take(4 * (nF + 1));
+  w.order = (int*)take(4 * (M + 1));
+  w.pose_slot = (int*)take(4 * nP);
+  w.slot_pose = (int*)take(4 * nP);
+  w.fflags = (int*)take(4 * nF);
+  w.scratch = (int*)take(4 * (2 * nP + nF));
+  w.info = (int*)take(4 * 8);
+  w.sens_sum = (float*)take(4 * nF);
+  w.C = (float*)take(4 * nF * P);
+  w.wv = (float*)take(4 * nF * P);
+  w.Ekk = (float*)take(4 * nF * 6 * P);
+  w.Ef = (float*)take(4 * nF * 2 * P);
+  w.Ej = (float*)take(4 * (M + 1) * 6 * P);
+  w.S = (double*)take(8 * (nmax + 1) * (nmax + 1));
+  w.Hd = (double*)take(8 * nmax);
+  w.dx = (float*)take(4 * nmax);
+  w.ld = (int)(nmax + 1);
+  if (out) *out = w;
+  return off;
+}
+
+// ------------------------------------------------------------------------------------------------ plan
+
+__global__ __launch_bounds__(256) void ba_sens_kernel(const float* __restrict__ sens, float* __restrict__ out, int P) {
+  // buffer.py:470-471: frames whose sensor disparity sums to > 0
+  const int k = blockIdx.x;
+  float s = 0.f;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) s += sens[(int64_t)k * P + p];
+  s = wave_sum(s);
+  __shared__ float red[NWAVE];
+  if (lane_id() == 0) red[wave_id()] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[k] = red[0] + red[1] + red[2] + red[3];
+}
+
+// exclusive scan of v[0..n) in place with 1024 threads; returns the total (all threads)
+__device__ int block_scan_excl(int* v, int n, int* lds /* [1024] */) {
+  const int t = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int b = t * per;
+  int s = 0;
+  for (int i = b; i < b + per && i < n; ++i) s += v[i];
+  lds[t] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    int x = t >= o ? lds[t - o] : 0;
+    __syncthreads();
+    lds[t] += x;
+    __syncthreads();
+  }
+  int run = t > 0 ? lds[t - 1] : 0;
+  const int total = lds[1023];
+  for (int i = b; i < b + per && i < n; ++i) {
+    int c = v[i];
+    v[i] = run;
+    run += c;
+  }
+  __syncthreads();
+  return total;
+}
+
+__global__ __launch_bounds__(1024) void ba_plan_kernel(BAArgs a) {
+  const vipe_ba_params& p = a.p;
+  const int t = threadIdx.x;
+  const int nP = p.n_poses, nF = a.nF, M = p.M, V = p.n_views;
+  int* cnt = a.w.scratch;           // [nF]
+  int* is_src = cnt + nF;           // [nP]
+  int* used = is_src + nP;          // [nP]
+  __shared__ int lds[1024];
+  __shared__ int stage[4096];
+  for (int i = t; i < nF; i += 1024) cnt[i] = 0;
+  for (int i = t; i < nP; i += 1024) { is_src[i] = 0; used[i] = 0; }
+  __syncthreads();
+  for (int e = t; e < M; e += 1024) {
+    atomicAdd(&cnt[(int)a.di[e]], 1);
+    is_src[(int)a.pi[e]] = 1;
+    used[(int)a.pi[e]] = 1;
+    used[(int)a.pj[e]] = 1;
+  }
+  __syncthreads();
+  // frame flags before cnt is turned into offsets
+  const bool all_fixed = !(p.t0 < p.t1);
+  int nfd_local = 0;
+  for (int k = t; k < nF; k += 1024) {
+    const int pose = k / V;
+    int f = cnt[k] > 0 ? 1 : 0;
+    bool dfree = f && !p.motion_only && !(p.limited_disp && (pose < p.t0 || pose >= p.t1));  // buffer.py:490-493
+    if (dfree) { f |= 2; ++nfd_local; }
+    if (dfree && a.w.sens_sum[k] > 0.0f) f |= 4;
+    a.w.fflags[k] = f;
+  }
+  // rowptr = exclusive scan of counts
+  for (int i = t; i < nF; i += 1024) a.w.rowptr[i] = cnt[i];
+  __syncthreads();
+  const int total = block_scan_excl(a.w.rowptr, nF, lds);
+  if (t == 0) a.w.rowptr[nF] = total;
+  // pose slots (buffer.py:462-465: fixed iff it is a source pose outside [t0,t1); t0 == t1 fixes all)
+  for (int i = t; i < nP; i += 1024) {
+    const bool fixed = all_fixed || (is_src[i] && (i < p.t0 || i >= p.t1));
+    a.w.pose_slot[i] = (used[i] && !fixed) ? 1 : 0;
+  }
+  __syncthreads();
+  for (int i = t; i < nP; i += 1024) is_src[i] = a.w.pose_slot[i];  // keep the 0/1 flags
+  __syncthreads();
+  const int n_free = block_scan_excl(a.w.pose_slot, nP, lds);
+  for (int i = t; i < nP; i += 1024) {
+    if (is_src[i]) a.w.slot_pose[a.w.pose_slot[i]] = i;
+    else a.w.pose_slot[i] = -1;
+  }
+  // count free disparity frames
+  lds[t] = nfd_local;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (t < o) lds[t] += lds[t + o];
+    __syncthreads();
+  }
+  if (t == 0) {
+    const int F = p.optimize_intrinsics ? 1 + a.D : 0;
+    a.w.info[0] = n_free;
+    a.w.info[1] = lds[0];
+    a.w.info[2] = 0;
+    a.w.info[3] = 6 * n_free + F;
+  }
+  // stable counting sort of the terms by source frame: frame k's owner scans the term list in order
+  // (cursor kept in cnt[]: reuse cnt as the running write position)
+  __syncthreads();
+  for (int k = t; k < nF; k += 1024) cnt[k] = a.w.rowptr[k];
+  for (int c0 = 0; c0 < M; c0 += 4096) {
+    const int nc = min(4096, M - c0);
+    __syncthreads();
+    for (int i = t; i < nc; i += 1024) stage[i] = (int)a.di[c0 + i];
+    __syncthreads();
+    for (int k = t; k < nF; k += 1024) {
+      if (!(a.w.fflags[k] & 1)) continue;
+      int pos = cnt[k];
+      for (int i = 0; i < nc; ++i)
+        if (stage[i] == k) a.w.order[pos++] = c0 + i;
+      cnt[k] = pos;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ accumulate
+
+// lower-triangle index table for symmetric 6x6 (21 entries): (r,c), r >= c
+__device__ __constant__ int8_t SYM_R[21] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5};
+__device__ __constant__ int8_t SYM_C[21] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5};
+
+__device__ __forceinline__ void s_add(const BAWs& w, int row, int col, double v) {
+  // lower triangle storage: (row, col) with row >= col
+  if (row < col) { int tmp = row; row = col; col = tmp; }
+  atomicAdd(&w.S[(int64_t)row * w.ld + col], v);
+}
+
+// Reduce vals[0..N) over the workgroup; lane `i` of the first N lanes receives the sum of value i.
+template <int N>
+__device__ __forceinline__ float block_reduce(float (&vals)[N], float* red /* [NWAVE][N] */) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) vals[i] = wave_sum(vals[i]);
+  __syncthreads();  // previous consumers of `red` are done
+  if (lane_id() == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) red[wave_id() * N + i] = vals[i];
+  }
+  __syncthreads();
+  float s = 0.f;
+  if ((int)threadIdx.x < N) {
+#pragma unroll
+    for (int wv = 0; wv < NWAVE; ++wv) s += red[wv * N + threadIdx.x];
+  }
+  return s;
+}
+
+template <int CAM, int F>
+__global__ __launch_bounds__(TILE) void ba_accum_kernel(BAArgs a) {
+  constexpr int FF = F > 0 ? F : 1;
+  constexpr int NT = 63 + 6 * F;                          // per-term reduced values
+  constexpr int NK = 27 + 6 * F + F * (F + 1) / 2 + F;    // per-frame reduced values
+  constexpr int NRED = NT > NK ? NT : NK;
+  const vipe_ba_params& prm = a.p;
+  const BAWs& w = a.w;
+  const int k = blockIdx.y;
+  const int beg = w.rowptr[k], end = w.rowptr[k + 1];
+  if (beg == end) return;
+  const int P = a.P, V = prm.n_views, tid = threadIdx.x;
+  const int p_raw = blockIdx.x * TILE + tid;
+  const bool inb = p_raw < P;
+  const int p = inb ? p_raw : P - 1;
+  const int flags = w.fflags[k];
+  const bool dfree = flags & 2;
+  const int pose_i = k / V, qi = k % V;
+  const int si = w.pose_slot[pose_i];
+  const int n_free = w.info[0], nrow = w.info[3];
+  const int foff = 6 * n_free;
+
+  __shared__ TermGeom tg[TCHUNK];
+  __shared__ float red[NWAVE * NRED];
+
+  const cam::Intr Ii = cam::load_scaled(a.intr + qi * (4 + a.D), a.D, 1.0f / prm.intr_factor);
+  const float u = (float)(p % prm.wd), v = (float)(p / prm.wd);
+  const float d = a.disps[(int64_t)k * P + p];
+  float X0, Y0, dX0[FF], dY0[FF];
+  cam::iproj<CAM, F>(Ii, u, v, X0, Y0, dX0, dY0);
+
+  float C = 0.f, wz = 0.f, Ei[6] = {0, 0, 0, 0, 0, 0}, Efr[FF] = {};
+  float hii[21] = {}, vi[6] = {}, hif[6 * FF] = {}, hff[3] = {}, vf[FF] = {};
+
+  for (int c0 = beg; c0 < end; c0 += TCHUNK) {
+    const int nt = min(TCHUNK, end - c0);
+    __syncthreads();
+    if (tid < nt) {
+      const int e = w.order[c0 + tid];
+      const int pi = (int)a.pi[e], pj = (int)a.pj[e], qj = (int)a.qj[e];
+      TermGeom g;
+      term_transforms(a.poses, a.rig, pi, (int)a.qi[e], pj, qj, g.T, g.G, g.Rr);
+      g.Ij = cam::load_scaled(a.intr + qj * (4 + a.D), a.D, 1.0f / prm.intr_factor);
+      g.e = e;
+      g.merge = (pi == pj);
+      g.rig_adj = !(g.Rr.t[0] == 0.f && g.Rr.t[1] == 0.f && g.Rr.t[2] == 0.f && g.Rr.R[0] == 1.f &&
+                    g.Rr.R[4] == 1.f && g.Rr.R[8] == 1.f);
+      g.sj = g.merge ? -1 : w.pose_slot[pj];
+      tg[tid] = g;
+    }
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+      const TermGeom& G = tg[t];
+      const int e = G.e;
+      // ---- forward: X1 = T X0, projection, residual, weight
+      const float X = G.T.R[0] * X0 + G.T.R[1] * Y0 + G.T.R[2] + G.T.t[0] * d;
+      const float Y = G.T.R[3] * X0 + G.T.R[4] * Y0 + G.T.R[5] + G.T.t[1] * d;
+      const float Z = G.T.R[6] * X0 + G.T.R[7] * Y0 + G.T.R[8] + G.T.t[2] * d;
+      float x, y, Jp[2][3], Jfj[2][FF];
+      cam::proj<CAM, true, F>(G.Ij, X, Y, Z, x, y, Jp, Jfj);
+      const int64_t o2 = ((int64_t)e * P + p) * 2;
+      const float2 tgt = *reinterpret_cast<const float2*>(a.target + o2);
+      const float2 wg = *reinterpret_cast<const float2*>(a.weight + o2);
+      const float val = (inb && Z > cam::MIN_DEPTH) ? prm.weight_scale : 0.0f;  // geom.py:263, buffer.py:413
+      const float wc[2] = {val * wg.x, val * wg.y};
+      const float rc[2] = {x - tgt.x, y - tgt.y};
+      // ---- Jacobians (geom.py:114-145, 271-281)
+      float Ja[3][6] = {{d, 0, 0, 0, Z, -Y}, {0, d, 0, -Z, 0, X}, {0, 0, d, Y, -X, 0}};
+      if (G.rig_adj) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          float tmp[6];
+          adjT_apply(G.Rr, Ja[r], tmp);
+#pragma unroll
+          for (int q = 0; q < 6; ++q) Ja[r][q] = tmp[q];
+        }
+      }
+      float Jj[2][6], Ji[2][6], Jz[2], Jf[2][FF];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Jj[c][q] = Jp[c][0] * Ja[0][q] + Jp[c][1] * Ja[1][q] + Jp[c][2] * Ja[2][q];
+        float tmp[6];
+        adjT_apply(G.G, Jj[c], tmp);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Ji[c][q] = -tmp[q];
+        Jz[c] = Jp[c][0] * G.T.t[0] + Jp[c][1] * G.T.t[1] + Jp[c][2] * G.T.t[2];
+        if constexpr (F > 0) {
+#pragma unroll
+          for (int f = 0; f < F; ++f) {
+            // Jfi = Jp . (R_T dX0/df)  (geom.py:286-288), Jfj from the target camera; J_scale 1/8 (terms.py:224-227)
+            const float ax = G.T.R[0] * dX0[f] + G.T.R[1] * dY0[f];
+            const float ay = G.T.R[3] * dX0[f] + G.T.R[4] * dY0[f];
+            const float az = G.T.R[6] * dX0[f] + G.T.R[7] * dY0[f];
+            Jf[c][f] = (Jp[c][0] * ax + Jp[c][1] * ay + Jp[c][2] * az + Jfj[c][f]) * (1.0f / prm.intr_factor);
+          }
+        }
+      }
+      if (G.merge) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int q = 0; q < 6; ++q) Ji[c][q] += Jj[c][q];
+      }
+      const bool fi = si >= 0, fj = G.sj >= 0;
+      // ---- per-pixel disparity quantities (kept in registers across the walk)
+      const float wJz[2] = {wc[0] * Jz[0], wc[1] * Jz[1]};
+      if (dfree) {
+        C += wJz[0] * Jz[0] + wJz[1] * Jz[1];
+        wz -= wJz[0] * rc[0] + wJz[1] * rc[1];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Ei[q] += Ji[0][q] * wJz[0] + Ji[1][q] * wJz[1];
+        if constexpr (F > 0) {
+#pragma unroll
+          for (int f = 0; f < F; ++f) Efr[f] += Jf[0][f] * wJz[0] + Jf[1][f] * wJz[1];
+        }
+        if (fj && inb) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q)
+            w.Ej[((int64_t)e * 6 + q) * P + p] = Jj[0][q] * wJz[0] + Jj[1][q] * wJz[1];
+        }
+      }
+      // ---- frame-level Hessian pieces (pose i, intrinsics)
+      if (fi) {
+#pragma unroll
+        for (int s = 0; s < 21; ++s) {
+          const int r = SYM_R[s], c = SYM_C[s];
+          hii[s] += wc[0] * Ji[0][r] * Ji[0][c] + wc[1] * Ji[1][r] * Ji[1][c];
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) vi[q] -= wc[0] * rc[0] * Ji[0][q] + wc[1] * rc[1] * Ji[1][q];
+        if constexpr (F > 0) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int f = 0; f < F; ++f) hif[q * F + f] += wc[0] * Ji[0][q] * Jf[0][f] + wc[1] * Ji[1][q] * Jf[1][f];
+        }
+      }
+      if constexpr (F > 0) {
+        int s = 0;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+#pragma unroll
+          for (int f2 = 0; f2 <= f; ++f2) hff[s++] += wc[0] * Jf[0][f] * Jf[0][f2] + wc[1] * Jf[1][f] * Jf[1][f2];
+          vf[f] -= wc[0] * rc[0] * Jf[0][f] + wc[1] * rc[1] * Jf[1][f];
+        }
+      }
+      // ---- per-term blocks: H_ij, H_jj, v_j, H_jf  -> reduce over the tile, add in fp64
+      if (fj) {
+        float tv[NT];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = 0; c < 6; ++c)
+            tv[r * 6 + c] = fi ? (wc[0] * Ji[0][r] * Jj[0][c] + wc[1] * Ji[1][r] * Jj[1][c]) : 0.0f;
+#pragma unroll
+        for (int s = 0; s < 21; ++s) {
+          const int r = SYM_R[s], c = SYM_C[s];
+          tv[36 + s] = wc[0] * Jj[0][r] * Jj[0][c] + wc[1] * Jj[1][r] * Jj[1][c];
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) tv[57 + q] = -(wc[0] * rc[0] * Jj[0][q] + wc[1] * rc[1] * Jj[1][q]);
+        if constexpr (F > 0) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int f = 0; f < F; ++f)
+              tv[63 + q * F + f] = wc[0] * Jj[0][q] * Jf[0][f] + wc[1] * Jj[1][q] * Jf[1][f];
+        }
+        const float s = block_reduce<NT>(tv, red);
+        const int bj = 6 * G.sj, bi = 6 * si;
+        if (tid < 36) {
+          if (fi) s_add(w, bi + tid / 6, bj + tid % 6, (double)s);
+        } else if (tid < 57) {
+          const int r = SYM_R[tid - 36], c = SYM_C[tid - 36];
+          s_add(w, bj + r, bj + c, (double)s);
+          if (r == c) atomicAdd(&w.Hd[bj + r], (double)s);
+        } else if (tid < 63) {
+          atomicAdd(&w.S[(int64_t)nrow * w.ld + bj + (tid - 57)], (double)s);
+        } else if (tid < NT) {
+          const int q = (tid - 63) / FF, f = (tid - 63) % FF;
+          s_add(w, foff + f, bj + q, (double)s);
+        }
+      }
+    }
+  }
+
+  // ---- frame-level reduction: H_ii, v_i, H_if, H_ff, v_f
+  {
+    float kv[NK];
+#pragma unroll
+    for (int s = 0; s < 21; ++s) kv[s] = hii[s];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) kv[21 + q] = vi[q];
+    if constexpr (F > 0) {
+#pragma unroll
+      for (int q = 0; q < 6 * F; ++q) kv[27 + q] = hif[q];
+#pragma unroll
+      for (int q = 0; q < F * (F + 1) / 2; ++q) kv[27 + 6 * F + q] = hff[q];
+#pragma unroll
+      for (int f = 0; f < F; ++f) kv[27 + 6 * F + F * (F + 1) / 2 + f] = vf[f];
+    }
+    const float s = block_reduce<NK>(kv, red);
+    const int bi = 6 * si;
+    if (tid < 21) {
+      if (si >= 0) {
+        const int r = SYM_R[tid], c = SYM_C[tid];
+        s_add(w, bi + r, bi + c, (double)s);
+        if (r == c) atomicAdd(&w.Hd[bi + r], (double)s);
+      }
+    } else if (tid < 27) {
+      if (si >= 0) atomicAdd(&w.S[(int64_t)nrow * w.ld + bi + (tid - 21)], (double)s);
+    } else if (tid < NK) {
+      if constexpr (F > 0) {
+        int i2 = tid - 27;
+        if (i2 < 6 * F) {
+          if (si >= 0) s_add(w, foff + i2 % F, bi + i2 / F, (double)s);
+        } else if (i2 < 6 * F + F * (F + 1) / 2) {
+          i2 -= 6 * F;
+          const int f = i2 == 0 ? 0 : (i2 == 1 ? 1 : 1), f2 = i2 == 0 ? 0 : (i2 == 1 ? 0 : 1);
+          s_add(w, foff + f, foff + f2, (double)s);
+          if (f == f2) atomicAdd(&w.Hd[foff + f], (double)s);
+        } else {
+          i2 -= 6 * F + F * (F + 1) / 2;
+          atomicAdd(&w.S[(int64_t)nrow * w.ld + foff + i2], (double)s);
+        }
+      }
+    }
+  }
+
+  if (!dfree) return;
+  // ---- finish the disparity block of this pixel: sensor prior, damping (terms.py:258-268, buffer.py:482-489)
+  const int64_t kp = (int64_t)k * P + p;
+  if (flags & 4) {
+    C += prm.alpha;
+    wz -= prm.alpha * (d - a.sens[kp]);
+  }
+  C += 1e-7f + (0.2f * a.eta[kp] + 1e-7f);
+  const float Q = inb ? 1.0f / C : 0.0f;
+  if (inb) {
+    w.C[kp] = C;
+    w.wv[kp] = wz;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) w.Ekk[((int64_t)k * 6 + q) * P + p] = Ei[q];
+    if constexpr (F > 0) {
+#pragma unroll
+      for (int f = 0; f < F; ++f) w.Ef[((int64_t)k * 2 + f) * P + p] = Efr[f];
+    }
+  }
+
+  // ---- Schur complement of frame k: S -= E_a Q E_b^T, g -= E_a Q w over all member pairs (solver.py:176-178)
+  // members: 0 = pose i, 1..deg = target poses of the terms, deg+1 = intrinsics
+  const int deg = end - beg;
+  const int nm = deg + 2;
+  for (int ma = 0; ma < nm; ++ma) {
+    float Ea[6] = {0, 0, 0, 0, 0, 0};
+    int base_a = -1, dim_a = 6;
+    if (ma == 0) {
+      if (si >= 0) { base_a = 6 * si;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Ea[q] = Ei[q]; }
+    } else if (ma == deg + 1) {
+      if constexpr (F > 0) { base_a = foff; dim_a = F;
+#pragma unroll
+        for (int f = 0; f < F; ++f) Ea[f] = Efr[f]; }
+    } else {
+      const int e = w.order[beg + ma - 1];
+      const int pj = (int)a.pj[e];
+      const int sj = ((int)a.pi[e] == pj) ? -1 : w.pose_slot[pj];
+      if (sj >= 0) { base_a = 6 * sj;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Ea[q] = inb ? w.Ej[((int64_t)e * 6 + q) * P + p] : 0.0f; }
+    }
+    if (base_a < 0) continue;  // wave-uniform
+    float EaQ[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) EaQ[q] = Ea[q] * Q;
+    {
+      float gv[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) gv[q] = EaQ[q] * wz;
+      const float s = block_reduce<6>(gv, red);
+      if (tid < dim_a) atomicAdd(&w.S[(int64_t)nrow * w.ld + base_a + tid], -(double)s);
+    }
+    for (int mb = ma; mb < nm; ++mb) {
+      float Eb[6] = {0, 0, 0, 0, 0, 0};
+      int base_b = -1, dim_b = 6;
+      if (mb == ma) {
+        base_b = base_a; dim_b = dim_a;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Eb[q] = Ea[q];
+      } else if (mb == deg + 1) {
+        if constexpr (F > 0) { base_b = foff; dim_b = F;
+#pragma unroll
+          for (int f = 0; f < F; ++f) Eb[f] = Efr[f]; }
+      } else {
+        const int e = w.order[beg + mb - 1];
+        const int pj = (int)a.pj[e];
+        const int sj = ((int)a.pi[e] == pj) ? -1 : w.pose_slot[pj];
+        if (sj >= 0) { base_b = 6 * sj;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) Eb[q] = inb ? w.Ej[((int64_t)e * 6 + q) * P + p] : 0.0f; }
+      }
+      if (base_b < 0) continue;
+      float pr[36];
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) pr[r * 6 + c] = EaQ[r] * Eb[c];
+      const float s = block_reduce<36>(pr, red);
+      if (tid < 36) {
+        const int r = tid / 6, c = tid % 6;
+        if (r < dim_a && c < dim_b) {
+          const int gr = base_a + r, gc = base_b + c;
+          if (ma != mb || r >= c) s_add(w, gr, gc, -(double)s);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ solve
+
+__global__ __launch_bounds__(1024) void ba_solve_kernel(BAArgs a) {
+  const vipe_ba_params& prm = a.p;
+  const BAWs& w = a.w;
+  const int t = threadIdx.x;
+  const int n = w.info[3], n_free = w.info[0];
+  const int ld = w.ld;
+  double* S = w.S;
+  __shared__ double Lkk[6][6];
+  __shared__ double xk[6];
+  __shared__ int fail;
+  if (t == 0) fail = 0;
+  if (n == 0) return;
+  // LM damping on the diagonal: += ep + lambda * diag(H)  (matrix.py:179-186)
+  for (int dd = t; dd < n; dd += 1024) {
+    const bool pose = dd < 6 * n_free;
+    const double ep = pose ? (double)prm.pose_ep : 1e-6, lam = pose ? (double)prm.pose_damping : 1e-6;
+    S[(int64_t)dd * ld + dd] += ep + lam * w.Hd[dd];
+  }
+  __syncthreads();
+  // blocked right-looking Cholesky of the lower triangle; row n carries the rhs (=> y = L^-1 g)
+  for (int k0 = 0; k0 < n; k0 += 6) {
+    const int bw = min(6, n - k0);
+    if (t == 0) {
+      double A[6][6];
+      for (int r = 0; r < bw; ++r)
+        for (int c = 0; c <= r; ++c) A[r][c] = S[(int64_t)(k0 + r) * ld + k0 + c];
+      for (int j = 0; j < bw; ++j) {
+        double dj = A[j][j];
+        for (int m = 0; m < j; ++m) dj -= A[j][m] * A[j][m];
+        if (!(dj > 0.0)) { fail = 1; dj = 1.0; }
+        const double l = sqrt(dj);
+        A[j][j] = l;
+        for (int r = j + 1; r < bw; ++r) {
+          double s = A[r][j];
+          for (int m = 0; m < j; ++m) s -= A[r][m] * A[j][m];
+          A[r][j] = s / l;
+        }
+      }
+      for (int r = 0; r < bw; ++r)
+        for (int c = 0; c <= r; ++c) {
+          Lkk[r][c] = A[r][c];
+          S[(int64_t)(k0 + r) * ld + k0 + c] = A[r][c];
+        }
+    }
+    __syncthreads();
+    const int r0 = k0 + bw;  // first row of the panel; rows r0..n (n = rhs row)
+    for (int r = r0 + t; r <= n; r += 1024) {
+      double x[6];
+      double* row = S + (int64_t)r * ld + k0;
+      for (int j = 0; j < bw; ++j) {
+        double s = row[j];
+        for (int m = 0; m < j; ++m) s -= x[m] * Lkk[j][m];
+        x[j] = s / Lkk[j][j];
+      }
+      for (int j = 0; j < bw; ++j) row[j] = x[j];
+    }
+    __syncthreads();
+    const int m = n - r0 + 1;  // panel rows incl. rhs
+    for (int64_t idx = t; idx < (int64_t)m * m; idx += 1024) {
+      const int rr = (int)(idx / m), cc = (int)(idx % m);
+      if (cc > rr || cc == m - 1) continue;  // lower triangle; the rhs row has no diagonal / column
+      const double* pr = S + (int64_t)(r0 + rr) * ld + k0;
+      const double* pc = S + (int64_t)(r0 + cc) * ld + k0;
+      double s = 0.0;
+      for (int j = 0; j < bw; ++j) s += pr[j] * pc[j];
+      S[(int64_t)(r0 + rr) * ld + r0 + cc] -= s;
+    }
+    __syncthreads();
+  }
+  // backward substitution L^T x = y, y in row n
+  double* yrow = S + (int64_t)n * ld;
+  for (int k0 = ((n - 1) / 6) * 6; k0 >= 0; k0 -= 6) {
+    const int bw = min(6, n - k0);
+    if (t == 0) {
+      double x[6];
+      for (int j = bw - 1; j >= 0; --j) {
+        double s = yrow[k0 + j];
+        for (int m = j + 1; m < bw; ++m) s -= S[(int64_t)(k0 + m) * ld + k0 + j] * x[m];
+        x[j] = s / S[(int64_t)(k0 + j) * ld + k0 + j];
+      }
+      for (int j = 0; j < bw; ++j) { xk[j] = x[j]; yrow[k0 + j] = x[j]; }
+    }
+    __syncthreads();
+    for (int c = t; c < k0; c += 1024) {
+      double s = 0.0;
+      for (int m = 0; m < bw; ++m) s += S[(int64_t)(k0 + m) * ld + c] * xk[m];
+      yrow[c] -= s;
+    }
+    __syncthreads();
+  }
+  const bool bad = fail != 0;
+  if (t == 0 && bad) w.info[2] += 1;
+  for (int dd = t; dd < n; dd += 1024) {
+    double x = yrow[dd];
+    if (bad || !(x == x)) x = 0.0;  // zero step on a failed factorisation
+    w.dx[dd] = (float)x;
+  }
+  __syncthreads();
+  // retraction: poses X <- Exp(dx) X (retractor.py:27-29), intrinsics (retractor.py:50-62)
+  for (int sl = t; sl < n_free; sl += 1024) {
+    const int pidx = w.slot_pose[sl];
+    float xi[6];
+    for (int q = 0; q < 6; ++q) xi[q] = w.dx[6 * sl + q];
+    lie::SE3<float> X(a.poses + 7 * pidx);
+    (lie::SE3<float>::exp(xi) * X).store(a.poses + 7 * pidx);
+  }
+  if (prm.optimize_intrinsics && t == 0) {
+    const int F = 1 + a.D;
+    const float df = w.dx[6 * n_free];
+    for (int vq = 0; vq < prm.n_views; ++vq) {
+      float* I = a.intr + vq * (4 + a.D);
+      if (I[0] > 0) { I[0] += df; I[1] += df; if (F > 1) I[4] += 0.01f * w.dx[6 * n_free + 1]; }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ retract
+
+template <int F>
+__global__ __launch_bounds__(TILE) void ba_retract_kernel(BAArgs a) {
+  const BAWs& w = a.w;
+  const int k = blockIdx.y;
+  const int flags = w.fflags[k];
+  if (!(flags & 2)) return;
+  const int P = a.P, V = a.p.n_views;
+  const int p = blockIdx.x * TILE + threadIdx.x;
+  if (p >= P) return;
+  const int beg = w.rowptr[k], end = w.rowptr[k + 1];
+  const int64_t kp = (int64_t)k * P + p;
+  float rhs = w.wv[kp];
+  const int si = w.pose_slot[k / V];
+  const int n_free = w.info[0];
+  if (si >= 0) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) rhs -= w.Ekk[((int64_t)k * 6 + q) * P + p] * w.dx[6 * si + q];
+  }
+  for (int c = beg; c < end; ++c) {
+    const int e = w.order[c];
+    const int pj = (int)a.pj[e];
+    const int sj = ((int)a.pi[e] == pj) ? -1 : w.pose_slot[pj];
+    if (sj < 0) continue;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) rhs -= w.Ej[((int64_t)e * 6 + q) * P + p] * w.dx[6 * sj + q];
+  }
+  if constexpr (F > 0) {
+#pragma unroll
+    for (int f = 0; f < F; ++f) rhs -= w.Ef[((int64_t)k * 2 + f) * P + p] * w.dx[6 * n_free + f];
+  }
+  float dz = rhs / w.C[kp];
+  if (dz > 10.0f) dz = 0.0f;  // retractor.py:41
+  a.disps[kp] += dz;
+}
+
+__global__ void clamp_min_kernel(float* __restrict__ x, int64_t n, float lo) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = fmaxf(x[i], lo);  // NaN stays NaN? fmaxf(NaN, lo) = lo; torch.clamp keeps NaN - disparities are finite here
+}
+
+template <int CAM, int F>
+int run_iters(const BAArgs& a, hipStream_t s) {
+  const int tiles = (a.P + TILE - 1) / TILE;
+  const size_t sbytes = sizeof(double) * (size_t)a.w.ld * a.w.ld;
+  const size_t nmax = (size_t)a.w.ld - 1;
+  for (int it = 0; it < a.p.n_iters; ++it) {
+    hipError_t e1 = hipMemsetAsync(a.w.S, 0, sbytes, s);
+    hipError_t e2 = hipMemsetAsync(a.w.Hd, 0, sizeof(double) * nmax, s);
+    if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
+    ba_accum_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
+    ba_solve_kernel<<<1, 1024, 0, s>>>(a);
+    if (!a.p.motion_only) ba_retract_kernel<F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
+  }
+  return vipe_launch_status();
+}
+
+}  // namespace
+
+VIPE_EXPORT int64_t vipe_dense_ba_workspace_bytes(const vipe_ba_params* p) {
+  if (!p || p->n_poses <= 0 || p->n_views <= 0 || p->ht <= 0 || p->wd <= 0 || p->M < 0) return VIPE_EINVAL;
+  return (int64_t)carve(*p, nullptr, nullptr);
+}
+
+VIPE_EXPORT int vipe_dense_ba(const vipe_ba_params* p, float* d_poses, float* d_disps, const float* d_disps_sens,
+                              float* d_intrinsics, float* d_rig, const float* d_target, const float* d_weight,
+                              const float* d_disp_damping, const int64_t* d_pi, const int64_t* d_qi,
+                              const int64_t* d_pj, const int64_t* d_qj, const int64_t* d_di, void* d_workspace,
+                              int64_t workspace_bytes, int* d_info, void* stream) {
+  VIPE_CHECK_ARG(p && d_poses && d_disps && d_disps_sens && d_intrinsics && d_rig && d_disp_damping && d_workspace);
+  VIPE_CHECK_ARG(p->n_poses > 0 && p->n_views > 0 && p->ht > 0 && p->wd > 0 && p->M >= 0 && p->n_iters >= 0);
+  VIPE_CHECK_ARG(p->t0 <= p->t1 && p->intr_factor > 0);
+  VIPE_CHECK_ARG(p->camera == VIPE_CAM_PINHOLE || p->camera == VIPE_CAM_MEI);
+  VIPE_CHECK_ARG(p->M == 0 || (d_target && d_weight && d_pi && d_qi && d_pj && d_qj && d_di));
+  if (p->optimize_rig_rotation) return VIPE_EUNSUPPORTED;            // multi-view rigs only; not built yet
+  if (p->optimize_intrinsics && p->n_views != 1) return VIPE_EUNSUPPORTED;
+  if ((int64_t)p->n_poses * p->n_views > 65535) return VIPE_EINVAL;
+  BAArgs a;
+  a.p = *p;
+  if ((int64_t)carve(*p, (char*)d_workspace, &a.w) > workspace_bytes) return VIPE_ENOSPACE;
+  a.poses = d_poses; a.disps = d_disps; a.intr = d_intrinsics; a.rig = d_rig;
+  a.sens = d_disps_sens; a.target = d_target; a.weight = d_weight; a.eta = d_disp_damping;
+  a.pi = d_pi; a.qi = d_qi; a.pj = d_pj; a.qj = d_qj; a.di = d_di;
+  a.P = p->ht * p->wd;
+  a.nF = p->n_poses * p->n_views;
+  a.D = p->camera == VIPE_CAM_MEI ? 1 : 0;
+  hipStream_t s = as_stream(stream);
+  int rc = VIPE_OK;
+  if (p->M > 0 && p->n_iters > 0) {
+    ba_sens_kernel<<<a.nF, 256, 0, s>>>(d_disps_sens, a.w.sens_sum, a.P);
+    ba_plan_kernel<<<1, 1024, 0, s>>>(a);
+    const int F = p->optimize_intrinsics ? 1 + a.D : 0;
+    if (p->camera == VIPE_CAM_PINHOLE) rc = F ? run_iters<VIPE_CAM_PINHOLE, 1>(a, s) : run_iters<VIPE_CAM_PINHOLE, 0>(a, s);
+    else rc = F ? run_iters<VIPE_CAM_MEI, 2>(a, s) : run_iters<VIPE_CAM_MEI, 0>(a, s);
+    if (rc != VIPE_OK) return rc;
+    if (d_info) {
+      hipError_t e = hipMemcpyAsync(d_info, a.w.info, 4 * sizeof(int), hipMemcpyDeviceToDevice, s);
+      if (e != hipSuccess) return (int)e;
+    }
+  }
+  // buffer.py:525: disps.clamp_(min=1e-3) over the whole buffer handed in
+  const int64_t nd = (int64_t)a.nF * a.P;
+  clamp_min_kernel<<<(int)std::min<int64_t>((nd + 255) / 256, 2048), 256, 0, s>>>(d_disps, nd, 1e-3f);
+  return vipe_launch_status();
+}

@@ -1,0 +1,267 @@
+// Windowed bilinear lookup into the all-pairs correlation pyramid (droid_net_ext.corr_index_*).
+//
+// Replaces csrc/droid_net_ext/correlation_kernels.cu:22-159 of the reference.  One lane owns one
+// source pixel (b,y,x): it reads the (2r+2)^2 integer taps around floor(coords) from that pixel's
+// [h2,w2] slab and keeps the (2r+1)^2 outputs in registers, so every output is written exactly once,
+// coalesced along x (the reference does 4 global read-modify-writes per tap).
+//
+// Numerics (bit-parity contract): per output the four contributions are added in the reference's tap
+// order (i = x offset outer, j = y offset inner).  For half, every product and every sum is rounded
+// to half (c10::Half operators) and the bilinear weight is rounded to half first.  For float/double the
+// update `corr += s * w` is one fused multiply-add (the contraction nvcc applies to that statement).
+// Out-of-bounds taps are skipped in the reference; adding their +-0 products instead is bit-identical
+// because an accumulator that starts at +0 can never hold -0.
+#include "common.cuh"
+
+namespace {
+
+template <typename T>
+struct Acc;  // arithmetic in the storage type's rounding
+
+template <>
+struct Acc<half_t> {
+  using reg = float;  // holds a half-representable value
+  static __device__ __forceinline__ reg load(const half_t* p) { return (float)*p; }
+  static __device__ __forceinline__ reg weight(float w) { return (float)(half_t)w; }
+  static __device__ __forceinline__ reg madd(reg acc, reg s, reg w) {
+    float prod = (float)(half_t)(s * w);  // exact product of two halves, rounded once to half
+    return (float)(half_t)(acc + prod);
+  }
+  static __device__ __forceinline__ half_t store(reg v) { return (half_t)v; }
+};
+template <>
+struct Acc<float> {
+  using reg = float;
+  static __device__ __forceinline__ reg load(const float* p) { return *p; }
+  static __device__ __forceinline__ reg weight(float w) { return w; }
+  static __device__ __forceinline__ reg madd(reg acc, reg s, reg w) { return __builtin_fmaf(s, w, acc); }
+  static __device__ __forceinline__ float store(reg v) { return v; }
+};
+template <>
+struct Acc<double> {
+  using reg = double;
+  static __device__ __forceinline__ reg load(const double* p) { return *p; }
+  static __device__ __forceinline__ reg weight(float w) { return (double)w; }
+  static __device__ __forceinline__ reg madd(reg acc, reg s, reg w) { return __builtin_fma(s, w, acc); }
+  static __device__ __forceinline__ double store(reg v) { return v; }
+};
+
+// One pixel, one level.  R = radius (compile-time for full unrolling), RD = 2R+1.
+template <typename T, int R>
+__device__ __forceinline__ void lookup_pixel(const T* __restrict__ slab, int h2, int w2, float x0, float y0,
+                                             T* __restrict__ out, int64_t out_stride) {
+  constexpr int RD = 2 * R + 1;
+  using A = Acc<T>;
+  using reg = typename A::reg;
+  const float fx = floorf(x0), fy = floorf(y0);
+  const float dx = x0 - fx, dy = y0 - fy;
+  const int bx = (int)fx - R, by = (int)fy - R;
+  const reg w11 = A::weight(dx * dy);                  // tap (i,j) -> out[i-1][j-1]
+  const reg w10 = A::weight(dx * (1.0f - dy));         // tap (i,j) -> out[i-1][j]
+  const reg w01 = A::weight((1.0f - dx) * dy);         // tap (i,j) -> out[i][j-1]
+  const reg w00 = A::weight((1.0f - dx) * (1.0f - dy));// tap (i,j) -> out[i][j]
+
+  // taps: s[i][j] = slab[by + j][bx + i]   (i <-> x, j <-> y), zero outside the map
+  reg s[RD + 1][RD + 1];
+#pragma unroll
+  for (int j = 0; j <= RD; ++j) {
+    const int y1 = by + j;
+    const bool yin = (y1 >= 0) & (y1 < h2);
+    const T* row = slab + (int64_t)(yin ? y1 : 0) * w2;
+#pragma unroll
+    for (int i = 0; i <= RD; ++i) {
+      const int x1 = bx + i;
+      const bool in = yin & (x1 >= 0) & (x1 < w2);
+      s[i][j] = in ? A::load(row + x1) : (reg)0;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < RD; ++a) {
+#pragma unroll
+    for (int b = 0; b < RD; ++b) {
+      reg acc = (reg)0;
+      acc = A::madd(acc, s[a][b], w00);          // visited at (i=a,   j=b)
+      acc = A::madd(acc, s[a][b + 1], w01);      //            (i=a,   j=b+1)
+      acc = A::madd(acc, s[a + 1][b], w10);      //            (i=a+1, j=b)
+      acc = A::madd(acc, s[a + 1][b + 1], w11);  //            (i=a+1, j=b+1)
+      out[(int64_t)(a * RD + b) * out_stride] = A::store(acc);
+    }
+  }
+}
+
+// grid: (ceil(P/256), B); coords [B,2,h1,w1]
+template <typename T, int R>
+__global__ __launch_bounds__(256) void corr_index_forward_kernel(const T* __restrict__ volume,
+                                                                  const float* __restrict__ coords,
+                                                                  T* __restrict__ corr, int h1, int w1, int h2,
+                                                                  int w2) {
+  const int P = h1 * w1;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  if (p >= P) return;
+  const float x0 = coords[((int64_t)n * 2 + 0) * P + p];
+  const float y0 = coords[((int64_t)n * 2 + 1) * P + p];
+  constexpr int RD = 2 * R + 1;
+  const T* slab = volume + ((int64_t)n * P + p) * ((int64_t)h2 * w2);
+  T* out = corr + (int64_t)n * RD * RD * P + p;
+  lookup_pixel<T, R>(slab, h2, w2, x0, y0, out, P);
+}
+
+struct LevelPtrs {
+  const void* p[8];
+};
+
+// grid: (ceil(P/256), B, levels); coords [B,h1,w1,2]; out [B, L*RD*RD, h1, w1]
+template <typename T, int R>
+__global__ __launch_bounds__(256) void corr_pyramid_lookup_kernel(LevelPtrs lv, const float* __restrict__ coords,
+                                                                   T* __restrict__ out, int h1, int w1, int h2,
+                                                                   int w2, int L) {
+  const int P = h1 * w1;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  const int l = blockIdx.z;
+  if (p >= P) return;
+  const float2 c = reinterpret_cast<const float2*>(coords)[(int64_t)n * P + p];
+  const float sc = 1.0f / (float)(1 << l);  // coords / 2**l is exact (droid_net.py:78)
+  const int h2l = h2 >> l, w2l = w2 >> l;
+  constexpr int RD = 2 * R + 1;
+  const T* slab = reinterpret_cast<const T*>(lv.p[l]) + ((int64_t)n * P + p) * ((int64_t)h2l * w2l);
+  T* o = out + ((int64_t)n * L + l) * (RD * RD) * P + p;
+  lookup_pixel<T, R>(slab, h2l, w2l, c.x * sc, c.y * sc, o, P);
+}
+
+// adjoint: each lane owns its pixel's slab, so plain stores into a zero-filled gradient are race free.
+template <typename T, int R>
+__global__ __launch_bounds__(256) void corr_index_backward_kernel(const float* __restrict__ coords,
+                                                                   const T* __restrict__ corr_grad,
+                                                                   T* __restrict__ volume_grad, int h1, int w1,
+                                                                   int h2, int w2) {
+  constexpr int RD = 2 * R + 1;
+  using A = Acc<T>;
+  using reg = typename A::reg;
+  const int P = h1 * w1;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  if (p >= P) return;
+  const float x0 = coords[((int64_t)n * 2 + 0) * P + p];
+  const float y0 = coords[((int64_t)n * 2 + 1) * P + p];
+  const float fx = floorf(x0), fy = floorf(y0);
+  const float dx = x0 - fx, dy = y0 - fy;
+  const int bx = (int)fx - R, by = (int)fy - R;
+  const reg w11 = A::weight(dx * dy), w10 = A::weight(dx * (1.0f - dy));
+  const reg w01 = A::weight((1.0f - dx) * dy), w00 = A::weight((1.0f - dx) * (1.0f - dy));
+  const T* g = corr_grad + (int64_t)n * RD * RD * P + p;
+  T* slab = volume_grad + ((int64_t)n * P + p) * ((int64_t)h2 * w2);
+  reg cg[RD][RD];
+#pragma unroll
+  for (int a = 0; a < RD; ++a)
+#pragma unroll
+    for (int b = 0; b < RD; ++b) cg[a][b] = A::load(g + (int64_t)(a * RD + b) * P);
+#pragma unroll
+  for (int i = 0; i <= RD; ++i) {
+#pragma unroll
+    for (int j = 0; j <= RD; ++j) {
+      const int x1 = bx + i, y1 = by + j;
+      if ((y1 >= 0) & (y1 < h2) & (x1 >= 0) & (x1 < w2)) {
+        reg acc = (reg)0;  // correlation_kernels.cu:100-107 order
+        if (i > 0 && j > 0) acc = A::madd(acc, cg[i - 1][j - 1], w11);
+        if (i > 0 && j < RD) acc = A::madd(acc, cg[i - 1][j], w10);
+        if (i < RD && j > 0) acc = A::madd(acc, cg[i][j - 1], w01);
+        if (i < RD && j < RD) acc = A::madd(acc, cg[i][j], w00);
+        slab[(int64_t)y1 * w2 + x1] = A::store(acc);
+      }
+    }
+  }
+}
+
+template <typename T>
+int launch_fwd(const void* vol, const float* coords, void* corr, int B, int h1, int w1, int h2, int w2, int r,
+               hipStream_t s) {
+  dim3 grid((h1 * w1 + 255) / 256, B), block(256);
+  switch (r) {
+    case 1: corr_index_forward_kernel<T, 1><<<grid, block, 0, s>>>((const T*)vol, coords, (T*)corr, h1, w1, h2, w2); break;
+    case 2: corr_index_forward_kernel<T, 2><<<grid, block, 0, s>>>((const T*)vol, coords, (T*)corr, h1, w1, h2, w2); break;
+    case 3: corr_index_forward_kernel<T, 3><<<grid, block, 0, s>>>((const T*)vol, coords, (T*)corr, h1, w1, h2, w2); break;
+    case 4: corr_index_forward_kernel<T, 4><<<grid, block, 0, s>>>((const T*)vol, coords, (T*)corr, h1, w1, h2, w2); break;
+    default: return VIPE_EUNSUPPORTED;
+  }
+  return vipe_launch_status();
+}
+
+template <typename T>
+int launch_bwd(const float* coords, const void* cg, void* vg, int B, int h1, int w1, int h2, int w2, int r,
+               hipStream_t s) {
+  hipError_t e = hipMemsetAsync(vg, 0, sizeof(T) * (size_t)B * h1 * w1 * h2 * w2, s);
+  if (e != hipSuccess) return (int)e;
+  dim3 grid((h1 * w1 + 255) / 256, B), block(256);
+  switch (r) {
+    case 1: corr_index_backward_kernel<T, 1><<<grid, block, 0, s>>>(coords, (const T*)cg, (T*)vg, h1, w1, h2, w2); break;
+    case 2: corr_index_backward_kernel<T, 2><<<grid, block, 0, s>>>(coords, (const T*)cg, (T*)vg, h1, w1, h2, w2); break;
+    case 3: corr_index_backward_kernel<T, 3><<<grid, block, 0, s>>>(coords, (const T*)cg, (T*)vg, h1, w1, h2, w2); break;
+    case 4: corr_index_backward_kernel<T, 4><<<grid, block, 0, s>>>(coords, (const T*)cg, (T*)vg, h1, w1, h2, w2); break;
+    default: return VIPE_EUNSUPPORTED;
+  }
+  return vipe_launch_status();
+}
+
+template <typename T>
+int launch_pyr(const LevelPtrs& lv, const float* coords, void* out, int B, int h1, int w1, int h2, int w2, int L,
+               int r, hipStream_t s) {
+  dim3 grid((h1 * w1 + 255) / 256, B, L), block(256);
+  switch (r) {
+    case 3: corr_pyramid_lookup_kernel<T, 3><<<grid, block, 0, s>>>(lv, coords, (T*)out, h1, w1, h2, w2, L); break;
+    case 4: corr_pyramid_lookup_kernel<T, 4><<<grid, block, 0, s>>>(lv, coords, (T*)out, h1, w1, h2, w2, L); break;
+    default: return VIPE_EUNSUPPORTED;
+  }
+  return vipe_launch_status();
+}
+
+}  // namespace
+
+VIPE_EXPORT int vipe_corr_index_forward(const void* d_volume, const float* d_coords, void* d_corr, int B, int h1,
+                                        int w1, int h2, int w2, int radius, int dtype, void* stream) {
+  VIPE_CHECK_ARG(d_volume && d_coords && d_corr);
+  VIPE_CHECK_ARG(B >= 0 && h1 > 0 && w1 > 0 && h2 > 0 && w2 > 0 && B <= 65535);
+  if (B == 0) return VIPE_OK;
+  hipStream_t s = as_stream(stream);
+  switch (dtype) {
+    case VIPE_F16: return launch_fwd<half_t>(d_volume, d_coords, d_corr, B, h1, w1, h2, w2, radius, s);
+    case VIPE_F32: return launch_fwd<float>(d_volume, d_coords, d_corr, B, h1, w1, h2, w2, radius, s);
+    case VIPE_F64: return launch_fwd<double>(d_volume, d_coords, d_corr, B, h1, w1, h2, w2, radius, s);
+  }
+  return VIPE_EINVAL;
+}
+
+VIPE_EXPORT int vipe_corr_index_backward(const float* d_coords, const void* d_corr_grad, void* d_volume_grad, int B,
+                                         int h1, int w1, int h2, int w2, int radius, int dtype, void* stream) {
+  VIPE_CHECK_ARG(d_coords && d_corr_grad && d_volume_grad);
+  VIPE_CHECK_ARG(B >= 0 && h1 > 0 && w1 > 0 && h2 > 0 && w2 > 0 && B <= 65535);
+  if (B == 0) return VIPE_OK;
+  hipStream_t s = as_stream(stream);
+  switch (dtype) {
+    case VIPE_F16: return launch_bwd<half_t>(d_coords, d_corr_grad, d_volume_grad, B, h1, w1, h2, w2, radius, s);
+    case VIPE_F32: return launch_bwd<float>(d_coords, d_corr_grad, d_volume_grad, B, h1, w1, h2, w2, radius, s);
+    case VIPE_F64: return launch_bwd<double>(d_coords, d_corr_grad, d_volume_grad, B, h1, w1, h2, w2, radius, s);
+  }
+  return VIPE_EINVAL;
+}
+
+VIPE_EXPORT int vipe_corr_pyramid_lookup(const void* const* h_levels, const float* d_coords, void* d_out, int B,
+                                         int h1, int w1, int h2, int w2, int num_levels, int radius, int dtype,
+                                         void* stream) {
+  VIPE_CHECK_ARG(h_levels && d_coords && d_out);
+  VIPE_CHECK_ARG(num_levels >= 1 && num_levels <= 8 && B >= 0 && B <= 65535);
+  VIPE_CHECK_ARG((h2 >> (num_levels - 1)) >= 1 && (w2 >> (num_levels - 1)) >= 1);
+  if (B == 0) return VIPE_OK;
+  LevelPtrs lv;
+  for (int i = 0; i < num_levels; ++i) {
+    VIPE_CHECK_ARG(h_levels[i]);
+    lv.p[i] = h_levels[i];
+  }
+  hipStream_t s = as_stream(stream);
+  switch (dtype) {
+    case VIPE_F16: return launch_pyr<half_t>(lv, d_coords, d_out, B, h1, w1, h2, w2, num_levels, radius, s);
+    case VIPE_F32: return launch_pyr<float>(lv, d_coords, d_out, B, h1, w1, h2, w2, num_levels, radius, s);
+  }
+  return VIPE_EINVAL;
+}

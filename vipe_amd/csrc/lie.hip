@@ -1,0 +1,240 @@
+// lietorch_ext: batched Lie-group ops, one group element per lane, grid-stride (device) or a plain
+// loop (host) over the SAME closed forms (lie_math.h).  Replaces csrc/lietorch_ext/lietorch_gpu.cu:24-299
+// and lietorch_cpu.cpp of the reference for SO3 (group_id 1) and SE3 (group_id 3), float32/float64.
+// RxSO3 / Sim3 (ids 2, 4) are not on the SLAM path and return VIPE_EUNSUPPORTED, as do the backward
+// passes (the SLAM system runs under torch.no_grad, system.py:207).
+#include "common.cuh"
+#include "lie_math.h"
+
+namespace {
+
+using namespace lie;
+
+// ---- per-element functors: in0 [n,A], in1 [n,B] (optional), out [n,C]; `bc` = rows per element of in0
+template <typename G, typename S>
+struct OpExp {
+  static constexpr int A = G::K, B = 0, C = G::N;
+  static LIE_HD void run(const S* a, const S*, S* o);
+};
+template <typename S>
+struct OpExp<SE3<S>, S> {
+  static constexpr int A = 6, B = 0, C = 7;
+  static LIE_HD void run(const S* a, const S*, S* o) { SE3<S>::exp(a).store(o); }
+};
+template <typename S>
+struct OpExp<SO3<S>, S> {
+  static constexpr int A = 3, B = 0, C = 4;
+  static LIE_HD void run(const S* a, const S*, S* o) { SO3<S>::exp(Vec3<S>{a[0], a[1], a[2]}).store(o); }
+};
+
+template <typename G, typename S>
+struct OpLog;
+template <typename S>
+struct OpLog<SE3<S>, S> {
+  static constexpr int A = 7, B = 0, C = 6;
+  static LIE_HD void run(const S* x, const S*, S* o) { SE3<S>(x).log(o); }
+};
+template <typename S>
+struct OpLog<SO3<S>, S> {
+  static constexpr int A = 4, B = 0, C = 3;
+  static LIE_HD void run(const S* x, const S*, S* o) {
+    Vec3<S> v = SO3<S>(x).log();
+    o[0] = v.x; o[1] = v.y; o[2] = v.z;
+  }
+};
+
+template <typename G, typename S>
+struct OpInv {
+  static constexpr int A = G::N, B = 0, C = G::N;
+  static LIE_HD void run(const S* x, const S*, S* o) { G(x).inv().store(o); }
+};
+template <typename G, typename S>
+struct OpMul {
+  static constexpr int A = G::N, B = G::N, C = G::N;
+  static LIE_HD void run(const S* x, const S* y, S* o) { (G(x) * G(y)).store(o); }
+};
+
+template <typename G, typename S>
+struct OpAdj;
+template <typename S>
+struct OpAdj<SE3<S>, S> {
+  static constexpr int A = 7, B = 6, C = 6;
+  static LIE_HD void run(const S* x, const S* a, S* o) { SE3<S>(x).adj(a, o); }
+};
+template <typename S>
+struct OpAdj<SO3<S>, S> {
+  static constexpr int A = 4, B = 3, C = 3;
+  static LIE_HD void run(const S* x, const S* a, S* o) {
+    Vec3<S> v = SO3<S>(x).matrix() * Vec3<S>{a[0], a[1], a[2]};
+    o[0] = v.x; o[1] = v.y; o[2] = v.z;
+  }
+};
+template <typename G, typename S>
+struct OpAdjT;
+template <typename S>
+struct OpAdjT<SE3<S>, S> {
+  static constexpr int A = 7, B = 6, C = 6;
+  static LIE_HD void run(const S* x, const S* a, S* o) { SE3<S>(x).adjT(a, o); }
+};
+template <typename S>
+struct OpAdjT<SO3<S>, S> {
+  static constexpr int A = 4, B = 3, C = 3;
+  static LIE_HD void run(const S* x, const S* a, S* o) {
+    Vec3<S> v = SO3<S>(x).matrix().tmul(Vec3<S>{a[0], a[1], a[2]});
+    o[0] = v.x; o[1] = v.y; o[2] = v.z;
+  }
+};
+
+template <typename G, typename S>
+struct OpAct {
+  static constexpr int A = G::N, B = 3, C = 3;
+  static LIE_HD void run(const S* x, const S* p, S* o) {
+    Vec3<S> v = G(x).act(Vec3<S>{p[0], p[1], p[2]});
+    o[0] = v.x; o[1] = v.y; o[2] = v.z;
+  }
+};
+template <typename G, typename S>
+struct OpAct4;
+template <typename S>
+struct OpAct4<SE3<S>, S> {
+  static constexpr int A = 7, B = 4, C = 4;
+  static LIE_HD void run(const S* x, const S* p, S* o) { SE3<S>(x).act4(p, o); }
+};
+template <typename S>
+struct OpAct4<SO3<S>, S> {
+  static constexpr int A = 4, B = 4, C = 4;
+  static LIE_HD void run(const S* x, const S* p, S* o) {
+    Vec3<S> v = SO3<S>(x).act(Vec3<S>{p[0], p[1], p[2]});
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = p[3];
+  }
+};
+
+template <typename G, typename S>
+struct OpMatrix;
+template <typename S>
+struct OpMatrix<SE3<S>, S> {
+  static constexpr int A = 7, B = 0, C = 16;
+  static LIE_HD void run(const S* x, const S*, S* o) {
+    SE3<S> X(x);
+    Mat3<S> R = X.r.matrix();
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) o[4 * i + j] = R.m[i][j]; }
+    o[3] = X.t.x; o[7] = X.t.y; o[11] = X.t.z;
+    o[12] = o[13] = o[14] = 0; o[15] = 1;
+  }
+};
+template <typename S>
+struct OpMatrix<SO3<S>, S> {
+  static constexpr int A = 4, B = 0, C = 16;
+  static LIE_HD void run(const S* x, const S*, S* o) {
+    Mat3<S> R = SO3<S>(x).matrix();
+    for (int i = 0; i < 16; ++i) o[i] = 0;
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) o[4 * i + j] = R.m[i][j]; }
+    o[15] = 1;
+  }
+};
+
+// rows_per_elem > 1: in0 (the group element) is shared by `rows_per_elem` consecutive rows of in1/out
+template <typename Op, typename S>
+__global__ __launch_bounds__(256) void lie_kernel(const S* __restrict__ in0, const S* __restrict__ in1,
+                                                   S* __restrict__ out, int64_t n, int64_t rows_per_elem) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    S a[Op::A], b[Op::B > 0 ? Op::B : 1], o[Op::C];
+    const int64_t e = rows_per_elem > 1 ? i / rows_per_elem : i;
+#pragma unroll
+    for (int k = 0; k < Op::A; ++k) a[k] = in0[e * Op::A + k];
+#pragma unroll
+    for (int k = 0; k < Op::B; ++k) b[k] = in1[i * Op::B + k];
+    Op::run(a, b, o);
+#pragma unroll
+    for (int k = 0; k < Op::C; ++k) out[i * Op::C + k] = o[k];
+  }
+}
+
+template <typename Op, typename S>
+int run_op(const void* in0, const void* in1, void* out, int64_t n, int64_t rpe, int on_device, hipStream_t s) {
+  if (n == 0) return VIPE_OK;
+  if (!in0 || !out || (Op::B > 0 && !in1)) return VIPE_EINVAL;
+  if (on_device) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    lie_kernel<Op, S><<<(int)blocks, 256, 0, s>>>((const S*)in0, (const S*)in1, (S*)out, n, rpe);
+    return vipe_launch_status();
+  }
+  const S* a = (const S*)in0;
+  const S* b = (const S*)in1;
+  S* o = (S*)out;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t e = rpe > 1 ? i / rpe : i;
+    Op::run(a + e * Op::A, Op::B > 0 ? b + i * Op::B : nullptr, o + i * Op::C);
+  }
+  return VIPE_OK;
+}
+
+template <template <typename, typename> class Op>
+int dispatch(int gid, const void* in0, const void* in1, void* out, int64_t n, int64_t rpe, int dtype, int on_device,
+             void* stream) {
+  hipStream_t s = as_stream(stream);
+  if (n < 0) return VIPE_EINVAL;
+  if (dtype == VIPE_F32) {
+    if (gid == 3) return run_op<Op<SE3<float>, float>, float>(in0, in1, out, n, rpe, on_device, s);
+    if (gid == 1) return run_op<Op<SO3<float>, float>, float>(in0, in1, out, n, rpe, on_device, s);
+  } else if (dtype == VIPE_F64) {
+    if (gid == 3) return run_op<Op<SE3<double>, double>, double>(in0, in1, out, n, rpe, on_device, s);
+    if (gid == 1) return run_op<Op<SO3<double>, double>, double>(in0, in1, out, n, rpe, on_device, s);
+  } else {
+    return VIPE_EINVAL;
+  }
+  return (gid == 2 || gid == 4) ? VIPE_EUNSUPPORTED : VIPE_EINVAL;
+}
+
+}  // namespace
+
+VIPE_EXPORT int vipe_lie_expm(int g, const void* a, void* X, int64_t n, int dt, int dev, void* st) {
+  return dispatch<OpExp>(g, a, nullptr, X, n, 1, dt, dev, st);
+}
+VIPE_EXPORT int vipe_lie_logm(int g, const void* X, void* a, int64_t n, int dt, int dev, void* st) {
+  return dispatch<OpLog>(g, X, nullptr, a, n, 1, dt, dev, st);
+}
+VIPE_EXPORT int vipe_lie_inv(int g, const void* X, void* Y, int64_t n, int dt, int dev, void* st) {
+  return dispatch<OpInv>(g, X, nullptr, Y, n, 1, dt, dev, st);
+}
+VIPE_EXPORT int vipe_lie_mul(int g, const void* X, const void* Y, void* Z, int64_t n, int dt, int dev, void* st) {
+  return dispatch<OpMul>(g, X, Y, Z, n, 1, dt, dev, st);
+}
+VIPE_EXPORT int vipe_lie_adj(int g, const void* X, const void* a, void* b, int64_t n, int dt, int dev, void* st) {
+  return dispatch<OpAdj>(g, X, a, b, n, 1, dt, dev, st);
+}
+VIPE_EXPORT int vipe_lie_adjT(int g, const void* X, const void* a, void* b, int64_t n, int dt, int dev, void* st) {
+  return dispatch<OpAdjT>(g, X, a, b, n, 1, dt, dev, st);
+}
+VIPE_EXPORT int vipe_lie_act(int g, const void* X, const void* p, void* q, int64_t n, int dt, int dev, void* st) {
+  return dispatch<OpAct>(g, X, p, q, n, 1, dt, dev, st);
+}
+VIPE_EXPORT int vipe_lie_act4(int g, const void* X, const void* p, void* q, int64_t n, int dt, int dev, void* st) {
+  return dispatch<OpAct4>(g, X, p, q, n, 1, dt, dev, st);
+}
+VIPE_EXPORT int vipe_lie_as_matrix(int g, const void* X, void* T, int64_t n, int dt, int dev, void* st) {
+  return dispatch<OpMatrix>(g, X, nullptr, T, n, 1, dt, dev, st);
+}
+VIPE_EXPORT int vipe_lie_adjT_bcast(int g, const void* X, const void* a, void* b, int64_t n_elem, int64_t rpe, int dt,
+                                    void* st) {
+  if (rpe < 1) return VIPE_EINVAL;
+  return dispatch<OpAdjT>(g, X, a, b, n_elem * rpe, rpe, dt, 1, st);
+}
+VIPE_EXPORT int vipe_lie_act4_bcast(int g, const void* X, const void* p, void* q, int64_t n_elem, int64_t rpe, int dt,
+                                    void* st) {
+  if (rpe < 1) return VIPE_EINVAL;
+  return dispatch<OpAct4>(g, X, p, q, n_elem * rpe, rpe, dt, 1, st);
+}
+
+// Not on the inference path (torch.no_grad): declared for ABI completeness.
+VIPE_EXPORT int vipe_lie_projector(int, const void*, void*, int64_t, int, int, void*) { return VIPE_EUNSUPPORTED; }
+VIPE_EXPORT int vipe_lie_jinv(int, const void*, const void*, void*, int64_t, int, int, void*) { return VIPE_EUNSUPPORTED; }
+VIPE_EXPORT int vipe_lie_expm_backward(int, const void*, const void*, void*, int64_t, int, int, void*) { return VIPE_EUNSUPPORTED; }
+VIPE_EXPORT int vipe_lie_logm_backward(int, const void*, const void*, void*, int64_t, int, int, void*) { return VIPE_EUNSUPPORTED; }
+VIPE_EXPORT int vipe_lie_inv_backward(int, const void*, const void*, void*, int64_t, int, int, void*) { return VIPE_EUNSUPPORTED; }
+VIPE_EXPORT int vipe_lie_mul_backward(int, const void*, const void*, const void*, void*, void*, int64_t, int, int, void*) { return VIPE_EUNSUPPORTED; }
+VIPE_EXPORT int vipe_lie_adj_backward(int, const void*, const void*, const void*, void*, void*, int64_t, int, int, void*) { return VIPE_EUNSUPPORTED; }
+VIPE_EXPORT int vipe_lie_adjT_backward(int, const void*, const void*, const void*, void*, void*, int64_t, int, int, void*) { return VIPE_EUNSUPPORTED; }
+VIPE_EXPORT int vipe_lie_act_backward(int, const void*, const void*, const void*, void*, void*, int64_t, int, int, void*) { return VIPE_EUNSUPPORTED; }
+VIPE_EXPORT int vipe_lie_act4_backward(int, const void*, const void*, const void*, void*, void*, int64_t, int, int, void*) { return VIPE_EUNSUPPORTED; }

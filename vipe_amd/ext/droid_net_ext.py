@@ -1,0 +1,105 @@
+"""droid_net_ext: correlation lookup ops (reference: csrc/droid_net_ext/droid.cpp:57-63)."""
+
+import ctypes
+
+import torch
+
+from .._lib import DTYPE_CODE, check, check_gpu_contig, lib, ptr, require, stream_ptr
+
+
+def corr_index_forward(volume, coords, radius):
+    """droid.cpp:20-27 -> correlation_kernels.cu:115-136. volume [B,h1,w1,h2,w2]; coords [B,2,h1,w1] f32."""
+    check_gpu_contig(volume, coords)
+    require(volume.dim() == 5 and coords.dim() == 4 and coords.dtype == torch.float32, "bad corr_index_forward inputs")
+    require(volume.dtype in DTYPE_CODE, "volume must be half/float/double")
+    B, h1, w1, h2, w2 = volume.shape
+    require(tuple(coords.shape) == (B, 2, h1, w1), "coords must be [B,2,h1,w1]")
+    rd = 2 * radius + 1
+    corr = torch.empty((B, rd, rd, h1, w1), dtype=volume.dtype, device=volume.device)
+    check(lib().vipe_corr_index_forward(ptr(volume), ptr(coords), ptr(corr), B, h1, w1, h2, w2, radius,
+                                        DTYPE_CODE[volume.dtype], stream_ptr(volume)), "corr_index_forward")
+    return [corr]
+
+
+def corr_index_backward(volume, coords, corr_grad, radius):
+    """droid.cpp:29-37 -> correlation_kernels.cu:138-159."""
+    check_gpu_contig(volume, coords, corr_grad)
+    B, h1, w1, h2, w2 = volume.shape
+    require(corr_grad.dtype == volume.dtype, "corr_grad dtype must match volume")
+    grad = torch.empty_like(volume)
+    check(lib().vipe_corr_index_backward(ptr(coords), ptr(corr_grad), ptr(grad), B, h1, w1, h2, w2, radius,
+                                         DTYPE_CODE[volume.dtype], stream_ptr(volume)), "corr_index_backward")
+    return [grad]
+
+
+def altcorr_forward(fmap1, fmap2, coords, radius):
+    """droid.cpp:39-45 -> altcorr_kernel.cu:266-290. fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C], coords [B,N,H1,W1,2]."""
+    check_gpu_contig(fmap1, fmap2, coords)
+    require(fmap1.dtype == fmap2.dtype and fmap1.dtype in (torch.float16, torch.float32), "fmaps must be half/float")
+    require(coords.dtype == torch.float32 and coords.dim() == 5, "coords must be [B,N,H1,W1,2] float32")
+    B, H1, W1, C = fmap1.shape
+    _, H2, W2, _ = fmap2.shape
+    N = coords.shape[1]
+    rd = 2 * radius + 1
+    corr = torch.empty((B, N, rd * rd, H1, W1), dtype=fmap1.dtype, device=fmap1.device)
+    check(lib().vipe_altcorr_forward(ptr(fmap1), ptr(fmap2), ptr(coords), ptr(corr), B, H1, W1, H2, W2, N, C,
+                                     radius, DTYPE_CODE[fmap1.dtype], stream_ptr(fmap1)), "altcorr_forward")
+    return [corr]
+
+
+def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
+    """droid.cpp:47-55 -> altcorr_kernel.cu:292-320 (float32 only)."""
+    check_gpu_contig(fmap1, fmap2, coords, corr_grad)
+    require(fmap1.dtype == torch.float32 and fmap2.dtype == torch.float32, "altcorr_backward is float32 only")
+    B, H1, W1, C = fmap1.shape
+    _, H2, W2, _ = fmap2.shape
+    N = coords.shape[1]
+    g1 = torch.zeros_like(fmap1)
+    g2 = torch.zeros_like(fmap2)
+    check(lib().vipe_altcorr_backward(ptr(fmap1), ptr(fmap2), ptr(coords), ptr(corr_grad), ptr(g1), ptr(g2), B, H1,
+                                      W1, H2, W2, N, C, radius, stream_ptr(fmap1)), "altcorr_backward")
+    return [g1, g2, torch.zeros_like(coords)]
+
+
+# ------------------------------------------------------------------ fused entry points (MI355X design)
+
+
+def corr_volume(fmap1, fmap2):
+    """All-pairs correlation (fmap1/4)^T (fmap2/4), [E,C,h,w] x2 -> [E,h*w,h*w] (droid_net.py:94-102).
+
+    A plain batched GEMM: issued through hipBLASLt (torch.matmul), dtype of the inputs."""
+    E, C, h, w = fmap1.shape
+    f1 = fmap1.reshape(E, C, h * w) / 4.0
+    f2 = fmap2.reshape(E, C, h * w) / 4.0
+    return torch.matmul(f1.transpose(1, 2), f2)
+
+
+def corr_pyramid_build(fmap1, fmap2, num_levels=4):
+    """CorrBlock.__init__ (droid_net.py:56-69): list of [E,h,w,h>>i,w>>i]."""
+    E, C, h, w = fmap1.shape
+    vol = corr_volume(fmap1, fmap2).reshape(E * h * w, 1, h, w)
+    levels = []
+    for i in range(num_levels):
+        levels.append(vol.view(E, h, w, h >> i, w >> i))
+        if i + 1 < num_levels:
+            vol = torch.nn.functional.avg_pool2d(vol, 2, stride=2)
+    return levels
+
+
+def corr_pyramid_lookup(levels, coords, radius=3):
+    """CorrBlock.__call__ (droid_net.py:71-82) in ONE launch. levels: list of [E,h1,w1,h2>>i,w2>>i];
+    coords [E,h1,w1,2] f32 -> [E, L*(2r+1)^2, h1, w1] in the volume dtype."""
+    check_gpu_contig(coords, *levels)
+    require(coords.dtype == torch.float32, "coords must be float32")
+    E, h1, w1, h2, w2 = levels[0].shape
+    L = len(levels)
+    for i, lv in enumerate(levels):
+        require(tuple(lv.shape) == (E, h1, w1, h2 >> i, w2 >> i) and lv.dtype == levels[0].dtype, "bad pyramid level")
+    require(tuple(coords.shape) == (E, h1, w1, 2), "coords must be [E,h1,w1,2]")
+    rd = 2 * radius + 1
+    out = torch.empty((E, L * rd * rd, h1, w1), dtype=levels[0].dtype, device=coords.device)
+    arr = (ctypes.c_void_p * L)(*[lv.data_ptr() for lv in levels])
+    check(lib().vipe_corr_pyramid_lookup(ctypes.cast(arr, ctypes.c_void_p), ptr(coords), ptr(out), E, h1, w1, h2, w2,
+                                         L, radius, DTYPE_CODE[levels[0].dtype], stream_ptr(coords)),
+          "corr_pyramid_lookup")
+    return out

@@ -1,0 +1,152 @@
+"""slam_ext: projective geometry + dense BA (reference: csrc/slam_ext/slam.cpp:31-37)."""
+
+import ctypes
+
+import torch
+
+from .._lib import CAMERA_CODE, BAParams, check, check_gpu_contig, lib, ptr, require, stream_ptr
+
+_WS = {}
+
+
+def _workspace(device, nbytes):
+    """Grow-only per-device workspace (allocated outside the timed / captured region after the first call)."""
+    key = (device.type, device.index)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def _i64(t):
+    require(t.dtype == torch.int64, "index tensors must be int64")
+    return t
+
+
+def reproject(poses, disps, intrinsics, rig, pi, qi, pj, qj, di, camera="pinhole", intr_factor=8.0, want_valid=True):
+    """GraphBuffer.reproject_dense_disp core (buffer.py:527-548). disps [NV,ht,wd]; -> coords [M,ht,wd,2], valid [M,ht,wd,1]."""
+    check_gpu_contig(poses, disps, intrinsics, rig, pi, qi, pj, qj, di)
+    M = pi.shape[0]
+    _, ht, wd = disps.shape
+    coords = torch.empty((M, ht, wd, 2), dtype=torch.float32, device=poses.device)
+    valid = torch.empty((M, ht, wd, 1), dtype=torch.float32, device=poses.device) if want_valid else None
+    check(lib().vipe_reproject(ptr(poses), ptr(disps), ptr(intrinsics), ptr(rig), ptr(_i64(pi)), ptr(_i64(qi)),
+                               ptr(_i64(pj)), ptr(_i64(qj)), ptr(_i64(di)), ptr(coords), ptr(valid), M, ht, wd,
+                               rig.shape[0], CAMERA_CODE[camera], float(intr_factor), stream_ptr(poses)), "reproject")
+    return coords, valid
+
+
+def reproject_motion(poses, disps, intrinsics, rig, pi, qi, pj, qj, di, target, camera="pinhole", intr_factor=8.0,
+                     motn_dtype=torch.float16):
+    """coords1 + clamped motion features [M,4,ht,wd] in one launch (factor_graph.py:253-261)."""
+    check_gpu_contig(poses, disps, intrinsics, rig, pi, qi, pj, qj, di, target)
+    M = pi.shape[0]
+    _, ht, wd = disps.shape
+    require(target.numel() == M * ht * wd * 2 and target.dtype == torch.float32, "target must be [M,ht,wd,2] float32")
+    coords = torch.empty((M, ht, wd, 2), dtype=torch.float32, device=poses.device)
+    motn = torch.empty((M, 4, ht, wd), dtype=motn_dtype, device=poses.device)
+    code = {torch.float16: 0, torch.float32: 1}[motn_dtype]
+    check(lib().vipe_reproject_motion(ptr(poses), ptr(disps), ptr(intrinsics), ptr(rig), ptr(_i64(pi)), ptr(_i64(qi)),
+                                      ptr(_i64(pj)), ptr(_i64(qj)), ptr(_i64(di)), ptr(target), ptr(coords), ptr(motn),
+                                      M, ht, wd, rig.shape[0], CAMERA_CODE[camera], float(intr_factor), code,
+                                      stream_ptr(poses)), "reproject_motion")
+    return coords, motn
+
+
+def dense_ba(poses, disps, disps_sens, intrinsics, rig, target, weight, disp_damping, pi, qi, pj, qj, di, t0, t1,
+             n_iters, pose_damping, pose_ep, motion_only=False, limited_disp=False, optimize_intrinsics=False,
+             optimize_rig_rotation=False, camera="pinhole", alpha=0.001, n_poses=None, want_info=False):
+    """Live dense BA (GraphBuffer.bundle_adjustment, buffer.py:373-525), IN PLACE on poses / disps / intrinsics.
+
+    poses [>=n_poses,7]; disps, disps_sens, disp_damping [>=n_poses*V,ht,wd] (flattened views);
+    target, weight [M,ht*wd,2]; pi..di [M] int64.  `n_poses` bounds the pose/frame indices that occur
+    (default: all rows of `poses`); a tight bound keeps the reduced system small."""
+    check_gpu_contig(poses, disps, disps_sens, intrinsics, rig, target, weight, disp_damping, pi, qi, pj, qj, di)
+    for t in (poses, disps, disps_sens, intrinsics, rig, target, weight, disp_damping):
+        require(t.dtype == torch.float32, "dense_ba works in float32 (the reference's BA dtype)")
+    V = rig.shape[0]
+    n_poses = poses.shape[0] if n_poses is None else int(n_poses)
+    require(disps.dim() == 3 and disps.shape[0] >= n_poses * V, "disps must be [n_poses*V,ht,wd]")
+    _, ht, wd = disps.shape
+    M = pi.shape[0]
+    require(target.numel() == M * ht * wd * 2 and weight.numel() == M * ht * wd * 2, "target/weight must be [M,P,2]")
+    p = BAParams(n_poses=n_poses, n_views=V, ht=ht, wd=wd, M=M, t0=int(t0), t1=int(t1), n_iters=int(n_iters),
+                 pose_damping=float(pose_damping), pose_ep=float(pose_ep), motion_only=int(motion_only),
+                 limited_disp=int(limited_disp), optimize_intrinsics=int(optimize_intrinsics),
+                 optimize_rig_rotation=int(optimize_rig_rotation), camera=CAMERA_CODE[camera], alpha=float(alpha),
+                 weight_scale=0.001, intr_factor=8.0)
+    L = lib()
+    nbytes = L.vipe_dense_ba_workspace_bytes(ctypes.byref(p))
+    require(nbytes > 0, "bad BA parameters")
+    ws = _workspace(poses.device, nbytes)
+    info = torch.zeros(4, dtype=torch.int32, device=poses.device) if want_info else None
+    check(L.vipe_dense_ba(ctypes.byref(p), ptr(poses), ptr(disps), ptr(disps_sens), ptr(intrinsics), ptr(rig),
+                          ptr(target), ptr(weight), ptr(disp_damping), ptr(_i64(pi)), ptr(_i64(qi)), ptr(_i64(pj)),
+                          ptr(_i64(qj)), ptr(_i64(di)), ptr(ws), ws.numel(), ptr(info), stream_ptr(poses)), "dense_ba")
+    return info
+
+
+# ------------------------------------------------------------------ reference-named entry points (slam.cpp:31-37)
+
+
+def frame_distance(poses, disps, intrinsics, pi, pj, qi, qj, di, beta):
+    """geom_kernels.cu:1406-1434. poses [NV,7], disps [NV,ht,wd], intrinsics [V,4] -> dist [M]."""
+    check_gpu_contig(poses, disps, intrinsics, pi, pj, qi, qj, di)
+    M = pi.shape[0]
+    _, ht, wd = disps.shape
+    dist = torch.empty(M, dtype=torch.float32, device=poses.device)
+    check(lib().vipe_frame_distance(ptr(poses), ptr(disps), ptr(intrinsics), ptr(_i64(pi)), ptr(_i64(pj)), ptr(_i64(qi)),
+                                    ptr(_i64(qj)), ptr(_i64(di)), ptr(dist), M, ht, wd, float(beta), stream_ptr(poses)),
+          "frame_distance")
+    return dist
+
+
+def depth_filter(poses, disps, intrinsics, ix, thresh):
+    """geom_kernels.cu:1462-1486 -> counter [num,ht,wd] float32."""
+    check_gpu_contig(poses, disps, intrinsics, ix, thresh)
+    n, ht, wd = disps.shape
+    num = ix.shape[0]
+    counter = torch.zeros((num, ht, wd), dtype=torch.float32, device=poses.device)
+    check(lib().vipe_depth_filter(ptr(poses), ptr(disps), ptr(intrinsics), ptr(_i64(ix)), ptr(thresh), ptr(counter), n,
+                                  num, ht, wd, stream_ptr(poses)), "depth_filter")
+    return counter
+
+
+def projmap(poses, disps, intrinsics, ii, jj):
+    """geom_kernels.cu:1436-1460 -> [coords [E,ht,wd,3], valid [E,ht,wd,1]]."""
+    check_gpu_contig(poses, disps, intrinsics, ii, jj)
+    E = ii.shape[0]
+    _, ht, wd = disps.shape
+    coords = torch.zeros((E, ht, wd, 3), dtype=torch.float32, device=poses.device)
+    valid = torch.zeros((E, ht, wd, 1), dtype=torch.float32, device=poses.device)
+    check(lib().vipe_projmap(ptr(poses), ptr(disps), ptr(intrinsics), ptr(_i64(ii)), ptr(_i64(jj)), ptr(coords),
+                             ptr(valid), E, ht, wd, stream_ptr(poses)), "projmap")
+    return [coords, valid]
+
+
+def iproj(poses, disps, intrinsics):
+    """geom_kernels.cu:1488-1507 -> points [n,ht,wd,3]."""
+    check_gpu_contig(poses, disps, intrinsics)
+    n, ht, wd = disps.shape
+    pts = torch.zeros((n, ht, wd, 3), dtype=torch.float32, device=poses.device)
+    check(lib().vipe_iproj(ptr(poses), ptr(disps), ptr(intrinsics), ptr(pts), n, ht, wd, stream_ptr(poses)), "iproj")
+    return pts
+
+
+def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep, motion_only):
+    """DROID BA signature (slam.cpp:31, geom_kernels.cu:1273-1404) - dormant in the reference."""
+    check_gpu_contig(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj)
+    n, ht, wd = disps.shape
+    E = ii.shape[0]
+    L = lib()
+    nbytes = L.vipe_ba_workspace_bytes(n, ht, wd, E)
+    check(min(nbytes, 0), "ba")
+    ws = _workspace(poses.device, nbytes)
+    dx = torch.zeros((t1 - t0, 6), dtype=torch.float32, device=poses.device)
+    dz = torch.zeros((eta.shape[0], ht * wd), dtype=torch.float32, device=poses.device)
+    check(L.vipe_ba(ptr(poses), ptr(disps), ptr(intrinsics), ptr(disps_sens), ptr(targets), ptr(weights), ptr(eta),
+                    ptr(_i64(ii)), ptr(_i64(jj)), n, ht, wd, E, eta.shape[0], int(t0), int(t1), int(iterations),
+                    float(lm), float(ep), int(motion_only), ptr(dx), ptr(dz), ptr(ws), ws.numel(),
+                    stream_ptr(poses)), "ba")
+    return [dx, dz]

@@ -1,0 +1,123 @@
+"""Keyframe state + the geometry/BA entry points the factor graph calls.
+
+Host-side mirror of vipe/slam/components/buffer.py for the hot path: same tensor names, shapes and dtypes
+(buffer.py:79-176), same method signatures for `expand_edge_multiview` (:318-361), `bundle_adjustment`
+(:373-390), `reproject_dense_disp` (:527) and `frame_distance_dense_disp` (:550).  The arithmetic is one
+C-ABI call each (vipe_amd.ext.slam_ext); the Python Solver / term / sparse-block machinery of the
+reference (vipe/slam/ba, vipe/slam/maths) has no counterpart here - it is what the fused kernels replace.
+"""
+
+from dataclasses import dataclass
+
+import torch
+
+from ..ext import slam_ext
+
+
+@dataclass
+class BAConfig:
+    dense_disp_alpha: float = 0.001  # configs/slam/default.yaml:48-49
+
+
+class GraphBuffer:
+    def __init__(self, height, width, n_views=1, buffer_size=1024, init_disp=1.0, cross_view_idx=None,
+                 ba_config=None, camera_type="pinhole", device=torch.device("cuda")):
+        assert height % 8 == 0 and width % 8 == 0  # buffer.py:76
+        if cross_view_idx is None:
+            cross_view_idx = [(i + 1) % n_views for i in range(n_views)]
+        self.n_frames = 0
+        self.height, self.width, self.n_views, self.device = height, width, n_views, device
+        self.ba_config = ba_config or BAConfig()
+        self.camera_type = camera_type
+        ht, wd = height // 8, width // 8
+        f32 = dict(device=device, dtype=torch.float)
+        self.tstamp = torch.zeros(buffer_size, device=device, dtype=torch.int)
+        self.poses = torch.zeros(buffer_size, 7, **f32)
+        self.poses[:, 6] = 1.0
+        intr_dim = 5 if camera_type == "mei" else 4
+        self.intrinsics = torch.zeros(n_views, intr_dim, **f32)
+        self.rig = torch.zeros(n_views, 7, **f32)
+        self.rig[:, 6] = 1.0
+        self.disps = torch.ones(buffer_size, n_views, ht, wd, **f32) * init_disp
+        self.disps_sens = torch.zeros(buffer_size, n_views, ht, wd, **f32)
+        self.masks = torch.zeros(buffer_size, n_views, ht, wd, device=device, dtype=torch.bool)
+        self.fmaps = torch.zeros(buffer_size, n_views, 128, ht, wd, device=device, dtype=torch.half)
+        self.nets = torch.zeros(buffer_size, n_views, 128, ht, wd, device=device, dtype=torch.half)
+        self.inps = torch.zeros(buffer_size, n_views, 128, ht, wd, device=device, dtype=torch.half)
+        self.cross_view_idx = torch.zeros(buffer_size, n_views, 2, device=device, dtype=torch.long)
+        self.cross_view_idx[..., 0] = torch.arange(buffer_size, device=device)[:, None]
+        self.cross_view_idx[..., 1] = torch.tensor(cross_view_idx, device=device).long()[None]
+
+    # ---- flattened (n v) views, buffer.py:181-199
+    @property
+    def flattened_disps(self):
+        return self.disps.view(-1, *self.disps.shape[2:])
+
+    @property
+    def flattened_disps_sens(self):
+        return self.disps_sens.view(-1, *self.disps_sens.shape[2:])
+
+    @property
+    def flattened_fmaps(self):
+        return self.fmaps.view(-1, *self.fmaps.shape[2:])
+
+    def expand_edge_multiview(self, ii, jj, cross=True, view_offset=0):
+        """buffer.py:318-361 -> pi, qi, di, pj, qj, dj (each [M * n_views])."""
+        V = self.n_views
+        qi = torch.arange(V, device=self.device).reshape(1, -1).repeat(ii.shape[0], 1)
+        pi = ii.reshape(-1, 1).repeat(1, V).to(self.device)
+        qj = torch.arange(V, device=self.device).reshape(1, -1).repeat(jj.shape[0], 1)
+        pj = jj.reshape(-1, 1).repeat(1, V).to(self.device)
+        if cross and V > 1:
+            cross_mask = ii == jj
+            if torch.any(cross_mask):
+                t, v = self.cross_view_idx[pi[cross_mask], qi[cross_mask]].unbind(-1)
+                pj[cross_mask], qj[cross_mask] = t, v
+        qj = (qj + view_offset) % V
+        di = pi * V + qi
+        dj = pj * V + qj
+        return tuple(x.reshape(-1).contiguous() for x in (pi, qi, di, pj, qj, dj))
+
+    def bundle_adjustment(self, target, weight, disp_damping, ii, jj, t0, t1, n_iters, pose_damping, pose_ep,
+                          motion_only, limited_disp, optimize_intrinsics, optimize_rig_rotation, verbose=False):
+        """buffer.py:373-525, in place on self.poses / self.disps (/ self.intrinsics)."""
+        assert t0 <= t1
+        pi, qi, di, pj, qj, _ = self.expand_edge_multiview(ii, jj)
+        n_poses = max(self.n_frames, int(t1))
+        return slam_ext.dense_ba(
+            self.poses, self.flattened_disps, self.flattened_disps_sens, self.intrinsics, self.rig,
+            target.contiguous(), weight.contiguous(), disp_damping.contiguous(), pi, qi, pj, qj, di, t0, t1, n_iters,
+            pose_damping, pose_ep, motion_only, limited_disp, optimize_intrinsics, optimize_rig_rotation,
+            camera=self.camera_type, alpha=self.ba_config.dense_disp_alpha, n_poses=n_poses, want_info=verbose)
+
+    def reproject_dense_disp(self, ii, jj):
+        """buffer.py:527-548 -> coords [M,ht,wd,2], valid [M,ht,wd,1]."""
+        ii, jj = ii.reshape(-1), jj.reshape(-1)
+        pi, qi, di, pj, qj, _ = self.expand_edge_multiview(ii, jj)
+        return slam_ext.reproject(self.poses, self.flattened_disps, self.intrinsics, self.rig, pi, qi, pj, qj, di,
+                                  camera=self.camera_type)
+
+    def _pinhole_intrinsics_8(self):
+        """camera_model.pinhole() at 1/8 scale (cameras.py:209-213, 338-348; geom.py:335)."""
+        intr = self.intrinsics[:, :4] / 8.0
+        if self.camera_type == "mei":
+            intr = intr.clone()
+            intr[:, 0:2] = intr[:, 0:2] / (1 + self.intrinsics[:, 4:5])
+        return intr.contiguous()
+
+    def frame_distance_dense_disp(self, ii, jj, beta=0.3, bidirectional=True, view_offset=0):
+        """buffer.py:550-593 -> [M, n_views]."""
+        from ..ext.lietorch import SE3
+
+        pi, qi, di, pj, qj, dj = self.expand_edge_multiview(ii, jj, cross=False, view_offset=view_offset)
+        V = self.n_views
+        poses = SE3(self.poses[: self.n_frames])
+        rig = SE3(self.rig)
+        # expand poses into (n v) space: R_v^-1 * G_n   (geom.py:338)
+        exp = (rig.inv().view((1, -1)) * poses.view((-1, 1))).view((-1,)).data.contiguous()
+        intr = self._pinhole_intrinsics_8()
+        d = slam_ext.frame_distance(exp, self.flattened_disps, intr, pi * V + qi, pj * V + qj, qi, qj, di, beta)
+        if bidirectional:
+            d2 = slam_ext.frame_distance(exp, self.flattened_disps, intr, pj * V + qj, pi * V + qi, qj, qi, dj, beta)
+            d = 0.5 * (d + d2)
+        return d.view(-1, V)

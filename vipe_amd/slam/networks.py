@@ -1,0 +1,151 @@
+"""Flow-update operator and correlation blocks - host-side mirror of vipe/slam/networks/droid_net.py.
+
+Same class names, constructor arguments, call signatures and state-dict keys as the reference
+(CorrBlock droid_net.py:48-102, AltCorrBlock :121-176, ConvGRU :373-400, GraphAgg :403-429,
+UpdateModule :432-499) so `FactorGraph.update` host code reads unchanged.  The arithmetic runs in the
+HIP library (vipe_amd/csrc) through `vipe_amd.ext.droid_net_ext`; parameters live in ordinary
+nn.Conv2d holders so reference checkpoints (`update.*` keys) load with `load_state_dict`.
+"""
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..ext import droid_net_ext
+from ..ext.scatter import scatter_mean
+
+
+class CorrBlock:
+    """All-pairs correlation pyramid + 7x7 bilinear lookup (droid_net.py:48-102).
+
+    Layout: level i is [E, h1, w1, h2/2^i, w2/2^i], contiguous, dtype of the feature maps (fp16 under
+    autocast in the reference, factor_graph.py:119) - 25.1 MB/edge at 48x64.
+    """
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=3):
+        self.num_levels = num_levels
+        self.radius = radius
+        batch, num, dim, ht, wd = fmap1.shape
+        self.corr_pyramid = droid_net_ext.corr_pyramid_build(
+            fmap1.reshape(batch * num, dim, ht, wd), fmap2.reshape(batch * num, dim, ht, wd), num_levels)
+
+    def __call__(self, coords):
+        batch, num, ht, wd, _ = coords.shape
+        out = droid_net_ext.corr_pyramid_lookup(self.corr_pyramid, coords.reshape(batch * num, ht, wd, 2), self.radius)
+        return out.view(batch, num, -1, ht, wd)
+
+    def cat(self, other):
+        for i in range(self.num_levels):
+            self.corr_pyramid[i] = torch.cat([self.corr_pyramid[i], other.corr_pyramid[i]], 0)
+        return self
+
+    def __getitem__(self, index):
+        for i in range(self.num_levels):
+            self.corr_pyramid[i] = self.corr_pyramid[i][index]
+        return self
+
+    @staticmethod
+    def corr(fmap1, fmap2):
+        """all-pairs correlation (droid_net.py:94-102): (fmap1/4)^T (fmap2/4) -> [B,num,ht,wd,ht,wd]"""
+        batch, num, dim, ht, wd = fmap1.shape
+        vol = droid_net_ext.corr_volume(fmap1.reshape(batch * num, dim, ht, wd), fmap2.reshape(batch * num, dim, ht, wd))
+        return vol.view(batch, num, ht, wd, ht, wd)
+
+
+class AltCorrBlock:
+    """Volume-free correlation (droid_net.py:121-176): pyramid of channels-last fmaps/4, looked up on the fly."""
+
+    def __init__(self, fmaps, num_levels=4, radius=3):
+        self.num_levels = num_levels
+        self.radius = radius
+        B, N, C, H, W = fmaps.shape
+        f = fmaps.view(B * N, C, H, W) / 4.0
+        self.pyramid = []
+        for i in range(num_levels):
+            self.pyramid.append(f.permute(0, 2, 3, 1).contiguous().view(B, N, H // 2**i, W // 2**i, C))
+            if i + 1 < num_levels:
+                f = F.avg_pool2d(f, 2, stride=2)
+
+    def corr_fn(self, coords, ii, jj):
+        B, N, H, W, S, _ = coords.shape
+        coords = coords.permute(0, 1, 4, 2, 3, 5)
+        corr_list = []
+        for i in range(self.num_levels):
+            fmap1_i = self.pyramid[0][:, ii]
+            fmap2_i = self.pyramid[i][:, jj]
+            coords_i = (coords / 2**i).reshape(B * N, S, H, W, 2).contiguous()
+            fmap1_i = fmap1_i.reshape((B * N,) + fmap1_i.shape[2:])
+            fmap2_i = fmap2_i.reshape((B * N,) + fmap2_i.shape[2:])
+            (corr,) = droid_net_ext.altcorr_forward(fmap1_i.float(), fmap2_i.float(), coords_i, self.radius)
+            corr_list.append(corr.view(B, N, S, -1, H, W).permute(0, 1, 3, 4, 5, 2))
+        return torch.cat(corr_list, dim=2)
+
+    def __call__(self, coords, ii, jj):
+        squeeze = coords.dim() == 5
+        if squeeze:
+            coords = coords.unsqueeze(-2)
+        corr = self.corr_fn(coords, ii, jj)
+        if squeeze:
+            corr = corr.squeeze(-1)
+        return corr.contiguous()
+
+
+class ConvGRU(nn.Module):
+    """Parameter holder with the reference key layout (droid_net.py:373-385)."""
+
+    def __init__(self, h_planes=128, i_planes=128):
+        super().__init__()
+        self.convz = nn.Conv2d(h_planes + i_planes, h_planes, 3, padding=1)
+        self.convr = nn.Conv2d(h_planes + i_planes, h_planes, 3, padding=1)
+        self.convq = nn.Conv2d(h_planes + i_planes, h_planes, 3, padding=1)
+        self.w = nn.Conv2d(h_planes, h_planes, 1, padding=0)
+        self.convz_glo = nn.Conv2d(h_planes, h_planes, 1, padding=0)
+        self.convr_glo = nn.Conv2d(h_planes, h_planes, 1, padding=0)
+        self.convq_glo = nn.Conv2d(h_planes, h_planes, 1, padding=0)
+
+
+class GraphAgg(nn.Module):
+    """Parameter holder (droid_net.py:403-412)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(128, 128, 3, padding=1)
+        self.conv2 = nn.Conv2d(128, 128, 3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+        self.eta = nn.Sequential(nn.Conv2d(128, 1, 3, padding=1), nn.Softplus())
+        self.upmask = nn.Sequential(nn.Conv2d(128, 8 * 8 * 9, 1, padding=0))
+
+
+class UpdateModule(nn.Module):
+    """RaftSLAM update operator (droid_net.py:432-499)."""
+
+    def __init__(self):
+        super().__init__()
+        cor_planes = 4 * (2 * 3 + 1) ** 2
+        self.corr_encoder = nn.Sequential(
+            nn.Conv2d(cor_planes, 128, 1, padding=0), nn.ReLU(inplace=True),
+            nn.Conv2d(128, 128, 3, padding=1), nn.ReLU(inplace=True))
+        self.flow_encoder = nn.Sequential(
+            nn.Conv2d(4, 128, 7, padding=3), nn.ReLU(inplace=True),
+            nn.Conv2d(128, 64, 3, padding=1), nn.ReLU(inplace=True))
+        self.weight = nn.Sequential(
+            nn.Conv2d(128, 128, 3, padding=1), nn.ReLU(inplace=True),
+            nn.Conv2d(128, 2, 3, padding=1), nn.Sigmoid())
+        self.delta = nn.Sequential(
+            nn.Conv2d(128, 128, 3, padding=1), nn.ReLU(inplace=True),
+            nn.Conv2d(128, 2, 3, padding=1))
+        self.gru = ConvGRU(128, 128 + 128 + 64)
+        self.agg = GraphAgg()
+        self._engine = None
+
+    def forward(self, net, inp, corr, flow=None, ix=None, skip_upmask=False):
+        """net, inp [1,E,128,h,w]; corr [1,E,196,h,w]; flow [1,E,4,h,w]; ix [E] -> source-node slot.
+
+        Returns (net, delta[1,E,h,w,2], weight[1,E,h,w,2], eta[1,Nsrc,h,w], upmask) like the reference;
+        `skip_upmask=True` returns None for upmask (the SLAM host code discards it, factor_graph.py:269).
+        """
+        from .update_engine import UpdateEngine
+
+        if self._engine is None or self._engine.device != net.device:
+            self._engine = UpdateEngine(self, net.device)
+        return self._engine.forward(net, inp, corr, flow, ix, skip_upmask)

@@ -1,0 +1,124 @@
+"""Seeded synthetic factor graphs for tests and bench (no video, no weights).
+
+Shapes follow SURVEY.md section 8(d): N keyframes on a smooth trajectory, pinhole
+fx = fy = 0.9 * width, disparities 1/U(1,5), radius-r bidirectional neighbourhood
+edges (what add_proximity_factors(rad=2) always inserts, factor_graph.py:467-470),
+targets = reprojection of the ground truth + N(0, 0.5 px), weights U(0,1),
+eta = 0.01 * softplus(N(0,1)).  Pure numpy so it runs without a GPU.
+"""
+
+from dataclasses import dataclass
+
+import numpy as np
+
+
+def _qmul(a, b):
+    ax, ay, az, aw = np.moveaxis(a, -1, 0)
+    bx, by, bz, bw = np.moveaxis(b, -1, 0)
+    return np.stack([aw * bx + ax * bw + ay * bz - az * by, aw * by + ay * bw + az * bx - ax * bz,
+                     aw * bz + az * bw + ax * by - ay * bx, aw * bw - ax * bx - ay * by - az * bz], -1)
+
+
+def _qrot(q, p):
+    qv, w = q[..., :3], q[..., 3:4]
+    uv = 2 * np.cross(qv, p)
+    return p + w * uv + np.cross(qv, uv)
+
+
+def _qexp(phi):
+    th = np.linalg.norm(phi, axis=-1, keepdims=True)
+    th = np.maximum(th, 1e-12)
+    return np.concatenate([np.sin(0.5 * th) / th * phi, np.cos(0.5 * th)], -1)
+
+
+def _se3_mul(A, B):
+    return np.concatenate([A[..., :3] + _qrot(A[..., 3:], B[..., :3]), _qmul(A[..., 3:], B[..., 3:])], -1)
+
+
+def _se3_inv(A):
+    qi = A[..., 3:] * np.array([-1, -1, -1, 1.0])
+    return np.concatenate([-_qrot(qi, A[..., :3]), qi], -1)
+
+
+def neighbourhood_edges(n, radius=3):
+    """All ordered pairs 0 < |i-j| <= radius (factor_graph.py:396-409); 276 edges at n=48, r=3."""
+    ii, jj = [], []
+    for i in range(n):
+        for j in range(max(i - radius, 0), i):
+            ii += [i, j]
+            jj += [j, i]
+    return np.asarray(ii, dtype=np.int64), np.asarray(jj, dtype=np.int64)
+
+
+@dataclass
+class SyntheticGraph:
+    ht: int
+    wd: int
+    n: int
+    poses_gt: np.ndarray  # [n,7] world->camera
+    disps_gt: np.ndarray  # [n,ht,wd]
+    poses: np.ndarray  # perturbed initial estimate
+    disps: np.ndarray
+    disps_sens: np.ndarray
+    intrinsics: np.ndarray  # [1,4] FULL resolution (divided by 8 inside the path)
+    ii: np.ndarray
+    jj: np.ndarray
+    target: np.ndarray  # [E,ht,wd,2]
+    weight: np.ndarray  # [E,ht,wd,2]
+    eta: np.ndarray  # [n,ht,wd]
+
+
+def reproject_pinhole(poses, disps, intr8, ii, jj):
+    """coords [E,ht,wd,2] of pixels of frame ii seen in frame jj (float64)."""
+    n, ht, wd = disps.shape
+    v, u = np.meshgrid(np.arange(ht, dtype=np.float64), np.arange(wd, dtype=np.float64), indexing="ij")
+    fx, fy, cx, cy = intr8
+    X0 = np.stack([(u - cx) / fx, (v - cy) / fy, np.ones_like(u)], -1)
+    T = _se3_mul(poses[jj], _se3_inv(poses[ii]))
+    d = disps[ii]
+    X1 = _qrot(T[:, None, None, 3:], np.broadcast_to(X0, d.shape + (3,))) + T[:, None, None, :3] * d[..., None]
+    Z = np.where(X1[..., 2] < 0.1, 1.0, X1[..., 2])
+    return np.stack([fx * X1[..., 0] / Z + cx, fy * X1[..., 1] / Z + cy], -1)
+
+
+def make_graph(n=48, height=384, width=512, radius=3, extra_edges=0, seed=1234, depth_prior=False,
+               pose_noise=0.003, disp_noise=0.05):
+    """Config 2/3 of BASELINE.json at the defaults (E=276); config 1 at n=2, 96x128."""
+    rng = np.random.default_rng(seed)
+    ht, wd = height // 8, width // 8
+    k = np.arange(n, dtype=np.float64)
+    c2w_t = np.stack([0.05 * k, np.zeros(n), np.zeros(n)], -1) + rng.normal(0, 0.01, (n, 3))
+    c2w_q = _qexp(rng.normal(0, 0.01, (n, 3)))
+    c2w = np.concatenate([c2w_t, c2w_q], -1)
+    c2w[0] = [0, 0, 0, 0, 0, 0, 1]
+    poses_gt = _se3_inv(c2w)
+    disps_gt = 1.0 / rng.uniform(1.0, 5.0, (n, ht, wd))
+    intr = np.array([[0.9 * width, 0.9 * width, width / 2.0, height / 2.0]])
+    ii, jj = neighbourhood_edges(n, radius)
+    if extra_edges > 0:
+        have = set(zip(ii.tolist(), jj.tolist()))
+        ei, ej = [], []
+        while len(ei) < extra_edges:
+            a, b = rng.integers(0, n, 2)
+            if a != b and (a, b) not in have:
+                have.add((int(a), int(b)))
+                ei.append(int(a))
+                ej.append(int(b))
+        ii = np.concatenate([ii, np.asarray(ei, dtype=np.int64)])
+        jj = np.concatenate([jj, np.asarray(ej, dtype=np.int64)])
+    E = len(ii)
+    target = reproject_pinhole(poses_gt, disps_gt, intr[0] / 8.0, ii, jj) + rng.normal(0, 0.5, (E, ht, wd, 2))
+    weight = rng.uniform(0, 1, (E, ht, wd, 2))
+    eta = 0.01 * np.log1p(np.exp(rng.normal(0, 1, (n, ht, wd))))
+    # perturbed starting point (pose 0 stays the gauge)
+    dq = _qexp(rng.normal(0, pose_noise, (n, 3)))
+    dT = np.concatenate([rng.normal(0, pose_noise, (n, 3)), dq], -1)
+    dT[0] = [0, 0, 0, 0, 0, 0, 1]
+    poses = _se3_mul(dT, poses_gt)
+    poses[:, 3:] /= np.linalg.norm(poses[:, 3:], axis=-1, keepdims=True)
+    disps = disps_gt * (1 + rng.normal(0, disp_noise, disps_gt.shape))
+    sens = disps_gt * (1 + rng.normal(0, 0.05, disps_gt.shape)) if depth_prior else np.zeros_like(disps_gt)
+    f32 = np.float32
+    return SyntheticGraph(ht, wd, n, poses_gt.astype(f32), disps_gt.astype(f32), poses.astype(f32),
+                          disps.astype(f32), sens.astype(f32), intr.astype(f32), ii, jj,
+                          target.astype(f32), weight.astype(f32), eta.astype(f32))
