@@ -30,6 +30,7 @@ def test_header_cites_reference_interfaces():
 def test_argument_errors_do_not_launch():
     L = _lib.lib()
     assert L.vipe_corr_index_forward(None, None, None, 1, 4, 4, 4, 4, 3, 0, None) == -1
+    assert L.vipe_corr_index_forward(None, None, None, 0, 4, 4, 4, 4, 3, 0, None) == 0  # empty batch
     p = _lib.BAParams(n_poses=0)
     assert L.vipe_dense_ba_workspace_bytes(ctypes.byref(p)) < 0
     p = _lib.BAParams(n_poses=48, n_views=1, ht=48, wd=64, M=276)

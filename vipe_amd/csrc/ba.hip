@@ -563,17 +563,35 @@ __global__ __launch_bounds__(TILE) void ba_accum_kernel(BAArgs a) {
 
 // ------------------------------------------------------------------------------------------------ solve
 
-__global__ __launch_bounds__(1024) void ba_solve_kernel(BAArgs a) {
+// Dense Cholesky solve of the reduced system by ONE workgroup (16 waves), fp64.
+//   S: lower triangle, row-major, ld; row n holds the rhs, so the forward substitution y = L^-1 g falls out of
+//   the factorisation as the last panel row.  Right-looking, NB = 24 columns per step:
+//     1. diagonal block: wave 0, one matrix row per lane in registers, column-by-column (Crout) with the
+//        finished columns published to LDS;
+//     2. panel: one row per thread, X Lkk^T = A by forward substitution against Lkk in LDS; the solved panel is
+//        kept TRANSPOSED in LDS (PT[j][row]) so the update below reads it without bank conflicts;
+//     3. trailing update A22 -= P P^T: 1x4 register tiles per thread, panel from LDS, S read-modify-write in
+//        32-byte row segments.
+//   Then blocked backward substitution L^T x = y and the pose / intrinsics retraction.
+constexpr int NB = 24;
+
+struct SolveLds {
+  double Lkk[NB][NB + 1];
+  double xk[NB];
+  int fail;
+};
+
+__global__ __launch_bounds__(1024) void ba_solve_kernel(BAArgs a, int panel_cap) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  SolveLds& sh = *reinterpret_cast<SolveLds*>(smem_raw);
+  double* PT = reinterpret_cast<double*>(smem_raw + ((sizeof(SolveLds) + 15) / 16) * 16);  // [NB][panel_cap]
   const vipe_ba_params& prm = a.p;
   const BAWs& w = a.w;
   const int t = threadIdx.x;
   const int n = w.info[3], n_free = w.info[0];
   const int ld = w.ld;
   double* S = w.S;
-  __shared__ double Lkk[6][6];
-  __shared__ double xk[6];
-  __shared__ int fail;
-  if (t == 0) fail = 0;
+  if (t == 0) sh.fail = 0;
   if (n == 0) return;
   // LM damping on the diagonal: += ep + lambda * diag(H)  (matrix.py:179-186)
   for (int dd = t; dd < n; dd += 1024) {
@@ -582,78 +600,149 @@ __global__ __launch_bounds__(1024) void ba_solve_kernel(BAArgs a) {
     S[(int64_t)dd * ld + dd] += ep + lam * w.Hd[dd];
   }
   __syncthreads();
-  // blocked right-looking Cholesky of the lower triangle; row n carries the rhs (=> y = L^-1 g)
-  for (int k0 = 0; k0 < n; k0 += 6) {
-    const int bw = min(6, n - k0);
-    if (t == 0) {
-      double A[6][6];
-      for (int r = 0; r < bw; ++r)
-        for (int c = 0; c <= r; ++c) A[r][c] = S[(int64_t)(k0 + r) * ld + k0 + c];
-      for (int j = 0; j < bw; ++j) {
-        double dj = A[j][j];
-        for (int m = 0; m < j; ++m) dj -= A[j][m] * A[j][m];
-        if (!(dj > 0.0)) { fail = 1; dj = 1.0; }
-        const double l = sqrt(dj);
-        A[j][j] = l;
-        for (int r = j + 1; r < bw; ++r) {
-          double s = A[r][j];
-          for (int m = 0; m < j; ++m) s -= A[r][m] * A[j][m];
-          A[r][j] = s / l;
+  const bool use_lds_panel = (n + 1) <= panel_cap;
+
+  for (int k0 = 0; k0 < n; k0 += NB) {
+    const int bw = min(NB, n - k0);
+    // ---- 1. diagonal block (wave 0)
+    if (t < WAVE) {
+      double row[NB];
+      const int r = t;
+      if (r < bw) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c) row[c] = (c <= r && c < bw) ? S[(int64_t)(k0 + r) * ld + k0 + c] : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        if (j < bw) {
+          double sacc = 0.0;
+          if (r >= j && r < bw) {
+            sacc = row[j];
+#pragma unroll
+            for (int m = 0; m < NB; ++m)
+              if (m < j) sacc -= row[m] * sh.Lkk[j][m];
+          }
+          // pivot from lane j
+          double piv = __shfl(sacc, j, WAVE);
+          if (!(piv > 0.0)) {
+            if (r == 0) sh.fail = 1;
+            piv = 1.0;
+          }
+          const double l = sqrt(piv);
+          if (r >= j && r < bw) {
+            row[j] = (r == j) ? l : sacc / l;
+            sh.Lkk[r][j] = row[j];
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
       }
-      for (int r = 0; r < bw; ++r)
-        for (int c = 0; c <= r; ++c) {
-          Lkk[r][c] = A[r][c];
-          S[(int64_t)(k0 + r) * ld + k0 + c] = A[r][c];
-        }
-    }
-    __syncthreads();
-    const int r0 = k0 + bw;  // first row of the panel; rows r0..n (n = rhs row)
-    for (int r = r0 + t; r <= n; r += 1024) {
-      double x[6];
-      double* row = S + (int64_t)r * ld + k0;
-      for (int j = 0; j < bw; ++j) {
-        double s = row[j];
-        for (int m = 0; m < j; ++m) s -= x[m] * Lkk[j][m];
-        x[j] = s / Lkk[j][j];
+      if (r < bw) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+          if (c <= r) S[(int64_t)(k0 + r) * ld + k0 + c] = row[c];
       }
-      for (int j = 0; j < bw; ++j) row[j] = x[j];
     }
     __syncthreads();
-    const int m = n - r0 + 1;  // panel rows incl. rhs
-    for (int64_t idx = t; idx < (int64_t)m * m; idx += 1024) {
-      const int rr = (int)(idx / m), cc = (int)(idx % m);
-      if (cc > rr || cc == m - 1) continue;  // lower triangle; the rhs row has no diagonal / column
-      const double* pr = S + (int64_t)(r0 + rr) * ld + k0;
-      const double* pc = S + (int64_t)(r0 + cc) * ld + k0;
-      double s = 0.0;
-      for (int j = 0; j < bw; ++j) s += pr[j] * pc[j];
-      S[(int64_t)(r0 + rr) * ld + r0 + cc] -= s;
+    // ---- 2. panel rows r0..n (row n = rhs)
+    const int r0 = k0 + bw;
+    const int m = n - r0 + 1;
+    for (int pr = t; pr < m; pr += 1024) {
+      double x[NB];
+      double* grow = S + (int64_t)(r0 + pr) * ld + k0;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) x[j] = j < bw ? grow[j] : 0.0;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        if (j < bw) {
+          double sacc = x[j];
+#pragma unroll
+          for (int q = 0; q < NB; ++q)
+            if (q < j) sacc -= x[q] * sh.Lkk[j][q];
+          x[j] = sacc / sh.Lkk[j][j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        if (j < bw) {
+          grow[j] = x[j];
+          if (use_lds_panel) PT[j * panel_cap + pr] = x[j];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- 3. trailing update: rows rr in [0,m), cols cc <= rr, cc < m-1 (the rhs row has no column)
+    {
+      const int tx = t & 31, ty = t >> 5;  // 32 x 32 threads, each a 1 x 4 tile
+      for (int rr = ty; rr < m; rr += 32) {
+        const int cmax = min(rr, m - 2);  // inclusive
+        for (int c4 = tx * 4; c4 <= cmax; c4 += 128) {
+          double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+          if (use_lds_panel) {
+#pragma unroll 4
+            for (int j = 0; j < bw; ++j) {
+              const double pr_ = PT[j * panel_cap + rr];
+              const double* pc = PT + j * panel_cap + c4;
+              acc0 += pr_ * pc[0]; acc1 += pr_ * pc[1]; acc2 += pr_ * pc[2]; acc3 += pr_ * pc[3];
+            }
+          } else {
+            const double* prw = S + (int64_t)(r0 + rr) * ld + k0;
+            for (int j = 0; j < bw; ++j) {
+              const double pr_ = prw[j];
+              acc0 += pr_ * S[(int64_t)(r0 + c4) * ld + k0 + j];
+              if (c4 + 1 <= cmax) acc1 += pr_ * S[(int64_t)(r0 + c4 + 1) * ld + k0 + j];
+              if (c4 + 2 <= cmax) acc2 += pr_ * S[(int64_t)(r0 + c4 + 2) * ld + k0 + j];
+              if (c4 + 3 <= cmax) acc3 += pr_ * S[(int64_t)(r0 + c4 + 3) * ld + k0 + j];
+            }
+          }
+          double* dst = S + (int64_t)(r0 + rr) * ld + r0 + c4;
+          dst[0] -= acc0;
+          if (c4 + 1 <= cmax) dst[1] -= acc1;
+          if (c4 + 2 <= cmax) dst[2] -= acc2;
+          if (c4 + 3 <= cmax) dst[3] -= acc3;
+        }
+      }
     }
     __syncthreads();
   }
-  // backward substitution L^T x = y, y in row n
+
+  // ---- backward substitution L^T x = y (y = row n), blocks from the last to the first
   double* yrow = S + (int64_t)n * ld;
-  for (int k0 = ((n - 1) / 6) * 6; k0 >= 0; k0 -= 6) {
-    const int bw = min(6, n - k0);
-    if (t == 0) {
-      double x[6];
-      for (int j = bw - 1; j >= 0; --j) {
-        double s = yrow[k0 + j];
-        for (int m = j + 1; m < bw; ++m) s -= S[(int64_t)(k0 + m) * ld + k0 + j] * x[m];
-        x[j] = s / S[(int64_t)(k0 + j) * ld + k0 + j];
+  for (int k0 = ((n - 1) / NB) * NB; k0 >= 0; k0 -= NB) {
+    const int bw = min(NB, n - k0);
+    if (t < WAVE) {
+      // stage the diagonal block in LDS (one coalesced pass), then lane j owns x[j]
+      for (int idx = t; idx < bw * bw; idx += WAVE) {
+        const int rr = idx / bw, cc = idx % bw;
+        if (cc <= rr) sh.Lkk[rr][cc] = S[(int64_t)(k0 + rr) * ld + k0 + cc];
       }
-      for (int j = 0; j < bw; ++j) { xk[j] = x[j]; yrow[k0 + j] = x[j]; }
+      const double yj = t < bw ? yrow[k0 + t] : 0.0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      double xj = 0.0;
+      for (int j = bw - 1; j >= 0; --j) {
+        // s = y[j] - sum_{m>j} L[k0+m][k0+j] * x[m]
+        double part = 0.0;
+        if (t > j && t < bw) part = sh.Lkk[t][j] * xj;
+        part = wave_sum(part);
+        if (t == j) xj = (yj - part) / sh.Lkk[j][j];
+      }
+      if (t < bw) {
+        sh.xk[t] = xj;
+        yrow[k0 + t] = xj;
+      }
     }
     __syncthreads();
     for (int c = t; c < k0; c += 1024) {
-      double s = 0.0;
-      for (int m = 0; m < bw; ++m) s += S[(int64_t)(k0 + m) * ld + c] * xk[m];
-      yrow[c] -= s;
+      double sacc = 0.0;
+      for (int q = 0; q < bw; ++q) sacc += S[(int64_t)(k0 + q) * ld + c] * sh.xk[q];
+      yrow[c] -= sacc;
     }
     __syncthreads();
   }
-  const bool bad = fail != 0;
+  const bool bad = sh.fail != 0;
   if (t == 0 && bad) w.info[2] += 1;
   for (int dd = t; dd < n; dd += 1024) {
     double x = yrow[dd];
@@ -726,12 +815,22 @@ int run_iters(const BAArgs& a, hipStream_t s) {
   const int tiles = (a.P + TILE - 1) / TILE;
   const size_t sbytes = sizeof(double) * (size_t)a.w.ld * a.w.ld;
   const size_t nmax = (size_t)a.w.ld - 1;
+  // LDS panel of the solve kernel: [NB][panel_cap] doubles next to the fixed part, up to ~150 KB
+  const size_t fixed = ((sizeof(SolveLds) + 15) / 16) * 16;
+  int panel_cap = (int)std::min<size_t>(nmax + 1, (150 * 1024 - fixed) / (NB * sizeof(double)));
+  panel_cap = (panel_cap + 3) & ~3;
+  const size_t solve_lds = fixed + (size_t)NB * panel_cap * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
   for (int it = 0; it < a.p.n_iters; ++it) {
     hipError_t e1 = hipMemsetAsync(a.w.S, 0, sbytes, s);
     hipError_t e2 = hipMemsetAsync(a.w.Hd, 0, sizeof(double) * nmax, s);
     if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
     ba_accum_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
-    ba_solve_kernel<<<1, 1024, 0, s>>>(a);
+    ba_solve_kernel<<<1, 1024, solve_lds, s>>>(a, panel_cap);
     if (!a.p.motion_only) ba_retract_kernel<F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
   }
   return vipe_launch_status();

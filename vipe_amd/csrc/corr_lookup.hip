@@ -22,7 +22,12 @@ template <>
 struct Acc<half_t> {
   using reg = float;  // holds a half-representable value
   static __device__ __forceinline__ reg load(const half_t* p) { return (float)*p; }
-  static __device__ __forceinline__ reg weight(float w) { return (float)(half_t)w; }
+  static __device__ __forceinline__ reg weight(float w) {
+    // the f32 product must be ROUNDED TO f32 before the half conversion (scalar_t(dx * dy) in the reference);
+    // without the barrier hipcc fuses mul + cvt into v_fma_mixlo_f16, which rounds the exact product once
+    asm volatile("" : "+v"(w));
+    return (float)(half_t)w;
+  }
   static __device__ __forceinline__ reg madd(reg acc, reg s, reg w) {
     float prod = (float)(half_t)(s * w);  // exact product of two halves, rounded once to half
     return (float)(half_t)(acc + prod);
@@ -220,9 +225,9 @@ int launch_pyr(const LevelPtrs& lv, const float* coords, void* out, int B, int h
 
 VIPE_EXPORT int vipe_corr_index_forward(const void* d_volume, const float* d_coords, void* d_corr, int B, int h1,
                                         int w1, int h2, int w2, int radius, int dtype, void* stream) {
-  VIPE_CHECK_ARG(d_volume && d_coords && d_corr);
   VIPE_CHECK_ARG(B >= 0 && h1 > 0 && w1 > 0 && h2 > 0 && w2 > 0 && B <= 65535);
   if (B == 0) return VIPE_OK;
+  VIPE_CHECK_ARG(d_volume && d_coords && d_corr);
   hipStream_t s = as_stream(stream);
   switch (dtype) {
     case VIPE_F16: return launch_fwd<half_t>(d_volume, d_coords, d_corr, B, h1, w1, h2, w2, radius, s);
@@ -234,9 +239,9 @@ VIPE_EXPORT int vipe_corr_index_forward(const void* d_volume, const float* d_coo
 
 VIPE_EXPORT int vipe_corr_index_backward(const float* d_coords, const void* d_corr_grad, void* d_volume_grad, int B,
                                          int h1, int w1, int h2, int w2, int radius, int dtype, void* stream) {
-  VIPE_CHECK_ARG(d_coords && d_corr_grad && d_volume_grad);
   VIPE_CHECK_ARG(B >= 0 && h1 > 0 && w1 > 0 && h2 > 0 && w2 > 0 && B <= 65535);
   if (B == 0) return VIPE_OK;
+  VIPE_CHECK_ARG(d_coords && d_corr_grad && d_volume_grad);
   hipStream_t s = as_stream(stream);
   switch (dtype) {
     case VIPE_F16: return launch_bwd<half_t>(d_coords, d_corr_grad, d_volume_grad, B, h1, w1, h2, w2, radius, s);
@@ -249,10 +254,10 @@ VIPE_EXPORT int vipe_corr_index_backward(const float* d_coords, const void* d_co
 VIPE_EXPORT int vipe_corr_pyramid_lookup(const void* const* h_levels, const float* d_coords, void* d_out, int B,
                                          int h1, int w1, int h2, int w2, int num_levels, int radius, int dtype,
                                          void* stream) {
-  VIPE_CHECK_ARG(h_levels && d_coords && d_out);
   VIPE_CHECK_ARG(num_levels >= 1 && num_levels <= 8 && B >= 0 && B <= 65535);
   VIPE_CHECK_ARG((h2 >> (num_levels - 1)) >= 1 && (w2 >> (num_levels - 1)) >= 1);
   if (B == 0) return VIPE_OK;
+  VIPE_CHECK_ARG(h_levels && d_coords && d_out);
   LevelPtrs lv;
   for (int i = 0; i < num_levels; ++i) {
     VIPE_CHECK_ARG(h_levels[i]);

@@ -1,0 +1,146 @@
+"""Factor graph: edge lists + the update iteration (host-side mirror of vipe/slam/components/factor_graph.py).
+
+`update()` is the hot loop A of SURVEY.md section 3.3 (factor_graph.py:231-314): reproject -> 4-level
+correlation lookup -> flow-update operator -> dense BA.  Per iteration it issues 2 + (GRU convolutions) +
+1 C-ABI calls on the current stream and never synchronises the host (the reference syncs in torch.unique,
+scatter_mean's index.max(), every _tmult_mat_elements and the CPU spsolve).
+"""
+
+import torch
+
+from ..ext import slam_ext
+from .networks import CorrBlock
+
+
+class FactorGraph:
+    def __init__(self, update_module, buffer, device, max_factors=48, incremental=True):
+        self.update_op = update_module
+        self.buffer = buffer
+        self.device = device
+        self.max_factors = max_factors
+        self.incremental = incremental
+        ht, wd = buffer.height // 8, buffer.width // 8
+        self.ht, self.wd = ht, wd
+        self.ii = torch.as_tensor([], dtype=torch.long, device=device)
+        self.jj = torch.as_tensor([], dtype=torch.long, device=device)
+        self.age = torch.as_tensor([], dtype=torch.long, device=device)
+        self.damping = 1e-6 * torch.ones_like(buffer.flattened_disps)  # factor_graph.py:76
+        self.target = torch.zeros([1, 0, ht, wd, 2], device=device, dtype=torch.float)
+        self.weight = torch.zeros([1, 0, ht, wd, 2], device=device, dtype=torch.float)
+        self.corr, self.f_net, self.inp = None, None, None
+        self.ii_inac = torch.as_tensor([], dtype=torch.long, device=device)
+        self.jj_inac = torch.as_tensor([], dtype=torch.long, device=device)
+        self.target_inac = torch.zeros([1, 0, ht, wd, 2], device=device, dtype=torch.float)
+        self.weight_inac = torch.zeros([1, 0, ht, wd, 2], device=device, dtype=torch.float)
+        self._plan = None
+
+    def _filter_repeated_edges(self, ii, jj):
+        """factor_graph.py:96-108 (one D2H copy instead of a .item() per edge)."""
+        have = set(zip(self.ii.tolist(), self.jj.tolist())) | set(zip(self.ii_inac.tolist(), self.jj_inac.tolist()))
+        keep = torch.tensor([(i, j) not in have for i, j in zip(ii.tolist(), jj.tolist())], dtype=torch.bool,
+                            device=ii.device)
+        return ii[keep], jj[keep]
+
+    @torch.no_grad()
+    def add_factors(self, ii, jj, remove=False):
+        """factor_graph.py:119-173."""
+        ii = torch.as_tensor(ii, dtype=torch.long, device=self.device)
+        jj = torch.as_tensor(jj, dtype=torch.long, device=self.device)
+        ii, jj = self._filter_repeated_edges(ii, jj)
+        if ii.shape[0] == 0:
+            return
+        if (self.max_factors > 0 and self.ii.shape[0] + ii.shape[0] > self.max_factors and self.corr is not None
+                and remove):
+            ix = torch.arange(len(self.age))[torch.argsort(self.age).cpu()]
+            self.rm_factors(ix >= self.max_factors - ii.shape[0], store=True)
+        pi, qi, _, pj, qj, _ = self.buffer.expand_edge_multiview(ii, jj)
+        if self.incremental:
+            corr = CorrBlock(self.buffer.fmaps[pi, qi][None], self.buffer.fmaps[pj, qj][None])
+            self.corr = corr if self.corr is None else self.corr.cat(corr)
+            inp = self.buffer.inps[pi, qi][None]
+            self.inp = inp if self.inp is None else torch.cat([self.inp, inp], 1)
+        target, _ = self.buffer.reproject_dense_disp(ii, jj)
+        target = target[None]
+        self.ii = torch.cat([self.ii, ii], 0)
+        self.jj = torch.cat([self.jj, jj], 0)
+        self.age = torch.cat([self.age, torch.zeros_like(ii)], 0)
+        net = self.buffer.nets[pi, qi][None]
+        self.f_net = net if self.f_net is None else torch.cat([self.f_net, net], 1)
+        self.target = torch.cat([self.target, target], 1)
+        self.weight = torch.cat([self.weight, torch.zeros_like(target)], 1)
+        self._plan = None
+
+    @torch.no_grad()
+    def rm_factors(self, mask, store=False):
+        """factor_graph.py:175-202."""
+        mask = mask.to(self.device)
+        exp_mask = mask.view(-1, 1).repeat(1, self.buffer.n_views).view(-1)
+        if store:
+            self.ii_inac = torch.cat([self.ii_inac, self.ii[mask]], 0)
+            self.jj_inac = torch.cat([self.jj_inac, self.jj[mask]], 0)
+            self.target_inac = torch.cat([self.target_inac, self.target[:, exp_mask]], 1)
+            self.weight_inac = torch.cat([self.weight_inac, self.weight[:, exp_mask]], 1)
+        self.ii, self.jj, self.age = self.ii[~mask], self.jj[~mask], self.age[~mask]
+        if self.corr is not None:
+            self.corr = self.corr[~exp_mask]
+        if self.f_net is not None:
+            self.f_net = self.f_net[:, ~exp_mask]
+        if self.inp is not None:
+            self.inp = self.inp[:, ~exp_mask]
+        self.target = self.target[:, ~exp_mask]
+        self.weight = self.weight[:, ~exp_mask]
+        self._plan = None
+
+    def add_neighborhood_factors(self, t0, t1, r=3):
+        """factor_graph.py:396-409 (mono: c = 0)."""
+        ii, jj = torch.meshgrid(torch.arange(t0, t1), torch.arange(t0, t1), indexing="ij")
+        ii, jj = ii.reshape(-1), jj.reshape(-1)
+        keep = ((ii - jj).abs() > 0) & ((ii - jj).abs() <= r)
+        self.add_factors(ii[keep], jj[keep])
+
+    def _edge_plan(self):
+        """Index tensors that only change when the edge set changes (the reference recomputes them, with a
+        torch.unique sync, on every update: factor_graph.py:267-268)."""
+        if self._plan is None:
+            pi, qi, di, pj, qj, _ = self.buffer.expand_edge_multiview(self.ii, self.jj)
+            du, dix = torch.unique(di, return_inverse=True)
+            self._plan = dict(pi=pi, qi=qi, di=di, pj=pj, qj=qj, du=du, dix=dix, n_src=int(du.numel()),
+                              t0=int(max(1, self.ii.min().item() + 1)),
+                              t1=int(max(self.ii.max().item(), self.jj.max().item()) + 1))
+        return self._plan
+
+    @torch.no_grad()
+    def update(self, t0=None, t1=None, itrs=3, use_inactive=False, motion_only=False, fixed_motion=False,
+               limited_disp=False):
+        """run update operator on factor graph (factor_graph.py:230-314)."""
+        assert self.incremental and self.corr is not None and self.inp is not None and self.f_net is not None
+        assert not (motion_only and fixed_motion)
+        P = self._edge_plan()
+        t0 = P["t0"] if t0 is None else t0
+        t1 = P["t1"] if t1 is None else t1
+        buf = self.buffer
+        # motion features + coords1 in one launch (factor_graph.py:253-261)
+        coords1, motn = slam_ext.reproject_motion(buf.poses, buf.flattened_disps, buf.intrinsics, buf.rig, P["pi"],
+                                                  P["qi"], P["pj"], P["qj"], P["di"], self.target[0].contiguous(),
+                                                  camera=buf.camera_type)
+        corr = self.corr(coords1[None])  # [1,E,196,h,w], one launch for the 4 levels
+        self.f_net, delta, weight, damping, _ = self.update_op(self.f_net, self.inp, corr, motn[None], ix=P["dix"],
+                                                                skip_upmask=True, n_src=P["n_src"])
+        weight = weight.float()
+        weight[:, buf.masks[P["pi"], P["qi"]]] = 0.0  # factor_graph.py:272
+        self.target = coords1[None] + delta.float()
+        self.weight = weight
+        self.damping[P["du"]] = damping[0]
+        if use_inactive:
+            m = (self.ii_inac >= t0 - 3) & (self.jj_inac >= t0 - 3)
+            ii = torch.cat([self.ii_inac[m], self.ii], 0)
+            jj = torch.cat([self.jj_inac[m], self.jj], 0)
+            exp_m = m.view(-1, 1).repeat(1, buf.n_views).view(-1)
+            target = torch.cat([self.target_inac[:, exp_m], self.target], 1)
+            weight = torch.cat([self.weight_inac[:, exp_m], self.weight], 1)
+        else:
+            ii, jj, target, weight = self.ii, self.jj, self.target, self.weight
+        E = target.shape[1]
+        buf.bundle_adjustment(target.view(E, -1, 2), weight.view(E, -1, 2), self.damping, ii, jj, t0,
+                              t1 if not fixed_motion else t0, itrs, 1e-3, 0.1, motion_only, limited_disp, False, False)
+        self.age += 1

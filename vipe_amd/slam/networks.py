@@ -138,7 +138,7 @@ class UpdateModule(nn.Module):
         self.agg = GraphAgg()
         self._engine = None
 
-    def forward(self, net, inp, corr, flow=None, ix=None, skip_upmask=False):
+    def forward(self, net, inp, corr, flow=None, ix=None, skip_upmask=False, n_src=None):
         """net, inp [1,E,128,h,w]; corr [1,E,196,h,w]; flow [1,E,4,h,w]; ix [E] -> source-node slot.
 
         Returns (net, delta[1,E,h,w,2], weight[1,E,h,w,2], eta[1,Nsrc,h,w], upmask) like the reference;
@@ -148,4 +148,4 @@ class UpdateModule(nn.Module):
 
         if self._engine is None or self._engine.device != net.device:
             self._engine = UpdateEngine(self, net.device)
-        return self._engine.forward(net, inp, corr, flow, ix, skip_upmask)
+        return self._engine.forward(net, inp, corr, flow, ix, skip_upmask, n_src)
