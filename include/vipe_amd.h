@@ -59,6 +59,12 @@ int vipe_corr_index_backward(const float* d_coords, const void* d_corr_grad, voi
 int vipe_corr_pyramid_lookup(const void* const* h_levels, const float* d_coords, void* d_out, int B, int h1, int w1,
                              int h2, int w2, int num_levels, int radius, int dtype, void* stream);
 
+/* [fused] same lookup written channels-last for the flow-update operator: out [B,h1,w1,channel_stride],
+ * channel = level*(2r+1)^2 + x_off*(2r+1) + y_off, channels beyond num_levels*(2r+1)^2 zero filled. */
+int vipe_corr_pyramid_lookup_nhwc(const void* const* h_levels, const float* d_coords, void* d_out, int B, int h1,
+                                  int w1, int h2, int w2, int num_levels, int radius, int dtype, int channel_stride,
+                                  void* stream);
+
 /* [fused] CorrBlock.corr + pyramid (droid_net.py:56-69,94-102): volume = (f1/4)^T (f2/4) on MFMA (fp16 in,
  * fp32 accumulate, stored as dtype), then 2x2 average pooling of the target dims for levels 1..num_levels-1.
  * fmap1, fmap2 [B,C,h,w] f16; h_levels: host array of num_levels device pointers (outputs). C % 32 == 0. */
@@ -144,6 +150,12 @@ int vipe_reproject_motion(const float* d_poses, const float* d_disps, const floa
                           const int64_t* d_pi, const int64_t* d_qi, const int64_t* d_pj, const int64_t* d_qj,
                           const int64_t* d_di, const float* d_target, float* d_coords, void* d_motn, int M, int ht,
                           int wd, int n_views, int camera, float intr_factor, int motn_dtype, void* stream);
+/* same with motn written channels-last [M,ht,wd,4] fp16 (the layout the MFMA convolutions read) */
+int vipe_reproject_motion_nhwc(const float* d_poses, const float* d_disps, const float* d_intrinsics,
+                               const float* d_rig, const int64_t* d_pi, const int64_t* d_qi, const int64_t* d_pj,
+                               const int64_t* d_qj, const int64_t* d_di, const float* d_target, float* d_coords,
+                               void* d_motn, int M, int ht, int wd, int n_views, int camera, float intr_factor,
+                               void* stream);
 
 /* Dense bundle adjustment with the LIVE semantics of GraphBuffer.bundle_adjustment (buffer.py:373-525,
  * solver.py:117-197, terms.py:94-303): Gauss-Newton on SE3 (+) per-pixel inverse depth (+ optional
@@ -254,6 +266,24 @@ int vipe_conv_pack_weights(const void* d_w_oihw, void* d_w_packed, int Cout, int
 int vipe_conv2d_nhwc_f16(const void* d_x, const void* d_w_packed, const float* d_bias, const float* d_extra,
                          void* d_y, int B, int H, int W, int Cin, int cin_total, int cin_off, int Cout,
                          int cout_total, int cout_off, int KH, int KW, int act, void* stream);
+
+/* padded sizes of the packed weight tensor [k_pad/64][cout_pad][64] (any pointer may be NULL) */
+int vipe_conv_packed_dims(int Cout, int Cin, int KH, int KW, int* cout_pad, int* cin_pad, int* k_pad);
+
+/* [fused] the flow-update operator's fused convolutions (droid_net.py:373-499).  Input channels [0,split)
+ * come from x0, [split,Cin) from x1 (the concatenations of the reference are never materialised).  mode:
+ *   0 plain   y = act(conv + bias + extra[image])
+ *   1 GLO     fout[image,c] += sum_pixels sigmoid(conv+bias)[c] * net[c]          (ConvGRU global context, :392-393)
+ *   2 ZR      Cout = 256: y[:, c] = z = sigmoid(.), c < 128;  y2[:, c-128] = sigmoid(.) * net   (:395-397)
+ *   3 Q       Cout = 128: y = (1 - z) * net + z * tanh(conv + bias + extra)                   (:397-399)
+ *   4 HEADS   Cout = 4: fout[pixel] = (delta_x, delta_y, sigmoid(w_x), sigmoid(w_y)) as float (:486-490)
+ *   5 ETA     Cout = 1: fout[pixel] = 0.01 * softplus(conv + bias)                            (:410,429)
+ */
+int vipe_conv2d_fused(const void* d_x0, int x0_ctot, int x0_coff, const void* d_x1, int x1_ctot, int x1_coff,
+                      int split, const void* d_w_packed, const float* d_bias, const float* d_extra, int extra_stride,
+                      int extra_off, void* d_y, int y_ctot, int y_coff, void* d_y2, int y2_ctot, int y2_coff,
+                      const void* d_net, int net_ctot, int net_coff, const void* d_z, float* d_fout, int B, int H,
+                      int W, int Cin, int Cout, int KH, int KW, int act, int mode, void* stream);
 
 #ifdef __cplusplus
 }

@@ -286,3 +286,61 @@ def test_dense_ba_full_size_properties():
     assert e[1] < e[0] and e[2] < e[1] and e[3] < e[2]
     p2, d2, _, _ = run_hip_ba(g, g.intrinsics, "pinhole", dict(bk, n_iters=3))
     assert np.abs(p2 - p).max() < 1e-5 and np.abs(d2 - d).max() < 1e-4 * np.abs(d).max()
+
+
+# ------------------------------------------------------------------------------------------------ flow-update operator
+
+
+def _seeded_update_inputs(E, ht, wd):
+    gen = torch.Generator().manual_seed(1)
+    net = torch.randn(1, E, 128, ht, wd, generator=gen).tanh()
+    inp = torch.randn(1, E, 128, ht, wd, generator=gen).relu()
+    cor = torch.randn(1, E, 196, ht, wd, generator=gen)
+    flow = torch.randn(1, E, 4, ht, wd, generator=gen) * 4
+    return net, inp, cor, flow
+
+
+@pytest.mark.parametrize("backend", ["hip", "miopen"])
+def test_update_module_matches_reference_fixture(backend):
+    """MFMA convolutions (fp16 in, fp32 accumulate) vs the reference UpdateModule output (fp32 CPU fixture).
+    Tolerance: fp16 activations through ~8 layers -> 2e-2 absolute on O(1) outputs (the reference itself runs
+    these convolutions under fp16 autocast, factor_graph.py:230)."""
+    from vipe_amd.slam.networks import UpdateModule
+    from vipe_amd.slam.update_engine import UpdateEngine
+    G = np.load(os.path.join(GOLD, "update_module_reference.npz"))
+    torch.manual_seed(0)
+    um = UpdateModule().eval()
+    net, inp, cor, flow = _seeded_update_inputs(5, 12, 16)
+    ix = torch.from_numpy(G["ix"])
+    eng = UpdateEngine(um, dev(), backend=backend)
+    n2, delta, weight, eta, upmask = eng.forward(net.to(dev()).half(), inp.to(dev()).half(), cor.to(dev()).half(),
+                                                 flow.to(dev()).half(), ix.to(dev()))
+    torch.cuda.synchronize()
+    assert np.abs(n2[:, :, ::4].float().cpu().numpy() - G["out_net_sub"]).max() < 2e-2
+    assert np.abs(delta.float().cpu().numpy() - G["out_delta"]).max() < 2e-2
+    assert np.abs(weight.float().cpu().numpy() - G["out_weight"]).max() < 1e-2
+    assert np.abs(eta.float().cpu().numpy() - G["out_eta"]).max() < 2e-4
+    assert np.abs(upmask[:, :, ::16].float().cpu().numpy() - G["out_upmask_sub"]).max() < 2e-2
+
+
+def test_conv_mfma_against_torch_fp32():
+    """Single convolutions through the C ABI vs torch fp32 conv2d of the same fp16-rounded operands."""
+    import torch.nn.functional as F
+    from vipe_amd._lib import check, lib, ptr, stream_ptr
+    from vipe_amd.slam.update_engine import _Packed
+    torch.manual_seed(3)
+    for (B, H, W, cin, cout, k, act) in [(3, 12, 16, 128, 128, 3, "relu"), (2, 9, 7, 448, 128, 3, "none"),
+                                         (2, 12, 16, 200, 128, 1, "relu"), (2, 10, 12, 4, 128, 7, "relu"),
+                                         (1, 6, 8, 128, 64, 3, "tanh"), (4, 5, 5, 64, 576, 1, "sigmoid")]:
+        x = (torch.randn(B, H, W, cin) * 0.5).half().to(dev())
+        w = (torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5).half()
+        b = torch.randn(cout) * 0.1
+        pk = _Packed(w, b, dev())
+        y = torch.full((B, H, W, cout), 7.0, dtype=torch.float16, device=dev())
+        check(lib().vipe_conv2d_nhwc_f16(ptr(x), ptr(pk.packed), ptr(pk.bias), None, ptr(y), B, H, W, cin, cin, 0, cout,
+                                         cout, 0, k, k, {"none": 0, "relu": 1, "sigmoid": 2, "tanh": 3}[act],
+                                         stream_ptr(x)), "conv")
+        ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float(), b, padding=k // 2)
+        ref = {"none": lambda t: t, "relu": torch.relu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}[act](ref)
+        err = (y.float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
+        assert err < 4e-3, (cin, cout, k, err)

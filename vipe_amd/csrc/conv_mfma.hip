@@ -1,0 +1,453 @@
+// NHWC fp16 implicit-GEMM convolution on the gfx950 matrix cores (v_mfma_f32_32x32x16_f16), fp32 accumulate,
+// with the flow-update operator's epilogues fused in (bias, per-image additive term, activation, GRU gates,
+// global-context reduction, flow / confidence heads, eta).
+//
+// This is the MI355X answer to the cuDNN autocast convolutions of UpdateModule (vipe/slam/networks/
+// droid_net.py:432-499) - the ~14 GFLOP/edge that dominate the update iteration.
+//
+// Mapping.  GEMM  D[cout, pixel] = sum_k Wp[cout, k] * X[k, pixel],  k = (tap, cin).
+//   * weights are the MFMA "A" operand (rows = cout), activations the "B" operand (cols = pixel), so a lane's
+//     accumulator registers hold 4 CONSECUTIVE output channels of one pixel -> 8-byte NHWC stores.
+//   * workgroup = 4 waves (256 lanes), tile BMC couts x BNP(=128) pixels, K step 64; both operand tiles live in
+//     LDS as [row][64 k] halves (128-byte rows) with the 16-byte chunk index XOR-swizzled by (row>>1)&7, which
+//     makes the 8-lane ds_write_b128 groups and the 16-lane ds_read_b128 groups bank-conflict free.
+//   * global -> register -> LDS staging, double buffered: the loads of K-step t+1 are issued before the MFMAs
+//     of step t and written to the other LDS buffer after them (one barrier per K-step).
+//   * activations: 8 consecutive lanes fetch the 128 contiguous bytes (64 channels) of one input pixel, so the
+//     gather of a 3x3 tap is coalesced in 128-byte segments; out-of-image taps and channels >= Cin read as 0.
+//   * the channel range may be split over two source tensors (the GRU's [r*net | inp, corr, flow] input), so
+//     the concatenations of the reference are never materialised.
+#include "common.cuh"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+enum Epi { EPI_PLAIN = 0, EPI_GLO = 1, EPI_ZR = 2, EPI_Q = 3, EPI_HEADS = 4, EPI_ETA = 5 };
+
+struct ConvArgs {
+  const half_t* x0; int x0_ctot, x0_coff;  // input channels [0, split)
+  const half_t* x1; int x1_ctot, x1_coff;  // input channels [split, Cin)
+  int split;
+  const half_t* w;      // packed [K_pad/64][Cout_pad][64]
+  const float* bias;    // [Cout_pad] (zero padded)
+  const float* extra;   // [B][extra_stride] per-image additive term or null
+  int extra_stride, extra_off;
+  half_t* y; int y_ctot, y_coff;
+  int B, H, W, Cin, Cin_pad, Cout, Cout_pad, KH, KW, nsteps;
+  int act, epi;
+  // epilogue operands
+  const half_t* net; int net_ctot, net_coff;  // hidden state [M, .] (GLO, ZR, Q)
+  const half_t* zbuf;                          // [M,128] (Q)
+  half_t* y2; int y2_ctot, y2_coff;            // second output (ZR: r*net)
+  float* fout;                                 // GLO: glo_sum [B,Cout]; HEADS: [M,4]; ETA: [M]
+};
+
+constexpr int BNP = 128;  // pixels per tile
+constexpr int BK = 64;    // k per step
+
+__device__ __forceinline__ int swz(int row, int k8) { return row * 128 + ((k8 ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case VIPE_ACT_RELU: return fmaxf(v, 0.0f);
+    case VIPE_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+    case VIPE_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+// BMC: couts per tile (128 / 64 / 32); WM x WN waves; SMALLCIN: Cin == 4 (k = tap*4 + c)
+template <int BMC, int WAVES_M, int WAVES_N, bool SMALLCIN>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+  constexpr int TM = BMC / (WAVES_M * 32);
+  constexpr int TN = BNP / (WAVES_N * 32);
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  constexpr int W_ITEMS = BMC * 8 / 256;  // 16-byte weight chunks per lane per K-step
+  constexpr int X_ITEMS = BNP * 8 / 256;  // = 4
+
+  extern __shared__ __align__(16) unsigned char lds[];
+  // [2][BMC*128] weights, then [2][BNP*128] activations
+  unsigned char* ldsW = lds;
+  unsigned char* ldsX = lds + 2 * BMC * 128;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int64_t M = (int64_t)a.B * a.H * a.W;
+  const int64_t pix0 = (int64_t)blockIdx.x * BNP;
+  const int cout0 = blockIdx.y * BMC;
+  const int HW = a.H * a.W;
+
+  // ---- per-lane load descriptors.  item i = tid + 256*j  ->  row = i / 8, chunk = i % 8
+  const int k8 = tid & 7;
+  int xe[X_ITEMS], xy[X_ITEMS], xx[X_ITEMS];
+  bool xvalid[X_ITEMS];
+#pragma unroll
+  for (int j = 0; j < X_ITEMS; ++j) {
+    const int64_t m = pix0 + (tid >> 3) + 32 * j;
+    xvalid[j] = m < M;
+    const int64_t mm = xvalid[j] ? m : 0;
+    xe[j] = (int)(mm / HW);
+    const int rem = (int)(mm % HW);
+    xy[j] = rem / a.W;
+    xx[j] = rem % a.W;
+  }
+  const int ph = a.KH / 2, pw = a.KW / 2;
+  const int csteps = a.Cin_pad / BK;  // K-steps per tap (generic mode)
+
+  half8 wreg[W_ITEMS], xreg[X_ITEMS];
+
+  auto issue_loads = [&](int s) {
+    // weights: block s of the packed tensor is [Cout_pad][64] halves; rows cout0.. are contiguous
+    const half_t* wb = a.w + ((int64_t)s * a.Cout_pad + cout0) * BK;
+#pragma unroll
+    for (int j = 0; j < W_ITEMS; ++j) {
+      const int row = (tid >> 3) + 32 * j;
+      wreg[j] = *reinterpret_cast<const half8*>(wb + row * BK + k8 * 8);
+    }
+    if constexpr (!SMALLCIN) {
+      const int tap = s / csteps, c0 = (s % csteps) * BK;
+      const int dy = tap / a.KW - ph, dx = tap % a.KW - pw;
+      const int c = c0 + k8 * 8;
+      const bool cok = c < a.Cin;
+      const bool s0 = c < a.split;
+      const half_t* src = s0 ? a.x0 : a.x1;
+      const int ctot = s0 ? a.x0_ctot : a.x1_ctot;
+      const int coff = s0 ? a.x0_coff + c : a.x1_coff + (c - a.split);
+#pragma unroll
+      for (int j = 0; j < X_ITEMS; ++j) {
+        const int yy = xy[j] + dy, xc = xx[j] + dx;
+        const bool ok = cok & xvalid[j] & (yy >= 0) & (yy < a.H) & (xc >= 0) & (xc < a.W);
+        half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ok) v = *reinterpret_cast<const half8*>(src + ((int64_t)(xe[j] * a.H + yy) * a.W + xc) * ctot + coff);
+        xreg[j] = v;
+      }
+    } else {
+      // chunk = global k-chunk index: taps 2q, 2q+1 with 4 channels each
+      const int q = s * 8 + k8;
+#pragma unroll
+      for (int j = 0; j < X_ITEMS; ++j) {
+        half4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int tap = 2 * q + h;
+          if (tap < a.KH * a.KW) {
+            const int yy = xy[j] + tap / a.KW - ph, xc = xx[j] + tap % a.KW - pw;
+            if (xvalid[j] & (yy >= 0) & (yy < a.H) & (xc >= 0) & (xc < a.W)) {
+              const half4 v = *reinterpret_cast<const half4*>(
+                  a.x0 + ((int64_t)(xe[j] * a.H + yy) * a.W + xc) * a.x0_ctot + a.x0_coff);
+              if (h == 0) lo = v; else hi = v;
+            }
+          }
+        }
+        xreg[j] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+    }
+  };
+  auto write_lds = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < W_ITEMS; ++j) {
+      const int row = (tid >> 3) + 32 * j;
+      *reinterpret_cast<half8*>(ldsW + buf * BMC * 128 + swz(row, k8)) = wreg[j];
+    }
+#pragma unroll
+    for (int j = 0; j < X_ITEMS; ++j) {
+      const int row = (tid >> 3) + 32 * j;
+      *reinterpret_cast<half8*>(ldsX + buf * BNP * 128 + swz(row, k8)) = xreg[j];
+    }
+  };
+
+  float16v acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  issue_loads(0);
+  write_lds(0);
+  __syncthreads();
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  for (int s = 0; s < a.nsteps; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < a.nsteps) issue_loads(s + 1);
+    const unsigned char* bw = ldsW + cur * BMC * 128;
+    const unsigned char* bx = ldsX + cur * BNP * 128;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      half8 wf[TM], xf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        wf[i] = *reinterpret_cast<const half8*>(bw + swz((wm * TM + i) * 32 + lrow, kk * 2 + lhalf));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        xf[j] = *reinterpret_cast<const half8*>(bx + swz((wn * TN + j) * 32 + lrow, kk * 2 + lhalf));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    if (s + 1 < a.nsteps) write_lds(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  lane: pixel = col, regs r -> cout row (r&3) + 8(r>>2) + 4*lhalf
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int64_t m = pix0 + (wn * TN + j) * 32 + lrow;
+    const bool mok = m < M;
+    const int e = mok ? (int)(m / HW) : 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = cout0 + (wm * TM + i) * 32 + 8 * g + 4 * lhalf;  // 4 consecutive couts
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[q] = acc[i][j][4 * g + q];
+          if (co + q < a.Cout) {
+            v[q] += a.bias[co + q];
+            if (a.extra) v[q] += a.extra[(int64_t)e * a.extra_stride + a.extra_off + co + q];
+          }
+        }
+        if (a.epi == EPI_PLAIN) {
+          if (mok && co < a.Cout) {
+            half4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = (half_t)act_apply(v[q], a.act);
+            if (co + 3 < a.Cout) {
+              *reinterpret_cast<half4*>(a.y + m * a.y_ctot + a.y_coff + co) = o;
+            } else {
+              for (int q = 0; q < 4 && co + q < a.Cout; ++q) a.y[m * a.y_ctot + a.y_coff + co + q] = o[q];
+            }
+          }
+        } else if (a.epi == EPI_GLO) {
+          // sigmoid(w(net)) * net, summed over the tile's pixels (droid_net.py:392-393)
+          float s4[4] = {0, 0, 0, 0};
+          if (mok) {
+            const half4 nv = *reinterpret_cast<const half4*>(a.net + m * a.net_ctot + a.net_coff + co);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s4[q] = (float)(half_t)act_apply(v[q], VIPE_ACT_SIGMOID) * (float)nv[q];
+          }
+          const int e_first = (int)(pix0 / HW);
+          const int64_t last = (pix0 + BNP - 1 < M ? pix0 + BNP - 1 : M - 1);
+          const bool one_image = (int)(last / HW) == e_first;  // block-uniform
+          if (one_image) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float t = s4[q];
+#pragma unroll
+              for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, WAVE);  // over the 32 pixels of this half
+              if (lrow == 0) atomicAdd(a.fout + (int64_t)e_first * a.Cout + co + q, t);
+            }
+          } else if (mok) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) atomicAdd(a.fout + (int64_t)e * a.Cout + co + q, s4[q]);
+          }
+        } else if (a.epi == EPI_ZR) {
+          if (mok) {
+            half4 o;
+            if (co < 128) {  // z
+#pragma unroll
+              for (int q = 0; q < 4; ++q) o[q] = (half_t)act_apply(v[q], VIPE_ACT_SIGMOID);
+              *reinterpret_cast<half4*>(a.y + m * a.y_ctot + a.y_coff + co) = o;
+            } else {  // r * net
+              const half4 nv = *reinterpret_cast<const half4*>(a.net + m * a.net_ctot + a.net_coff + co - 128);
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                o[q] = (half_t)((float)(half_t)act_apply(v[q], VIPE_ACT_SIGMOID) * (float)nv[q]);
+              *reinterpret_cast<half4*>(a.y2 + m * a.y2_ctot + a.y2_coff + co - 128) = o;
+            }
+          }
+        } else if (a.epi == EPI_Q) {
+          if (mok) {
+            const half4 nv = *reinterpret_cast<const half4*>(a.net + m * a.net_ctot + a.net_coff + co);
+            const half4 zv = *reinterpret_cast<const half4*>(a.zbuf + m * 128 + co);
+            half4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float qq = (float)(half_t)tanhf(v[q]);
+              const float z = (float)zv[q];
+              o[q] = (half_t)((1.0f - z) * (float)nv[q] + z * qq);  // droid_net.py:399
+            }
+            *reinterpret_cast<half4*>(a.y + m * a.y_ctot + a.y_coff + co) = o;
+          }
+        } else if (a.epi == EPI_HEADS) {
+          // cout 0,1: delta; cout 2,3: sigmoid -> weight (droid_net.py:486-490); written as float [M,4]
+          if (mok && co == 0) {
+            float4 o = make_float4((float)(half_t)v[0], (float)(half_t)v[1],
+                                   (float)(half_t)act_apply(v[2], VIPE_ACT_SIGMOID),
+                                   (float)(half_t)act_apply(v[3], VIPE_ACT_SIGMOID));
+            *reinterpret_cast<float4*>(a.fout + m * 4) = o;
+          }
+        } else if (a.epi == EPI_ETA) {
+          // 0.01 * softplus (droid_net.py:410,429)
+          if (mok && co == 0) {
+            const float x = v[0];
+            const float sp = x > 20.0f ? x : log1pf(__expf(x));
+            a.fout[m] = 0.01f * (float)(half_t)sp;
+          }
+        }
+      }
+    }
+  }
+}
+
+// OIHW (fp16 or fp32) -> packed [K_pad/64][Cout_pad][64] fp16, k = tap*Cin_pad + c (generic) or tap*4 + c (Cin == 4)
+__global__ void pack_weights_kernel(const void* __restrict__ src, half_t* __restrict__ dst, int Cout, int Cin, int KH,
+                                    int KW, int Cout_pad, int Cin_pad, int K_pad, int src_f32, int smallcin) {
+  const int64_t total = (int64_t)K_pad * Cout_pad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int kin = (int)(i % 64);
+    const int co = (int)((i / 64) % Cout_pad);
+    const int s = (int)(i / (64 * (int64_t)Cout_pad));
+    const int k = s * 64 + kin;
+    int tap, c;
+    if (smallcin) { tap = k / 4; c = k % 4; }
+    else { tap = k / Cin_pad; c = k % Cin_pad; }
+    float v = 0.0f;
+    if (co < Cout && c < Cin && tap < KH * KW) {
+      const int64_t o = (((int64_t)co * Cin + c) * KH + tap / KW) * KW + tap % KW;
+      v = src_f32 ? reinterpret_cast<const float*>(src)[o] : (float)reinterpret_cast<const half_t*>(src)[o];
+    }
+    dst[i] = (half_t)v;
+  }
+}
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+}  // namespace
+
+// ---- C ABI ------------------------------------------------------------------------------------------------
+
+extern "C" {
+
+// Geometry helpers shared with the Python side: padded sizes of the packed weight tensor.
+VIPE_EXPORT int vipe_conv_packed_dims(int Cout, int Cin, int KH, int KW, int* cout_pad, int* cin_pad, int* k_pad) {
+  if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return VIPE_EINVAL;
+  const int cp = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : round_up(Cout, 128));
+  int cinp, kp;
+  if (Cin == 4) { cinp = 4; kp = round_up(KH * KW * 4, 64); }
+  else { cinp = round_up(Cin, 64); kp = KH * KW * cinp; }
+  if (cout_pad) *cout_pad = cp;
+  if (cin_pad) *cin_pad = cinp;
+  if (k_pad) *k_pad = kp;
+  return VIPE_OK;
+}
+
+VIPE_EXPORT int vipe_conv_pack_weights(const void* d_w_oihw, void* d_w_packed, int Cout, int Cin, int KH, int KW,
+                                       int src_dtype, void* stream) {
+  VIPE_CHECK_ARG(d_w_oihw && d_w_packed);
+  VIPE_CHECK_ARG(src_dtype == VIPE_F16 || src_dtype == VIPE_F32);
+  int cp, cinp, kp;
+  if (vipe_conv_packed_dims(Cout, Cin, KH, KW, &cp, &cinp, &kp) != VIPE_OK) return VIPE_EINVAL;
+  VIPE_CHECK_ARG(Cin == 4 || Cin % 8 == 0);
+  const int64_t total = (int64_t)kp * cp;
+  pack_weights_kernel<<<(int)std::min<int64_t>((total + 255) / 256, 4096), 256, 0, as_stream(stream)>>>(
+      d_w_oihw, (half_t*)d_w_packed, Cout, Cin, KH, KW, cp, cinp, kp, src_dtype == VIPE_F32, Cin == 4);
+  return vipe_launch_status();
+}
+
+}  // extern "C"
+
+namespace {
+
+int launch_conv(ConvArgs& a, hipStream_t s) {
+  int cp, cinp, kp;
+  if (vipe_conv_packed_dims(a.Cout, a.Cin, a.KH, a.KW, &cp, &cinp, &kp) != VIPE_OK) return VIPE_EINVAL;
+  a.Cout_pad = cp;
+  a.Cin_pad = cinp;
+  a.nsteps = kp / 64;
+  const int64_t M = (int64_t)a.B * a.H * a.W;
+  if (M == 0) return VIPE_OK;
+  const bool small = a.Cin == 4;
+  const int gx = (int)((M + BNP - 1) / BNP);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<128, 2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<128, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    attr = true;
+  }
+  if (cp >= 128) {
+    const size_t lds = 2 * (128 + BNP) * 128;
+    dim3 grid(gx, cp / 128);
+    if (small) conv_mfma_kernel<128, 2, 2, true><<<grid, 256, lds, s>>>(a);
+    else conv_mfma_kernel<128, 2, 2, false><<<grid, 256, lds, s>>>(a);
+  } else if (cp == 64) {
+    const size_t lds = 2 * (64 + BNP) * 128;
+    if (small) return VIPE_EUNSUPPORTED;
+    conv_mfma_kernel<64, 1, 4, false><<<dim3(gx, 1), 256, lds, s>>>(a);
+  } else {
+    const size_t lds = 2 * (32 + BNP) * 128;
+    if (small) return VIPE_EUNSUPPORTED;
+    conv_mfma_kernel<32, 1, 4, false><<<dim3(gx, 1), 256, lds, s>>>(a);
+  }
+  return vipe_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+VIPE_EXPORT int vipe_conv2d_nhwc_f16(const void* d_x, const void* d_w_packed, const float* d_bias,
+                                     const float* d_extra, void* d_y, int B, int H, int W, int Cin, int cin_total,
+                                     int cin_off, int Cout, int cout_total, int cout_off, int KH, int KW, int act,
+                                     void* stream) {
+  VIPE_CHECK_ARG(d_x && d_w_packed && d_bias && d_y);
+  VIPE_CHECK_ARG(B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (KH & 1) && (KW & 1));
+  VIPE_CHECK_ARG((Cin == 4 || Cin % 8 == 0) && cin_total % 4 == 0 && cin_off % 4 == 0 && cout_total % 4 == 0 &&
+                 cout_off % 4 == 0);
+  VIPE_CHECK_ARG(Cin == 4 || (cin_total % 8 == 0 && cin_off % 8 == 0));
+  VIPE_CHECK_ARG(act >= 0 && act <= 3);
+  ConvArgs a = {};
+  a.x0 = (const half_t*)d_x; a.x0_ctot = cin_total; a.x0_coff = cin_off;
+  a.x1 = a.x0; a.x1_ctot = cin_total; a.x1_coff = cin_off; a.split = Cin;
+  a.w = (const half_t*)d_w_packed; a.bias = d_bias; a.extra = d_extra; a.extra_stride = Cout; a.extra_off = 0;
+  a.y = (half_t*)d_y; a.y_ctot = cout_total; a.y_coff = cout_off;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW;
+  a.act = act; a.epi = EPI_PLAIN;
+  return launch_conv(a, as_stream(stream));
+}
+
+// [fused] GRU / head epilogues.  `mode`: 1 GLO, 2 ZR, 3 Q, 4 HEADS, 5 ETA (see conv_mfma.hip); two-source input.
+VIPE_EXPORT int vipe_conv2d_fused(const void* d_x0, int x0_ctot, int x0_coff, const void* d_x1, int x1_ctot,
+                                  int x1_coff, int split, const void* d_w_packed, const float* d_bias,
+                                  const float* d_extra, int extra_stride, int extra_off, void* d_y, int y_ctot,
+                                  int y_coff, void* d_y2, int y2_ctot, int y2_coff, const void* d_net, int net_ctot,
+                                  int net_coff, const void* d_z, float* d_fout, int B, int H, int W, int Cin,
+                                  int Cout, int KH, int KW, int act, int mode, void* stream) {
+  VIPE_CHECK_ARG(d_x0 && d_w_packed && d_bias);
+  VIPE_CHECK_ARG(B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (KH & 1) && (KW & 1));
+  if (Cin == 4) {
+    VIPE_CHECK_ARG(split >= Cin && x0_ctot % 4 == 0 && x0_coff % 4 == 0);
+  } else {
+    VIPE_CHECK_ARG(Cin % 8 == 0 && x0_ctot % 8 == 0 && x0_coff % 8 == 0);
+    VIPE_CHECK_ARG(split >= Cin || (split % 64 == 0 && d_x1 && x1_ctot % 8 == 0 && x1_coff % 8 == 0));
+  }
+  VIPE_CHECK_ARG(mode >= EPI_PLAIN && mode <= EPI_ETA);
+  if (mode == EPI_PLAIN) VIPE_CHECK_ARG(d_y && y_ctot % 4 == 0 && y_coff % 4 == 0);
+  if (mode == EPI_GLO) VIPE_CHECK_ARG(d_net && d_fout);
+  if (mode == EPI_ZR) VIPE_CHECK_ARG(d_y && d_y2 && d_net && Cout == 256);
+  if (mode == EPI_Q) VIPE_CHECK_ARG(d_y && d_net && d_z && Cout == 128);
+  if (mode == EPI_HEADS) VIPE_CHECK_ARG(d_fout && Cout == 4);
+  if (mode == EPI_ETA) VIPE_CHECK_ARG(d_fout && Cout == 1);
+  ConvArgs a = {};
+  a.x0 = (const half_t*)d_x0; a.x0_ctot = x0_ctot; a.x0_coff = x0_coff;
+  a.x1 = (const half_t*)(d_x1 ? d_x1 : d_x0); a.x1_ctot = d_x1 ? x1_ctot : x0_ctot; a.x1_coff = d_x1 ? x1_coff : x0_coff;
+  a.split = split > Cin ? Cin : split;
+  a.w = (const half_t*)d_w_packed; a.bias = d_bias; a.extra = d_extra; a.extra_stride = extra_stride; a.extra_off = extra_off;
+  a.y = (half_t*)d_y; a.y_ctot = y_ctot; a.y_coff = y_coff;
+  a.y2 = (half_t*)d_y2; a.y2_ctot = y2_ctot; a.y2_coff = y2_coff;
+  a.net = (const half_t*)d_net; a.net_ctot = net_ctot; a.net_coff = net_coff;
+  a.zbuf = (const half_t*)d_z; a.fout = d_fout;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW;
+  a.act = act; a.epi = mode;
+  return launch_conv(a, as_stream(stream));
+}
+
+}  // extern "C"

@@ -116,11 +116,12 @@ struct LevelPtrs {
   const void* p[8];
 };
 
-// grid: (ceil(P/256), B, levels); coords [B,h1,w1,2]; out [B, L*RD*RD, h1, w1]
+// grid: (ceil(P/256), B, levels); coords [B,h1,w1,2]; out [B, L*RD*RD, h1, w1], or with nhwc_stride > 0
+// out [B,h1,w1,nhwc_stride] (channel = level*RD*RD + a*RD + b; channels >= L*RD*RD are zero filled)
 template <typename T, int R>
 __global__ __launch_bounds__(256) void corr_pyramid_lookup_kernel(LevelPtrs lv, const float* __restrict__ coords,
                                                                    T* __restrict__ out, int h1, int w1, int h2,
-                                                                   int w2, int L) {
+                                                                   int w2, int L, int nhwc_stride) {
   const int P = h1 * w1;
   const int p = blockIdx.x * 256 + threadIdx.x;
   const int n = blockIdx.y;
@@ -131,8 +132,15 @@ __global__ __launch_bounds__(256) void corr_pyramid_lookup_kernel(LevelPtrs lv, 
   const int h2l = h2 >> l, w2l = w2 >> l;
   constexpr int RD = 2 * R + 1;
   const T* slab = reinterpret_cast<const T*>(lv.p[l]) + ((int64_t)n * P + p) * ((int64_t)h2l * w2l);
-  T* o = out + ((int64_t)n * L + l) * (RD * RD) * P + p;
-  lookup_pixel<T, R>(slab, h2l, w2l, c.x * sc, c.y * sc, o, P);
+  if (nhwc_stride > 0) {
+    T* o = out + ((int64_t)n * P + p) * nhwc_stride + l * (RD * RD);
+    lookup_pixel<T, R>(slab, h2l, w2l, c.x * sc, c.y * sc, o, 1);
+    if (l == L - 1)
+      for (int q = L * RD * RD; q < nhwc_stride; ++q) out[((int64_t)n * P + p) * nhwc_stride + q] = (T)0;
+  } else {
+    T* o = out + ((int64_t)n * L + l) * (RD * RD) * P + p;
+    lookup_pixel<T, R>(slab, h2l, w2l, c.x * sc, c.y * sc, o, P);
+  }
 }
 
 // adjoint: each lane owns its pixel's slab, so plain stores into a zero-filled gradient are race free.
@@ -211,11 +219,11 @@ int launch_bwd(const float* coords, const void* cg, void* vg, int B, int h1, int
 
 template <typename T>
 int launch_pyr(const LevelPtrs& lv, const float* coords, void* out, int B, int h1, int w1, int h2, int w2, int L,
-               int r, hipStream_t s) {
+               int r, int nhwc_stride, hipStream_t s) {
   dim3 grid((h1 * w1 + 255) / 256, B, L), block(256);
   switch (r) {
-    case 3: corr_pyramid_lookup_kernel<T, 3><<<grid, block, 0, s>>>(lv, coords, (T*)out, h1, w1, h2, w2, L); break;
-    case 4: corr_pyramid_lookup_kernel<T, 4><<<grid, block, 0, s>>>(lv, coords, (T*)out, h1, w1, h2, w2, L); break;
+    case 3: corr_pyramid_lookup_kernel<T, 3><<<grid, block, 0, s>>>(lv, coords, (T*)out, h1, w1, h2, w2, L, nhwc_stride); break;
+    case 4: corr_pyramid_lookup_kernel<T, 4><<<grid, block, 0, s>>>(lv, coords, (T*)out, h1, w1, h2, w2, L, nhwc_stride); break;
     default: return VIPE_EUNSUPPORTED;
   }
   return vipe_launch_status();
@@ -251,9 +259,8 @@ VIPE_EXPORT int vipe_corr_index_backward(const float* d_coords, const void* d_co
   return VIPE_EINVAL;
 }
 
-VIPE_EXPORT int vipe_corr_pyramid_lookup(const void* const* h_levels, const float* d_coords, void* d_out, int B,
-                                         int h1, int w1, int h2, int w2, int num_levels, int radius, int dtype,
-                                         void* stream) {
+static int pyramid_lookup_impl(const void* const* h_levels, const float* d_coords, void* d_out, int B, int h1, int w1,
+                               int h2, int w2, int num_levels, int radius, int dtype, int nhwc_stride, void* stream) {
   VIPE_CHECK_ARG(num_levels >= 1 && num_levels <= 8 && B >= 0 && B <= 65535);
   VIPE_CHECK_ARG((h2 >> (num_levels - 1)) >= 1 && (w2 >> (num_levels - 1)) >= 1);
   if (B == 0) return VIPE_OK;
@@ -265,8 +272,23 @@ VIPE_EXPORT int vipe_corr_pyramid_lookup(const void* const* h_levels, const floa
   }
   hipStream_t s = as_stream(stream);
   switch (dtype) {
-    case VIPE_F16: return launch_pyr<half_t>(lv, d_coords, d_out, B, h1, w1, h2, w2, num_levels, radius, s);
-    case VIPE_F32: return launch_pyr<float>(lv, d_coords, d_out, B, h1, w1, h2, w2, num_levels, radius, s);
+    case VIPE_F16: return launch_pyr<half_t>(lv, d_coords, d_out, B, h1, w1, h2, w2, num_levels, radius, nhwc_stride, s);
+    case VIPE_F32: return launch_pyr<float>(lv, d_coords, d_out, B, h1, w1, h2, w2, num_levels, radius, nhwc_stride, s);
   }
   return VIPE_EINVAL;
+}
+
+VIPE_EXPORT int vipe_corr_pyramid_lookup(const void* const* h_levels, const float* d_coords, void* d_out, int B,
+                                         int h1, int w1, int h2, int w2, int num_levels, int radius, int dtype,
+                                         void* stream) {
+  return pyramid_lookup_impl(h_levels, d_coords, d_out, B, h1, w1, h2, w2, num_levels, radius, dtype, 0, stream);
+}
+
+VIPE_EXPORT int vipe_corr_pyramid_lookup_nhwc(const void* const* h_levels, const float* d_coords, void* d_out, int B,
+                                              int h1, int w1, int h2, int w2, int num_levels, int radius, int dtype,
+                                              int channel_stride, void* stream) {
+  const int rd = 2 * radius + 1;
+  VIPE_CHECK_ARG(channel_stride >= num_levels * rd * rd);
+  return pyramid_lookup_impl(h_levels, d_coords, d_out, B, h1, w1, h2, w2, num_levels, radius, dtype, channel_stride,
+                             stream);
 }

@@ -18,5 +18,3 @@ VIPE_EXPORT int vipe_scatter(const void*, const int64_t*, void*, int64_t*, int64
 VIPE_EXPORT int vipe_scatter_mean_rows_f16(const void*, const int64_t*, void*, int, int, int64_t, void*) { return VIPE_EUNSUPPORTED; }
 VIPE_EXPORT int vipe_corr_sampler_forward(const void*, const void*, void*, int, int, int, int, int, int, int, int, int, int, int, int, int, int, int, int, int, void*) { return VIPE_EUNSUPPORTED; }
 VIPE_EXPORT int vipe_corr_sampler_backward(const void*, const void*, const void*, void*, void*, int, int, int, int, int, int, int, int, int, int, int, int, int, int, int, int, int, void*) { return VIPE_EUNSUPPORTED; }
-VIPE_EXPORT int vipe_conv_pack_weights(const void*, void*, int, int, int, int, int, void*) { return VIPE_EUNSUPPORTED; }
-VIPE_EXPORT int vipe_conv2d_nhwc_f16(const void*, const void*, const float*, const float*, void*, int, int, int, int, int, int, int, int, int, int, int, int, void*) { return VIPE_EUNSUPPORTED; }

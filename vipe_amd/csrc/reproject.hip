@@ -18,7 +18,7 @@ struct ReprojArgs {
   float inv_factor;
 };
 
-template <int CAM, int MOTN /*0 none, 1 f16, 2 f32*/>
+template <int CAM, int MOTN /*0 none, 1 f16 [M,4,P], 2 f32 [M,4,P], 3 f16 channels-last [M,P,4]*/>
 __global__ __launch_bounds__(256) void reproject_kernel(ReprojArgs a) {
   const int e = blockIdx.y;
   const int P = a.ht * a.wd;
@@ -51,6 +51,14 @@ __global__ __launch_bounds__(256) void reproject_kernel(ReprojArgs a) {
   if constexpr (MOTN != 0) {
     const float2 tg = reinterpret_cast<const float2*>(a.target)[o];
     float m[4] = {x - u, y - v, tg.x - x, tg.y - y};  // factor_graph.py:259
+    if constexpr (MOTN == 3) {
+      typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+      half4v hv;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) hv[c] = (half_t)fminf(fmaxf(m[c], -64.0f), 64.0f);
+      reinterpret_cast<half4v*>(a.motn)[o] = hv;
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float mc = fminf(fmaxf(m[c], -64.0f), 64.0f);
@@ -98,4 +106,18 @@ VIPE_EXPORT int vipe_reproject_motion(const float* d_poses, const float* d_disps
   if (motn_dtype == VIPE_F16) return launch<1>(a, camera, as_stream(stream));
   if (motn_dtype == VIPE_F32) return launch<2>(a, camera, as_stream(stream));
   return VIPE_EINVAL;
+}
+
+VIPE_EXPORT int vipe_reproject_motion_nhwc(const float* d_poses, const float* d_disps, const float* d_intrinsics,
+                                           const float* d_rig, const int64_t* d_pi, const int64_t* d_qi,
+                                           const int64_t* d_pj, const int64_t* d_qj, const int64_t* d_di,
+                                           const float* d_target, float* d_coords, void* d_motn, int M, int ht,
+                                           int wd, int n_views, int camera, float intr_factor, void* stream) {
+  VIPE_CHECK_ARG(d_poses && d_disps && d_intrinsics && d_rig && d_pi && d_qi && d_pj && d_qj && d_di && d_coords);
+  VIPE_CHECK_ARG(d_target && d_motn);
+  VIPE_CHECK_ARG(M >= 0 && M <= 65535 && ht > 0 && wd > 0 && n_views >= 1 && intr_factor > 0);
+  if (M == 0) return VIPE_OK;
+  ReprojArgs a{d_poses, d_disps, d_intrinsics, d_rig, d_pi, d_qi, d_pj, d_qj, d_di, d_target, d_coords, nullptr,
+               d_motn, M, ht, wd, n_views, camera == VIPE_CAM_MEI ? 1 : 0, 1.0f / intr_factor};
+  return launch<3>(a, camera, as_stream(stream));
 }

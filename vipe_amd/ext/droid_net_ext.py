@@ -103,3 +103,18 @@ def corr_pyramid_lookup(levels, coords, radius=3):
                                          L, radius, DTYPE_CODE[levels[0].dtype], stream_ptr(coords)),
           "corr_pyramid_lookup")
     return out
+
+
+def corr_pyramid_lookup_nhwc(levels, coords, radius=3, channel_stride=200):
+    """Same lookup, written channels-last [E,h1,w1,channel_stride] (zero padded) for the MFMA convolutions."""
+    check_gpu_contig(coords, *levels)
+    require(coords.dtype == torch.float32, "coords must be float32")
+    E, h1, w1, h2, w2 = levels[0].shape
+    L = len(levels)
+    require(tuple(coords.shape) == (E, h1, w1, 2), "coords must be [E,h1,w1,2]")
+    out = torch.empty((E, h1, w1, channel_stride), dtype=levels[0].dtype, device=coords.device)
+    arr = (ctypes.c_void_p * L)(*[lv.data_ptr() for lv in levels])
+    check(lib().vipe_corr_pyramid_lookup_nhwc(ctypes.cast(arr, ctypes.c_void_p), ptr(coords), ptr(out), E, h1, w1, h2,
+                                              w2, L, radius, DTYPE_CODE[levels[0].dtype], channel_stride,
+                                              stream_ptr(coords)), "corr_pyramid_lookup_nhwc")
+    return out

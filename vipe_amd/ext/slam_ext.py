@@ -54,6 +54,21 @@ def reproject_motion(poses, disps, intrinsics, rig, pi, qi, pj, qj, di, target, 
     return coords, motn
 
 
+def reproject_motion_nhwc(poses, disps, intrinsics, rig, pi, qi, pj, qj, di, target, camera="pinhole", intr_factor=8.0):
+    """coords1 + clamped motion features channels-last [M,ht,wd,4] fp16 in one launch."""
+    check_gpu_contig(poses, disps, intrinsics, rig, pi, qi, pj, qj, di, target)
+    M = pi.shape[0]
+    _, ht, wd = disps.shape
+    require(target.numel() == M * ht * wd * 2 and target.dtype == torch.float32, "target must be [M,ht,wd,2] float32")
+    coords = torch.empty((M, ht, wd, 2), dtype=torch.float32, device=poses.device)
+    motn = torch.empty((M, ht, wd, 4), dtype=torch.float16, device=poses.device)
+    check(lib().vipe_reproject_motion_nhwc(ptr(poses), ptr(disps), ptr(intrinsics), ptr(rig), ptr(_i64(pi)),
+                                           ptr(_i64(qi)), ptr(_i64(pj)), ptr(_i64(qj)), ptr(_i64(di)), ptr(target),
+                                           ptr(coords), ptr(motn), M, ht, wd, rig.shape[0], CAMERA_CODE[camera],
+                                           float(intr_factor), stream_ptr(poses)), "reproject_motion_nhwc")
+    return coords, motn
+
+
 def dense_ba(poses, disps, disps_sens, intrinsics, rig, target, weight, disp_damping, pi, qi, pj, qj, di, t0, t1,
              n_iters, pose_damping, pose_ep, motion_only=False, limited_disp=False, optimize_intrinsics=False,
              optimize_rig_rotation=False, camera="pinhole", alpha=0.001, n_poses=None, want_info=False):

@@ -27,7 +27,8 @@ class FactorGraph:
         self.damping = 1e-6 * torch.ones_like(buffer.flattened_disps)  # factor_graph.py:76
         self.target = torch.zeros([1, 0, ht, wd, 2], device=device, dtype=torch.float)
         self.weight = torch.zeros([1, 0, ht, wd, 2], device=device, dtype=torch.float)
-        self.corr, self.f_net, self.inp = None, None, None
+        # channels-last state of the flow-update operator: hidden state [E,h,w,128] and [inp | corr | flow] features
+        self.corr, self.net_n, self.xbuf = None, None, None
         self.ii_inac = torch.as_tensor([], dtype=torch.long, device=device)
         self.jj_inac = torch.as_tensor([], dtype=torch.long, device=device)
         self.target_inac = torch.zeros([1, 0, ht, wd, 2], device=device, dtype=torch.float)
@@ -57,15 +58,17 @@ class FactorGraph:
         if self.incremental:
             corr = CorrBlock(self.buffer.fmaps[pi, qi][None], self.buffer.fmaps[pj, qj][None])
             self.corr = corr if self.corr is None else self.corr.cat(corr)
-            inp = self.buffer.inps[pi, qi][None]
-            self.inp = inp if self.inp is None else torch.cat([self.inp, inp], 1)
+            xb = torch.zeros((ii.shape[0] * self.buffer.n_views, self.ht, self.wd, 320), dtype=torch.half,
+                             device=self.device)
+            xb[..., 0:128] = self.buffer.inps[pi, qi].permute(0, 2, 3, 1)
+            self.xbuf = xb if self.xbuf is None else torch.cat([self.xbuf, xb], 0)
         target, _ = self.buffer.reproject_dense_disp(ii, jj)
         target = target[None]
         self.ii = torch.cat([self.ii, ii], 0)
         self.jj = torch.cat([self.jj, jj], 0)
         self.age = torch.cat([self.age, torch.zeros_like(ii)], 0)
-        net = self.buffer.nets[pi, qi][None]
-        self.f_net = net if self.f_net is None else torch.cat([self.f_net, net], 1)
+        net = self.buffer.nets[pi, qi].permute(0, 2, 3, 1).contiguous()
+        self.net_n = net if self.net_n is None else torch.cat([self.net_n, net], 0)
         self.target = torch.cat([self.target, target], 1)
         self.weight = torch.cat([self.weight, torch.zeros_like(target)], 1)
         self._plan = None
@@ -83,10 +86,10 @@ class FactorGraph:
         self.ii, self.jj, self.age = self.ii[~mask], self.jj[~mask], self.age[~mask]
         if self.corr is not None:
             self.corr = self.corr[~exp_mask]
-        if self.f_net is not None:
-            self.f_net = self.f_net[:, ~exp_mask]
-        if self.inp is not None:
-            self.inp = self.inp[:, ~exp_mask]
+        if self.net_n is not None:
+            self.net_n = self.net_n[~exp_mask]
+        if self.xbuf is not None:
+            self.xbuf = self.xbuf[~exp_mask]
         self.target = self.target[:, ~exp_mask]
         self.weight = self.weight[:, ~exp_mask]
         self._plan = None
@@ -97,6 +100,23 @@ class FactorGraph:
         ii, jj = ii.reshape(-1), jj.reshape(-1)
         keep = ((ii - jj).abs() > 0) & ((ii - jj).abs() <= r)
         self.add_factors(ii[keep], jj[keep])
+
+    @property
+    def f_net(self):
+        """GRU hidden state in the reference's layout [1,E,128,h,w] (factor_graph.py:84-86)."""
+        return None if self.net_n is None else self.net_n.permute(0, 3, 1, 2)[None]
+
+    @property
+    def inp(self):
+        return None if self.xbuf is None else self.xbuf[..., 0:128].permute(0, 3, 1, 2)[None]
+
+    def _net_spare(self):
+        """Ping-pong buffer for the new hidden state (the Q epilogue cannot write in place: 3x3 halo)."""
+        sp = getattr(self, "_spare", None)
+        if sp is None or sp.shape != self.net_n.shape or sp.data_ptr() == self.net_n.data_ptr():
+            sp = torch.empty_like(self.net_n)
+        self._spare = self.net_n  # the current state becomes next iteration's spare
+        return sp
 
     def _edge_plan(self):
         """Index tensors that only change when the edge set changes (the reference recomputes them, with a
@@ -113,24 +133,33 @@ class FactorGraph:
     def update(self, t0=None, t1=None, itrs=3, use_inactive=False, motion_only=False, fixed_motion=False,
                limited_disp=False):
         """run update operator on factor graph (factor_graph.py:230-314)."""
-        assert self.incremental and self.corr is not None and self.inp is not None and self.f_net is not None
+        assert self.incremental and self.corr is not None and self.xbuf is not None and self.net_n is not None
         assert not (motion_only and fixed_motion)
         P = self._edge_plan()
         t0 = P["t0"] if t0 is None else t0
         t1 = P["t1"] if t1 is None else t1
         buf = self.buffer
         # motion features + coords1 in one launch (factor_graph.py:253-261)
-        coords1, motn = slam_ext.reproject_motion(buf.poses, buf.flattened_disps, buf.intrinsics, buf.rig, P["pi"],
-                                                  P["qi"], P["pj"], P["qj"], P["di"], self.target[0].contiguous(),
-                                                  camera=buf.camera_type)
-        corr = self.corr(coords1[None])  # [1,E,196,h,w], one launch for the 4 levels
-        self.f_net, delta, weight, damping, _ = self.update_op(self.f_net, self.inp, corr, motn[None], ix=P["dix"],
-                                                                skip_upmask=True, n_src=P["n_src"])
-        weight = weight.float()
+        coords1, motn = slam_ext.reproject_motion_nhwc(buf.poses, buf.flattened_disps, buf.intrinsics, buf.rig,
+                                                       P["pi"], P["qi"], P["pj"], P["qj"], P["di"],
+                                                       self.target[0].contiguous(), camera=buf.camera_type)
+        corr = self.corr.lookup_nhwc(coords1)  # [E,h,w,200] channels-last, one launch for the 4 levels
+        eng = self.update_op.engine(self.device)
+        if eng.backend == "hip":
+            self.net_n, dw, eta, _ = eng.forward_nhwc(self.net_n, self.xbuf, corr, motn, ix=P["dix"], n_src=P["n_src"],
+                                                      net_out=self._net_spare())
+            delta, weight = dw[None, ..., 0:2], dw[None, ..., 2:4].clone()
+        else:  # A/B baseline: reference-shaped NCHW call
+            f_net, delta, weight, eta, _ = eng.forward(
+                self.net_n.permute(0, 3, 1, 2)[None], self.xbuf[..., 0:128].permute(0, 3, 1, 2)[None],
+                corr[..., :196].permute(0, 3, 1, 2)[None], motn.permute(0, 3, 1, 2)[None], ix=P["dix"],
+                skip_upmask=True, n_src=P["n_src"])
+            self.net_n = f_net[0].permute(0, 2, 3, 1).contiguous()
+            delta, weight, eta = delta.float(), weight.float(), eta[0]
         weight[:, buf.masks[P["pi"], P["qi"]]] = 0.0  # factor_graph.py:272
-        self.target = coords1[None] + delta.float()
+        self.target = coords1[None] + delta
         self.weight = weight
-        self.damping[P["du"]] = damping[0]
+        self.damping[P["du"]] = eta
         if use_inactive:
             m = (self.ii_inac >= t0 - 3) & (self.jj_inac >= t0 - 3)
             ii = torch.cat([self.ii_inac[m], self.ii], 0)

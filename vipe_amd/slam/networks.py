@@ -34,6 +34,10 @@ class CorrBlock:
         out = droid_net_ext.corr_pyramid_lookup(self.corr_pyramid, coords.reshape(batch * num, ht, wd, 2), self.radius)
         return out.view(batch, num, -1, ht, wd)
 
+    def lookup_nhwc(self, coords, channel_stride=200):
+        """coords [E,h,w,2] -> [E,h,w,channel_stride] fp16 channels-last (the GRU's input layout)."""
+        return droid_net_ext.corr_pyramid_lookup_nhwc(self.corr_pyramid, coords, self.radius, channel_stride)
+
     def cat(self, other):
         for i in range(self.num_levels):
             self.corr_pyramid[i] = torch.cat([self.corr_pyramid[i], other.corr_pyramid[i]], 0)
@@ -138,14 +142,17 @@ class UpdateModule(nn.Module):
         self.agg = GraphAgg()
         self._engine = None
 
+    def engine(self, device):
+        from .update_engine import UpdateEngine
+
+        if self._engine is None or self._engine.device != device:
+            self._engine = UpdateEngine(self, device)
+        return self._engine
+
     def forward(self, net, inp, corr, flow=None, ix=None, skip_upmask=False, n_src=None):
         """net, inp [1,E,128,h,w]; corr [1,E,196,h,w]; flow [1,E,4,h,w]; ix [E] -> source-node slot.
 
         Returns (net, delta[1,E,h,w,2], weight[1,E,h,w,2], eta[1,Nsrc,h,w], upmask) like the reference;
         `skip_upmask=True` returns None for upmask (the SLAM host code discards it, factor_graph.py:269).
         """
-        from .update_engine import UpdateEngine
-
-        if self._engine is None or self._engine.device != net.device:
-            self._engine = UpdateEngine(self, net.device)
-        return self._engine.forward(net, inp, corr, flow, ix, skip_upmask, n_src)
+        return self.engine(net.device).forward(net, inp, corr, flow, ix, skip_upmask, n_src)

@@ -1,18 +1,26 @@
 """Execution engine of the flow-update operator (UpdateModule.forward, droid_net.py:467-499) on MI355X.
 
 Data layout: every activation is NHWC fp16 ([E, h, w, C], channels innermost) so that a 3x3 tap reads
-C contiguous halves (256 B at C=128) and the implicit-GEMM K dimension is contiguous for MFMA fragments.
-Concatenations of the reference (`cat[net, inp, corr_feat, flow_feat]`, droid_net.py:388-389) are never
-materialised separately: producers write straight into channel slices of one [E,h,w,448] buffer.
+C contiguous halves and the implicit-GEMM K dimension is contiguous for MFMA fragments.  The concatenations
+of the reference (`cat[net, inp, corr_feat, flow_feat]`, droid_net.py:388-389) are never materialised: the
+GRU convolutions read channels [0,128) from the hidden state (or r*net) and [128,448) from one
+[E,h,w,320] buffer that the encoders write into.
 
-Backends
-  * "hip"   : hand-written MFMA implicit-GEMM convolutions of libvipe_amd.so (vipe_conv2d_nhwc_f16) with
-              fused bias / activation / per-image additive term.
-  * "miopen": the same dataflow with torch.nn.functional.conv2d in fp16 channels_last (MIOpen / hipBLASLt).
-              Kept as the A/B baseline for the hand-written kernels; selected only explicitly or through
-              VIPE_AMD_CONV=miopen.
+13 launches per update, all hand-written MFMA implicit-GEMM convolutions (csrc/conv_mfma.hip) with fused
+epilogues:
+    corr0 (1x1 200->128, relu) -> corr2 (3x3, relu)            -> xbuf[128:256]
+    flow0 (7x7 4->128, relu)   -> flow2 (3x3 128->64, relu)    -> xbuf[256:320]
+    w     (1x1, sigmoid * net, summed over pixels)             -> glo_sum        [GLO epilogue]
+    convz|convr (3x3 448->256): z, r*net                                          [ZR epilogue]
+    convq (3x3 448->128): net' = (1-z) net + z tanh(.)                            [Q epilogue]
+    delta0|weight0|agg1 (3x3 128->384, relu) -> delta2|weight2 (3x3 256->4)       [HEADS epilogue]
+    agg2 (3x3, relu) -> eta (3x3 128->1, 0.01 softplus)                           [ETA epilogue]
+
+Backends: "hip" (default, the kernels above) and "miopen" (torch conv2d, fp16 channels_last) kept as the A/B
+baseline for the hand-written kernels - selected only explicitly or through VIPE_AMD_CONV=miopen.
 """
 
+import ctypes
 import os
 
 import torch
@@ -21,136 +29,227 @@ import torch.nn.functional as F
 from .._lib import check, lib, ptr, stream_ptr
 
 ACT = {"none": 0, "relu": 1, "sigmoid": 2, "tanh": 3}
+EPI = {"plain": 0, "glo": 1, "zr": 2, "q": 3, "heads": 4, "eta": 5}
+CORR_CH = 200  # 196 correlation channels padded to a multiple of 8 (zeros)
 
 
-class _ConvW:
-    """One convolution's parameters in both layouts."""
+class _Packed:
+    """Weights of one (possibly fused) convolution packed for conv_mfma: [K_pad/64][Cout_pad][64] fp16."""
 
-    def __init__(self, conv, device, cout_slice=None):
-        w = conv.weight.detach()
-        b = conv.bias.detach()
-        if cout_slice is not None:
-            w, b = w[cout_slice], b[cout_slice]
+    def __init__(self, w_oihw, bias, device):
+        w = w_oihw.detach().to(device=device, dtype=torch.float16).contiguous()
         self.cout, self.cin, self.kh, self.kw = w.shape
-        self.w_oihw = w.to(device=device, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
-        self.bias16 = b.to(device=device, dtype=torch.float16)
-        self.bias32 = b.to(device=device, dtype=torch.float32).contiguous()
-        self.w_packed = None  # [KH*KW, Cin, Cout] fp16, built lazily for the hip backend
+        cp, cinp, kp = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(lib().vipe_conv_packed_dims(self.cout, self.cin, self.kh, self.kw, ctypes.addressof(cp),
+                                          ctypes.addressof(cinp), ctypes.addressof(kp)), "conv_packed_dims")
+        self.packed = torch.empty(kp.value * cp.value, dtype=torch.float16, device=device)
+        check(lib().vipe_conv_pack_weights(ptr(w), ptr(self.packed), self.cout, self.cin, self.kh, self.kw, 0,
+                                           stream_ptr(w)), "conv_pack_weights")
+        self.bias = bias.detach().to(device=device, dtype=torch.float32).contiguous()
+        self.flops_per_pixel = 2.0 * self.cout * self.cin * self.kh * self.kw
 
 
 class UpdateEngine:
     def __init__(self, module, device, backend=None):
         self.device = device
         self.backend = backend or os.environ.get("VIPE_AMD_CONV", "hip")
-        m = module
-        d = device
-        self.w = {
-            "corr0": _ConvW(m.corr_encoder[0], d), "corr2": _ConvW(m.corr_encoder[2], d),
-            "flow0": _ConvW(m.flow_encoder[0], d), "flow2": _ConvW(m.flow_encoder[2], d),
-            "weight0": _ConvW(m.weight[0], d), "weight2": _ConvW(m.weight[2], d),
-            "delta0": _ConvW(m.delta[0], d), "delta2": _ConvW(m.delta[2], d),
-            "convz": _ConvW(m.gru.convz, d), "convr": _ConvW(m.gru.convr, d), "convq": _ConvW(m.gru.convq, d),
-            "w": _ConvW(m.gru.w, d), "convz_glo": _ConvW(m.gru.convz_glo, d), "convr_glo": _ConvW(m.gru.convr_glo, d),
-            "convq_glo": _ConvW(m.gru.convq_glo, d),
-            "agg1": _ConvW(m.agg.conv1, d), "agg2": _ConvW(m.agg.conv2, d), "eta": _ConvW(m.agg.eta[0], d),
-            "upmask": _ConvW(m.agg.upmask[0], d),
-        }
+        self.m = module
+        self._bufs = {}
         if self.backend == "hip":
-            for cw in self.w.values():
-                self._pack(cw)
+            self._pack_all()
 
-    # ------------------------------------------------------------------ convolution primitive
-    def _pack(self, cw):
-        packed = torch.empty((cw.kh * cw.kw, cw.cin, cw.cout), dtype=torch.float16, device=self.device)
-        src = cw.w_oihw.contiguous()  # plain OIHW for the packer
-        check(lib().vipe_conv_pack_weights(ptr(src), ptr(packed), cw.cout, cw.cin, cw.kh, cw.kw, 0, stream_ptr(src)),
-              "conv_pack_weights")
-        cw.w_packed = packed
+    # ------------------------------------------------------------------ weights
+    def _pack_all(self):
+        m, d = self.m, self.device
+        f16 = torch.float16
 
-    def conv(self, x, name, act="none", out=None, cout_off=0, cin_off=0, extra=None):
-        """x [B,H,W,Ctot] fp16 NHWC (reads channels cin_off:cin_off+Cin) -> out[..., cout_off:cout_off+Cout]."""
-        cw = self.w[name]
-        B, H, W, ctot = x.shape
-        if out is None:
-            out = torch.empty((B, H, W, cw.cout), dtype=torch.float16, device=x.device)
-        if self.backend == "hip":
-            check(lib().vipe_conv2d_nhwc_f16(ptr(x), ptr(cw.w_packed), ptr(cw.bias32), ptr(extra), ptr(out), B, H, W,
-                                             cw.cin, ctot, cin_off, cw.cout, out.shape[-1], cout_off, cw.kh, cw.kw,
-                                             ACT[act], stream_ptr(x)), "conv2d_nhwc_f16")
-            return out
-        xin = x[..., cin_off:cin_off + cw.cin].permute(0, 3, 1, 2)  # NCHW view of NHWC memory (channels_last)
-        y = F.conv2d(xin, cw.w_oihw, cw.bias16, padding=cw.kh // 2)
-        if extra is not None:
-            y = y + extra.to(torch.float16)[:, :, None, None]
-        y = {"none": lambda t: t, "relu": torch.relu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}[act](y)
-        out[..., cout_off:cout_off + cw.cout] = y.permute(0, 2, 3, 1)
-        return out
+        def wb(conv):
+            return conv.weight.detach().to(d, f16), conv.bias.detach().to(d, torch.float32)
 
-    # ------------------------------------------------------------------ the operator
+        w, b = wb(m.corr_encoder[0])
+        w = torch.cat([w, torch.zeros(128, CORR_CH - 196, 1, 1, device=d, dtype=f16)], 1)
+        self.corr0 = _Packed(w, b, d)
+        self.corr2 = _Packed(*wb(m.corr_encoder[2]), d)
+        self.flow0 = _Packed(*wb(m.flow_encoder[0]), d)
+        self.flow2 = _Packed(*wb(m.flow_encoder[2]), d)
+        self.gw = _Packed(*wb(m.gru.w), d)
+        wz, bz = wb(m.gru.convz)
+        wr, br = wb(m.gru.convr)
+        self.zr = _Packed(torch.cat([wz, wr], 0), torch.cat([bz, br], 0), d)
+        self.q = _Packed(*wb(m.gru.convq), d)
+        wd0, bd0 = wb(m.delta[0])
+        ww0, bw0 = wb(m.weight[0])
+        wa1, ba1 = wb(m.agg.conv1)
+        self.heads0 = _Packed(torch.cat([wd0, ww0, wa1], 0), torch.cat([bd0, bw0, ba1], 0), d)
+        wd2, bd2 = wb(m.delta[2])
+        ww2, bw2 = wb(m.weight[2])
+        h2 = torch.zeros(4, 256, 3, 3, device=d, dtype=f16)
+        h2[0:2, 0:128] = wd2[:2]
+        h2[2:4, 128:256] = ww2[:2]
+        self.heads2 = _Packed(h2, torch.cat([bd2[:2], bw2[:2]], 0), d)
+        self.agg2 = _Packed(*wb(m.agg.conv2), d)
+        self.eta = _Packed(*wb(m.agg.eta[0]), d)
+        self.upmask = _Packed(*wb(m.agg.upmask[0]), d)
+        # global-context 1x1s applied to the pooled vector: one [128, 384] matrix (z | r | q)
+        g = m.gru
+        self.glo_w = torch.cat([g.convz_glo.weight, g.convr_glo.weight, g.convq_glo.weight], 0).detach().to(d).float() \
+            .reshape(384, 128).t().contiguous()
+        self.glo_b = torch.cat([g.convz_glo.bias, g.convr_glo.bias, g.convq_glo.bias], 0).detach().to(d).float()
+
+    # ------------------------------------------------------------------ launches
+    def _conv(self, pk, x0, x0_coff, B, H, W, y=None, y_coff=0, act="none", mode="plain", x1=None, x1_coff=0,
+              split=None, extra=None, extra_off=0, y2=None, y2_coff=0, net=None, net_coff=0, z=None, fout=None,
+              cin=None):
+        cin = pk.cin if cin is None else cin
+        split = cin if split is None else split
+        check(lib().vipe_conv2d_fused(
+            ptr(x0), x0.shape[-1], x0_coff, ptr(x1), x1.shape[-1] if x1 is not None else 0, x1_coff, split,
+            ptr(pk.packed), ptr(pk.bias), ptr(extra), extra.shape[-1] if extra is not None else 0, extra_off,
+            ptr(y), y.shape[-1] if y is not None else 0, y_coff, ptr(y2), y2.shape[-1] if y2 is not None else 0, y2_coff,
+            ptr(net), net.shape[-1] if net is not None else 0, net_coff, ptr(z), ptr(fout), B, H, W, cin, pk.cout,
+            pk.kh, pk.kw, ACT[act], EPI[mode], stream_ptr(x0)), "conv2d_fused")
+
+    def _buf(self, name, shape, dtype=torch.float16):
+        t = self._bufs.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._bufs[name] = t
+        return t
+
+    @torch.no_grad()
+    def forward_nhwc(self, net, xbuf, corr, motn, ix=None, n_src=None, net_out=None, want_upmask=False):
+        """The operator on channels-last state.
+
+        net  [E,h,w,128] f16 hidden state;  xbuf [E,h,w,320] f16 with the context features `inp` in channels
+        [0,128) (channels [128,320) are scratch, overwritten);  corr [E,h,w,200] f16 (196 + zero pad);
+        motn [E,h,w,4] f16;  ix [E] int64 -> source slot.  Returns (net' [E,h,w,128] f16, dw [E,h,w,4] f32 =
+        (delta_x, delta_y, weight_x, weight_y), eta [n_src,h,w] f32 or None, upmask or None)."""
+        E, H, W, _ = net.shape
+        assert self.backend == "hip"
+        c1 = self._buf("c1", (E, H, W, 128))
+        f1 = self._buf("f1", (E, H, W, 128))
+        zb = self._buf("z", (E, H, W, 128))
+        rnet = self._buf("rnet", (E, H, W, 128))
+        hbuf = self._buf("h", (E, H, W, 384))
+        dw = self._buf("dw", (E, H, W, 4), torch.float32)
+        glo = self._buf("glo", (E, 128), torch.float32)
+        if net_out is None:
+            net_out = torch.empty_like(net)
+        # encoders (droid_net.py:481-482)
+        self._conv(self.corr0, corr, 0, E, H, W, y=c1, act="relu", cin=CORR_CH)
+        self._conv(self.corr2, c1, 0, E, H, W, y=xbuf, y_coff=128, act="relu")
+        self._conv(self.flow0, motn, 0, E, H, W, y=f1, act="relu")
+        self._conv(self.flow2, f1, 0, E, H, W, y=xbuf, y_coff=256, act="relu")
+        # global context (droid_net.py:392-393) and its three 1x1s (a [E,128] x [128,384] product)
+        glo.zero_()
+        self._conv(self.gw, net, 0, E, H, W, mode="glo", net=net, fout=glo)
+        extra = torch.addmm(self.glo_b, glo, self.glo_w, alpha=1.0 / (H * W))  # [E,384] fp32
+        # gates (droid_net.py:395-399)
+        self._conv(self.zr, net, 0, E, H, W, x1=xbuf, split=128, y=zb, y2=rnet, net=net, mode="zr", extra=extra)
+        self._conv(self.q, rnet, 0, E, H, W, x1=xbuf, split=128, y=net_out, net=net, z=zb, mode="q", extra=extra,
+                   extra_off=256)
+        # heads + first aggregation conv on net' (droid_net.py:486-487, 418)
+        self._conv(self.heads0, net_out, 0, E, H, W, y=hbuf, act="relu")
+        self._conv(self.heads2, hbuf, 0, E, H, W, mode="heads", fout=dw, cin=256)
+        eta = upmask = None
+        if ix is not None:
+            if n_src is None:  # the reference syncs here too (scatter.py:40: int(index.max()) + 1)
+                n_src = int(ix.max().item()) + 1 if ix.numel() else 0
+            # scatter_mean over the edges of each source node (droid_net.py:420-421)
+            acc = torch.zeros((n_src, H, W, 128), dtype=torch.float32, device=self.device)
+            acc.index_add_(0, ix, hbuf[..., 256:384].float())
+            cnt = torch.zeros(n_src, dtype=torch.float32, device=self.device).index_add_(
+                0, ix, torch.ones(E, device=self.device))
+            agg = (acc / cnt.clamp(min=1).view(-1, 1, 1, 1)).to(torch.float16)
+            a2 = self._buf("a2", (n_src, H, W, 128))
+            eta = torch.empty((n_src, H, W), dtype=torch.float32, device=self.device)
+            self._conv(self.agg2, agg, 0, n_src, H, W, y=a2, act="relu")
+            self._conv(self.eta, a2, 0, n_src, H, W, mode="eta", fout=eta)
+            if want_upmask:
+                upmask = torch.empty((n_src, H, W, 576), dtype=torch.float16, device=self.device)
+                self._conv(self.upmask, a2, 0, n_src, H, W, y=upmask)
+        return net_out, dw, eta, upmask
+
+    # ------------------------------------------------------------------ reference-shaped entry point
     @torch.no_grad()
     def forward(self, net, inp, corr, flow=None, ix=None, skip_upmask=False, n_src=None):
-        """Reference signature and return structure (droid_net.py:467-499); tensors arrive NCHW like the reference
-        ([1,E,C,h,w]); NHWC buffers are used internally."""
+        """Reference signature and return structure (droid_net.py:467-499): NCHW [1,E,C,h,w] in and out."""
+        if self.backend != "hip":
+            return self._forward_miopen(net, inp, corr, flow, ix, skip_upmask, n_src)
         batch, num, ch, ht, wd = net.shape
         E = batch * num
         dev = net.device
         f16 = torch.float16
-
-        def nhwc(t, c):
-            return t.reshape(E, c, ht, wd).to(f16).permute(0, 2, 3, 1).contiguous()
-
-        # hx = [net(128) | inp(128) | corr_feat(128) | flow_feat(64)]  (droid_net.py:388-389)
-        hx = torch.empty((E, ht, wd, 448), dtype=f16, device=dev)
-        hx[..., 0:128] = net.reshape(E, 128, ht, wd).permute(0, 2, 3, 1)
-        hx[..., 128:256] = inp.reshape(E, 128, ht, wd).permute(0, 2, 3, 1)
-        corr_n = nhwc(corr, 196)
+        net_n = net.reshape(E, 128, ht, wd).to(f16).permute(0, 2, 3, 1).contiguous()
+        xbuf = torch.empty((E, ht, wd, 320), dtype=f16, device=dev)
+        xbuf[..., 0:128] = inp.reshape(E, 128, ht, wd).permute(0, 2, 3, 1)
+        corr_n = torch.zeros((E, ht, wd, CORR_CH), dtype=f16, device=dev)
+        corr_n[..., :196] = corr.reshape(E, 196, ht, wd).permute(0, 2, 3, 1)
         if flow is None:
-            flow_n = torch.zeros((E, ht, wd, 4), dtype=f16, device=dev)
+            motn_n = torch.zeros((E, ht, wd, 4), dtype=f16, device=dev)
         else:
-            flow_n = nhwc(flow, 4)
-
-        c1 = self.conv(corr_n, "corr0", "relu")
-        self.conv(c1, "corr2", "relu", out=hx, cout_off=256)
-        f1 = self.conv(flow_n, "flow0", "relu")
-        self.conv(f1, "flow2", "relu", out=hx, cout_off=384)
-
-        # global context (droid_net.py:392-393): glo = mean_hw(sigmoid(w(net)) * net)
-        g = self.conv(hx, "w", "sigmoid")  # reads channels 0:128
-        glo = (g.float() * hx[..., 0:128].float()).mean(dim=(1, 2))  # [E,128] fp32
-        glo16 = glo.to(f16)
-
-        def glo_term(name):
-            cw = self.w[name]
-            return (glo16 @ cw.w_oihw.reshape(cw.cout, cw.cin).t() + cw.bias16).float().contiguous()
-
-        z = self.conv(hx, "convz", "sigmoid", extra=glo_term("convz_glo"))
-        r = self.conv(hx, "convr", "sigmoid", extra=glo_term("convr_glo"))
-        rhx = hx.clone()
-        rhx[..., 0:128] = r * hx[..., 0:128]
-        q = self.conv(rhx, "convq", "tanh", extra=glo_term("convq_glo"))
-        net_n = (1 - z) * hx[..., 0:128] + z * q  # [E,h,w,128] fp16
-
-        d1 = self.conv(net_n, "delta0", "relu")
-        delta = self.conv(d1, "delta2", "none")
-        w1 = self.conv(net_n, "weight0", "relu")
-        weight = self.conv(w1, "weight2", "sigmoid")
-        delta = delta.view(batch, num, ht, wd, -1)[..., :2].contiguous()
-        weight = weight.view(batch, num, ht, wd, -1)[..., :2].contiguous()
-        net_out = net_n.permute(0, 3, 1, 2).reshape(batch, num, 128, ht, wd)
+            motn_n = flow.reshape(E, 4, ht, wd).to(f16).permute(0, 2, 3, 1).contiguous()
+        ixd = ix.to(dev) if ix is not None else None
+        net_o, dw, eta, upmask = self.forward_nhwc(net_n, xbuf, corr_n, motn_n, ixd, n_src, want_upmask=not skip_upmask)
+        net_out = net_o.permute(0, 3, 1, 2).reshape(batch, num, 128, ht, wd)
+        dwv = dw.view(batch, num, ht, wd, 4).to(f16)
+        delta, weight = dwv[..., 0:2].contiguous(), dwv[..., 2:4].contiguous()
         if ix is None:
             return net_out, delta, weight
+        n_src = eta.shape[0]
+        if upmask is not None:
+            upmask = upmask.permute(0, 3, 1, 2).reshape(batch, n_src, 576, ht, wd)
+        return net_out, delta, weight, eta.view(batch, n_src, ht, wd), upmask
 
-        # GraphAgg (droid_net.py:414-429)
-        a = self.conv(net_n, "agg1", "relu")  # [E,h,w,128]
-        if n_src is None:  # the reference syncs here too (scatter.py:40: int(index.max()) + 1)
+    # ------------------------------------------------------------------ A/B baseline
+    def _forward_miopen(self, net, inp, corr, flow, ix, skip_upmask, n_src):
+        m = self.m
+        batch, num, ch, ht, wd = net.shape
+        E = batch * num
+        dev = net.device
+        f16 = torch.float16
+        if not hasattr(self, "_mio"):
+            self._mio = {k: (c.weight.detach().to(dev, f16).contiguous(memory_format=torch.channels_last),
+                             c.bias.detach().to(dev, f16))
+                         for k, c in dict(corr0=m.corr_encoder[0], corr2=m.corr_encoder[2], flow0=m.flow_encoder[0],
+                                          flow2=m.flow_encoder[2], w=m.gru.w, convz=m.gru.convz, convr=m.gru.convr,
+                                          convq=m.gru.convq, zg=m.gru.convz_glo, rg=m.gru.convr_glo, qg=m.gru.convq_glo,
+                                          d0=m.delta[0], d2=m.delta[2], w0=m.weight[0], w2=m.weight[2],
+                                          a1=m.agg.conv1, a2=m.agg.conv2, eta=m.agg.eta[0], up=m.agg.upmask[0]).items()}
+
+        def cv(x, k, pad):
+            w, b = self._mio[k]
+            return F.conv2d(x, w, b, padding=pad)
+
+        def cl(t, c):
+            return t.reshape(E, c, ht, wd).to(f16).contiguous(memory_format=torch.channels_last)
+
+        net_ = cl(net, 128)
+        inp_ = cl(inp, 128)
+        c = F.relu(cv(F.relu(cv(cl(corr, 196), "corr0", 0)), "corr2", 1))
+        fl = cl(flow, 4) if flow is not None else torch.zeros(E, 4, ht, wd, device=dev, dtype=f16)
+        f = F.relu(cv(F.relu(cv(fl, "flow0", 3)), "flow2", 1))
+        x = torch.cat([inp_, c, f], 1)
+        hx = torch.cat([net_, x], 1)
+        glo = (torch.sigmoid(cv(net_, "w", 0)) * net_).mean(dim=(2, 3), keepdim=True)
+        z = torch.sigmoid(cv(hx, "convz", 1) + cv(glo, "zg", 0))
+        r = torch.sigmoid(cv(hx, "convr", 1) + cv(glo, "rg", 0))
+        q = torch.tanh(cv(torch.cat([r * net_, x], 1), "convq", 1) + cv(glo, "qg", 0))
+        net_ = (1 - z) * net_ + z * q
+        delta = cv(F.relu(cv(net_, "d0", 1)), "d2", 1).view(batch, num, -1, ht, wd).permute(0, 1, 3, 4, 2)[..., :2].contiguous()
+        weight = torch.sigmoid(cv(F.relu(cv(net_, "w0", 1)), "w2", 1)).view(batch, num, -1, ht, wd) \
+            .permute(0, 1, 3, 4, 2)[..., :2].contiguous()
+        net_out = net_.view(batch, num, 128, ht, wd)
+        if ix is None:
+            return net_out, delta, weight
+        a = F.relu(cv(net_, "a1", 1))
+        if n_src is None:
             n_src = int(ix.max().item()) + 1 if ix.numel() else 0
         ixd = ix.to(dev)
-        acc = torch.zeros((n_src, ht, wd, 128), dtype=torch.float32, device=dev).index_add_(0, ixd, a.float())
+        acc = torch.zeros((n_src, 128, ht, wd), dtype=torch.float32, device=dev).index_add_(0, ixd, a.float())
         cnt = torch.zeros(n_src, dtype=torch.float32, device=dev).index_add_(0, ixd, torch.ones(E, device=dev))
-        a = (acc / cnt.clamp(min=1).view(-1, 1, 1, 1)).to(f16)
-        a = self.conv(a, "agg2", "relu")
-        eta = F.softplus(self.conv(a, "eta", "none").float()).view(batch, n_src, ht, wd)
-        upmask = None
-        if not skip_upmask:
-            upmask = self.conv(a, "upmask", "none").permute(0, 3, 1, 2).reshape(batch, n_src, 8 * 8 * 9, ht, wd)
+        a = (acc / cnt.clamp(min=1).view(-1, 1, 1, 1)).to(f16).contiguous(memory_format=torch.channels_last)
+        a = F.relu(cv(a, "a2", 1))
+        eta = F.softplus(cv(a, "eta", 1).float()).view(batch, n_src, ht, wd)
+        upmask = None if skip_upmask else cv(a, "up", 0).view(batch, n_src, 576, ht, wd)
         return net_out, delta, weight, 0.01 * eta, upmask
