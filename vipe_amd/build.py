@@ -30,7 +30,7 @@ def _sources():
 
 def _deps_hash(src):
     h = hashlib.sha1()
-    for f in [src] + sorted(os.path.join(CSRC, x) for x in os.listdir(CSRC) if x.endswith((".cuh", ".h"))):
+    for f in [src] + sorted(os.path.join(CSRC, x) for x in os.listdir(CSRC) if x.endswith((".cuh", ".h", ".inc"))):
         h.update(open(f, "rb").read())
     h.update(open(os.path.join(os.path.dirname(HERE), "include", "vipe_amd.h"), "rb").read())
     h.update(" ".join(FLAGS).encode())

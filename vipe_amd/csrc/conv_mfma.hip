@@ -17,6 +17,8 @@
 //     gather of a 3x3 tap is coalesced in 128-byte segments; out-of-image taps and channels >= Cin read as 0.
 //   * the channel range may be split over two source tensors (the GRU's [r*net | inp, corr, flow] input), so
 //     the concatenations of the reference are never materialised.
+#include <stdlib.h>
+
 #include "common.cuh"
 
 namespace {
@@ -195,107 +197,160 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     __syncthreads();
   }
 
-  // ---- epilogue.  lane: pixel = col, regs r -> cout row (r&3) + 8(r>>2) + 4*lhalf
+#include "conv_epilogue.inc"
+}
+
+// ---- LDS-DMA variant (generic Cin): both operand tiles go global -> LDS with global_load_lds_dwordx4, no staging
+// registers and no ds_write.  A wave-instruction fills 1 KiB = 8 tile rows x 128 B; the XOR swizzle of the
+// 16-byte chunks is applied on the SOURCE address (the LDS destination of an LDS-DMA is lane-linear).
+// Out-of-image taps / channels >= Cin read a 16-byte zero page instead.  Blocks are remapped so that
+// consecutive logical tiles (and the cout tiles of one pixel tile) run on the same XCD and share its L2.
+__device__ __attribute__((aligned(16))) unsigned char g_zero_page[64];
+
+// 16 bytes per lane, global -> LDS (wave-uniform LDS byte address + lane * 16), as inline asm: hipcc orders every
+// later LDS read behind a visible LDS-DMA with s_waitcnt vmcnt(0), which would serialise load and compute; hidden
+// in asm the DMA is counted by hand (one s_waitcnt vmcnt(0) before the barrier that publishes the buffer).
+// M0 carries the LDS base and is compiler-reserved, so it is saved/restored inside the same statement.
+__device__ __forceinline__ void glds16(const void* g, unsigned lds_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned keep;
+  const unsigned base = __builtin_amdgcn_readfirstlane(lds_addr);
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(g), "s"(base)
+      : "memory");
+#endif
+}
+
+__device__ __forceinline__ unsigned lds_address(const void* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)p;
+}
+
+template <int BMC, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_mfma_glds_kernel(ConvArgs a, int gy) {
+  constexpr int TM = BMC / (WAVES_M * 32);
+  constexpr int TN = BNP / (WAVES_N * 32);
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  constexpr int WP = BMC / 32;  // 1-KiB weight pieces per wave per K-step
+  constexpr int XP = BNP / 32;  // activation pieces per wave per K-step (4)
+
+  extern __shared__ __align__(16) unsigned char lds[];
+  unsigned char* ldsW = lds;
+  unsigned char* ldsX = lds + 2 * BMC * 128;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int nb = gridDim.x;
+  const int L = xcd_remap(blockIdx.x, nb);
+  const int64_t M = (int64_t)a.B * a.H * a.W;
+  const int64_t pix0 = (int64_t)(L / gy) * BNP;
+  const int cout0 = (L % gy) * BMC;
+  const int HW = a.H * a.W;
+  const int ph = a.KH / 2, pw = a.KW / 2;
+  const int csteps = a.Cin_pad / BK;
+  const int r8 = lane >> 3, sl = lane & 7;
+
+  // ---- per-lane descriptors of this wave's pieces
+  int woff[WP];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int64_t m = pix0 + (wn * TN + j) * 32 + lrow;
-    const bool mok = m < M;
-    const int e = mok ? (int)(m / HW) : 0;
+  for (int q = 0; q < WP; ++q) {
+    const int row = (wave * WP + q) * 8 + r8;
+    woff[q] = row * BK + ((sl ^ ((row >> 1) & 7)) << 3);
+  }
+  const half_t* xb0[XP];
+  const half_t* xb1[XP];
+  int xk8[XP], py[XP], px[XP];
+  unsigned xmask[XP];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+  for (int q = 0; q < XP; ++q) {
+    const int row = (wave * XP + q) * 8 + r8;
+    const int64_t m = pix0 + row;
+    const bool ok = m < M;
+    const int64_t mm = ok ? m : 0;
+    const int rem = (int)(mm % HW);
+    py[q] = ok ? rem / a.W : -100000;  // invalid pixel: every tap fails the bounds test
+    px[q] = rem % a.W;
+    const int k8 = sl ^ ((row >> 1) & 7);
+    xk8[q] = k8 * 8;
+    xb0[q] = a.x0 + mm * a.x0_ctot + a.x0_coff + k8 * 8;
+    xb1[q] = a.x1 + mm * a.x1_ctot + a.x1_coff + k8 * 8 - a.split;
+    xmask[q] = 0;
+  }
+  for (int t = 0; t < a.KH * a.KW; ++t) {
+    const int dy = t / a.KW - ph, dx = t % a.KW - pw;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = cout0 + (wm * TM + i) * 32 + 8 * g + 4 * lhalf;  // 4 consecutive couts
-        float v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          v[q] = acc[i][j][4 * g + q];
-          if (co + q < a.Cout) {
-            v[q] += a.bias[co + q];
-            if (a.extra) v[q] += a.extra[(int64_t)e * a.extra_stride + a.extra_off + co + q];
-          }
-        }
-        if (a.epi == EPI_PLAIN) {
-          if (mok && co < a.Cout) {
-            half4 o;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = (half_t)act_apply(v[q], a.act);
-            if (co + 3 < a.Cout) {
-              *reinterpret_cast<half4*>(a.y + m * a.y_ctot + a.y_coff + co) = o;
-            } else {
-              for (int q = 0; q < 4 && co + q < a.Cout; ++q) a.y[m * a.y_ctot + a.y_coff + co + q] = o[q];
-            }
-          }
-        } else if (a.epi == EPI_GLO) {
-          // sigmoid(w(net)) * net, summed over the tile's pixels (droid_net.py:392-393)
-          float s4[4] = {0, 0, 0, 0};
-          if (mok) {
-            const half4 nv = *reinterpret_cast<const half4*>(a.net + m * a.net_ctot + a.net_coff + co);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) s4[q] = (float)(half_t)act_apply(v[q], VIPE_ACT_SIGMOID) * (float)nv[q];
-          }
-          const int e_first = (int)(pix0 / HW);
-          const int64_t last = (pix0 + BNP - 1 < M ? pix0 + BNP - 1 : M - 1);
-          const bool one_image = (int)(last / HW) == e_first;  // block-uniform
-          if (one_image) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              float t = s4[q];
-#pragma unroll
-              for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, WAVE);  // over the 32 pixels of this half
-              if (lrow == 0) atomicAdd(a.fout + (int64_t)e_first * a.Cout + co + q, t);
-            }
-          } else if (mok) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) atomicAdd(a.fout + (int64_t)e * a.Cout + co + q, s4[q]);
-          }
-        } else if (a.epi == EPI_ZR) {
-          if (mok) {
-            half4 o;
-            if (co < 128) {  // z
-#pragma unroll
-              for (int q = 0; q < 4; ++q) o[q] = (half_t)act_apply(v[q], VIPE_ACT_SIGMOID);
-              *reinterpret_cast<half4*>(a.y + m * a.y_ctot + a.y_coff + co) = o;
-            } else {  // r * net
-              const half4 nv = *reinterpret_cast<const half4*>(a.net + m * a.net_ctot + a.net_coff + co - 128);
-#pragma unroll
-              for (int q = 0; q < 4; ++q)
-                o[q] = (half_t)((float)(half_t)act_apply(v[q], VIPE_ACT_SIGMOID) * (float)nv[q]);
-              *reinterpret_cast<half4*>(a.y2 + m * a.y2_ctot + a.y2_coff + co - 128) = o;
-            }
-          }
-        } else if (a.epi == EPI_Q) {
-          if (mok) {
-            const half4 nv = *reinterpret_cast<const half4*>(a.net + m * a.net_ctot + a.net_coff + co);
-            const half4 zv = *reinterpret_cast<const half4*>(a.zbuf + m * 128 + co);
-            half4 o;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float qq = (float)(half_t)tanhf(v[q]);
-              const float z = (float)zv[q];
-              o[q] = (half_t)((1.0f - z) * (float)nv[q] + z * qq);  // droid_net.py:399
-            }
-            *reinterpret_cast<half4*>(a.y + m * a.y_ctot + a.y_coff + co) = o;
-          }
-        } else if (a.epi == EPI_HEADS) {
-          // cout 0,1: delta; cout 2,3: sigmoid -> weight (droid_net.py:486-490); written as float [M,4]
-          if (mok && co == 0) {
-            float4 o = make_float4((float)(half_t)v[0], (float)(half_t)v[1],
-                                   (float)(half_t)act_apply(v[2], VIPE_ACT_SIGMOID),
-                                   (float)(half_t)act_apply(v[3], VIPE_ACT_SIGMOID));
-            *reinterpret_cast<float4*>(a.fout + m * 4) = o;
-          }
-        } else if (a.epi == EPI_ETA) {
-          // 0.01 * softplus (droid_net.py:410,429)
-          if (mok && co == 0) {
-            const float x = v[0];
-            const float sp = x > 20.0f ? x : log1pf(__expf(x));
-            a.fout[m] = 0.01f * (float)(half_t)sp;
-          }
-        }
-      }
+    for (int q = 0; q < XP; ++q) {
+      const int yy = py[q] + dy, xc = px[q] + dx;
+      if (yy >= 0 && yy < a.H && xc >= 0 && xc < a.W) xmask[q] |= 1u << t;
     }
   }
+  const half_t* zp = reinterpret_cast<const half_t*>(g_zero_page);
+
+  auto issue = [&](int s, int buf) {
+    const half_t* wb = a.w + ((int64_t)s * a.Cout_pad + cout0) * BK;
+    unsigned char* lw = ldsW + buf * BMC * 128 + wave * WP * 1024;
+#pragma unroll
+    for (int q = 0; q < WP; ++q)
+      glds16(wb + woff[q], lds_address(lw) + q * 1024);
+    const int tap = s / csteps, c0 = (s % csteps) * BK;
+    const int dy = tap / a.KW - ph, dx = tap % a.KW - pw;
+    const bool s0 = c0 < a.split;  // uniform: split is a multiple of 64
+    const int64_t delta = (int64_t)(dy * a.W + dx) * (s0 ? a.x0_ctot : a.x1_ctot) + c0;
+    const int crem = a.Cin - c0;
+    unsigned char* lx = ldsX + buf * BNP * 128 + wave * XP * 1024;
+#pragma unroll
+    for (int q = 0; q < XP; ++q) {
+      const bool ok = ((xmask[q] >> tap) & 1u) && (xk8[q] < crem);
+      const half_t* p = (s0 ? xb0[q] : xb1[q]) + delta;
+      glds16(ok ? p : zp, lds_address(lx) + q * 1024);
+    }
+  };
+
+  float16v acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  for (int s = 0; s < a.nsteps; ++s) {
+    const int cur = s & 1;
+    const unsigned char* bw = ldsW + cur * BMC * 128;
+    const unsigned char* bx = ldsX + cur * BNP * 128;
+    // 1. all fragments of this K-step into registers.  hipcc orders any LDS read after an in-flight LDS-DMA with
+    //    s_waitcnt vmcnt(0), so the reads must be issued BEFORE the next step's DMA for the two to overlap.
+    half8 wf[BK / 16][TM], xf[BK / 16][TN];
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        wf[kk][i] = *reinterpret_cast<const half8*>(bw + swz((wm * TM + i) * 32 + lrow, kk * 2 + lhalf));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        xf[kk][j] = *reinterpret_cast<const half8*>(bx + swz((wn * TN + j) * 32 + lrow, kk * 2 + lhalf));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // 2. next K-step's tiles, global -> LDS (other buffer), in flight during the MFMAs
+    if (s + 1 < a.nsteps) issue(s + 1, cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // 3. matrix cores
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk][i], xf[kk][j], acc[i][j], 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#include "conv_epilogue.inc"
 }
 
 // OIHW (fp16 or fp32) -> packed [K_pad/64][Cout_pad][64] fp16, k = tap*Cin_pad + c (generic) or tap*4 + c (Cin == 4)
@@ -371,21 +426,26 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<128, 2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<128, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)conv_mfma_glds_kernel<128, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     attr = true;
   }
+  const bool glds = !small && a.KH * a.KW <= 32 && getenv("VIPE_AMD_CONV_REGSTAGE") == nullptr;
   if (cp >= 128) {
     const size_t lds = 2 * (128 + BNP) * 128;
-    dim3 grid(gx, cp / 128);
-    if (small) conv_mfma_kernel<128, 2, 2, true><<<grid, 256, lds, s>>>(a);
-    else conv_mfma_kernel<128, 2, 2, false><<<grid, 256, lds, s>>>(a);
+    const int gy = cp / 128;
+    if (small) conv_mfma_kernel<128, 2, 2, true><<<dim3(gx, gy), 256, lds, s>>>(a);
+    else if (glds) conv_mfma_glds_kernel<128, 2, 2><<<dim3(gx * gy), 256, lds, s>>>(a, gy);
+    else conv_mfma_kernel<128, 2, 2, false><<<dim3(gx, gy), 256, lds, s>>>(a);
   } else if (cp == 64) {
     const size_t lds = 2 * (64 + BNP) * 128;
     if (small) return VIPE_EUNSUPPORTED;
-    conv_mfma_kernel<64, 1, 4, false><<<dim3(gx, 1), 256, lds, s>>>(a);
+    if (glds) conv_mfma_glds_kernel<64, 1, 4><<<dim3(gx), 256, lds, s>>>(a, 1);
+    else conv_mfma_kernel<64, 1, 4, false><<<dim3(gx, 1), 256, lds, s>>>(a);
   } else {
     const size_t lds = 2 * (32 + BNP) * 128;
     if (small) return VIPE_EUNSUPPORTED;
-    conv_mfma_kernel<32, 1, 4, false><<<dim3(gx, 1), 256, lds, s>>>(a);
+    if (glds) conv_mfma_glds_kernel<32, 1, 4><<<dim3(gx), 256, lds, s>>>(a, 1);
+    else conv_mfma_kernel<32, 1, 4, false><<<dim3(gx, 1), 256, lds, s>>>(a);
   }
   return vipe_launch_status();
 }
