@@ -196,7 +196,7 @@ def main():
                        "conv_backend": args.conv, "parallelism": f"clip-sharded x{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP16_TFLOPS, "traffic": None,
-                         "kernel": "conv_mfma_kernel<128,2,2,false> (NHWC fp16 implicit-GEMM conv, all launches with "
+                         "kernel": "conv_halo_kernel (NHWC fp16 implicit-GEMM conv on MFMA 32x32x16, all launches with "
                                    "Cout >= 128 of the flow-update operator)",
                          "avg_launch_ms": gate_ms, "flops_per_launch": flops_per_launch,
                          "launches_per_step": len(rec) // max(1, args.prof_steps)},

@@ -344,3 +344,40 @@ def test_conv_mfma_against_torch_fp32():
         ref = {"none": lambda t: t, "relu": torch.relu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}[act](ref)
         err = (y.float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
         assert err < 4e-3, (cin, cout, k, err)
+
+
+def test_conv_halo_tile_kernel_against_torch_fp32():
+    """Width-64 images take the halo-tile kernel (4 rows x 64 px x 128 couts per workgroup): same check as above,
+    including a two-source input (channel split) and ragged channel counts."""
+    import torch.nn.functional as F
+    from vipe_amd._lib import check, lib, ptr, stream_ptr
+    from vipe_amd.slam.update_engine import _Packed
+    torch.manual_seed(5)
+    for (B, H, cin, cout, k, act) in [(2, 8, 128, 128, 3, "relu"), (1, 4, 448, 256, 3, "none"), (3, 12, 200, 128, 1, "relu"),
+                                      (2, 8, 128, 384, 3, "tanh")]:
+        W = 64
+        x = (torch.randn(B, H, W, cin) * 0.5).half().to(dev())
+        w = (torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5).half()
+        b = torch.randn(cout) * 0.1
+        pk = _Packed(w, b, dev())
+        y = torch.full((B, H, W, cout), 7.0, dtype=torch.float16, device=dev())
+        check(lib().vipe_conv2d_nhwc_f16(ptr(x), ptr(pk.packed), ptr(pk.bias), None, ptr(y), B, H, W, cin, cin, 0, cout,
+                                         cout, 0, k, k, {"none": 0, "relu": 1, "sigmoid": 2, "tanh": 3}[act],
+                                         stream_ptr(x)), "conv")
+        ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float(), b, padding=k // 2)
+        ref = {"none": lambda t: t, "relu": torch.relu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}[act](ref)
+        err = (y.float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
+        assert err < 4e-3, (cin, cout, k, err)
+    # two-source input: channels [0,128) from one tensor, [128,448) from another (the GRU gate input)
+    from vipe_amd.slam.update_engine import UpdateEngine  # noqa: F401
+    B, H, W = 2, 8, 64
+    xa = (torch.randn(B, H, W, 128) * 0.5).half().to(dev())
+    xb = (torch.randn(B, H, W, 320) * 0.5).half().to(dev())
+    w = (torch.randn(128, 448, 3, 3) / (448 * 9) ** 0.5).half()
+    pk = _Packed(w, torch.zeros(128), dev())
+    y = torch.empty((B, H, W, 128), dtype=torch.float16, device=dev())
+    check(lib().vipe_conv2d_fused(ptr(xa), 128, 0, ptr(xb), 320, 0, 128, ptr(pk.packed), ptr(pk.bias), None, 0, 0, ptr(y),
+                                  128, 0, None, 0, 0, None, 0, 0, None, None, B, H, W, 448, 128, 3, 3, 0, 0, stream_ptr(xa)),
+          "conv_fused")
+    ref = F.conv2d(torch.cat([xa, xb], -1).float().cpu().permute(0, 3, 1, 2), w.float(), None, padding=1)
+    assert (y.float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < 4e-3

@@ -18,6 +18,8 @@
 //                     rhs carried as an extra matrix row (forward substitution for free), blocked backward
 //                     substitution, pose / intrinsics retraction.
 //   ba_retract_kernel per pixel dz = (w - sum_a E_ak^T dx_a)/C, d += dz (dz > 10 rejected).
+#include <stdlib.h>
+
 #include "term_geom.cuh"
 
 namespace {
@@ -81,7 +83,7 @@ size_t carve(const vipe_ba_params& p, char* base, BAWs* out) {
   w.Ef = (float*)take(4 * nF * 2 * P);
   w.Ej = (float*)take(4 * (M + 1) * 6 * P);
   w.S = (double*)take(8 * (nmax + 1) * (nmax + 1));
-  w.Hd = (double*)take(8 * nmax);
+  w.Hd = (double*)take(8 * (nmax + 16));  // + 16 debug stamp slots
   w.dx = (float*)take(4 * nmax);
   w.ld = (int)(nmax + 1);
   if (out) *out = w;
@@ -574,14 +576,25 @@ __global__ __launch_bounds__(TILE) void ba_accum_kernel(BAArgs a) {
 //        32-byte row segments.
 //   Then blocked backward substitution L^T x = y and the pose / intrinsics retraction.
 constexpr int NB = 24;
+constexpr int SOLVE_T = 512;  // 8 waves: up to 256 VGPRs per lane, no spills in the register-resident phases
 
 struct SolveLds {
   double Lkk[NB][NB + 1];
+  double rdiag[NB];  // 1 / L[j][j]
   double xk[NB];
   int fail;
 };
 
-__global__ __launch_bounds__(1024) void ba_solve_kernel(BAArgs a, int panel_cap) {
+// 1/sqrt(x) in fp64: hardware estimate + 2 Newton steps (avoids the long sqrt / divide sequences on the
+// factorisation's critical path)
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * (1.5 - 0.5 * x * r * r);
+  r = r * (1.5 - 0.5 * x * r * r);
+  return r;
+}
+
+__global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_cap, long long* dbg) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   SolveLds& sh = *reinterpret_cast<SolveLds*>(smem_raw);
   double* PT = reinterpret_cast<double*>(smem_raw + ((sizeof(SolveLds) + 15) / 16) * 16);  // [NB][panel_cap]
@@ -591,10 +604,13 @@ __global__ __launch_bounds__(1024) void ba_solve_kernel(BAArgs a, int panel_cap)
   const int n = w.info[3], n_free = w.info[0];
   const int ld = w.ld;
   double* S = w.S;
+  long long tprev = dbg ? wall_clock64() : 0;
+  long long tacc[5] = {0, 0, 0, 0, 0};
+#define STAMP(i) if (dbg && t == 0) { long long tn = wall_clock64(); tacc[i] += tn - tprev; tprev = tn; }
   if (t == 0) sh.fail = 0;
   if (n == 0) return;
   // LM damping on the diagonal: += ep + lambda * diag(H)  (matrix.py:179-186)
-  for (int dd = t; dd < n; dd += 1024) {
+  for (int dd = t; dd < n; dd += SOLVE_T) {
     const bool pose = dd < 6 * n_free;
     const double ep = pose ? (double)prm.pose_ep : 1e-6, lam = pose ? (double)prm.pose_damping : 1e-6;
     S[(int64_t)dd * ld + dd] += ep + lam * w.Hd[dd];
@@ -628,10 +644,11 @@ __global__ __launch_bounds__(1024) void ba_solve_kernel(BAArgs a, int panel_cap)
             if (r == 0) sh.fail = 1;
             piv = 1.0;
           }
-          const double l = sqrt(piv);
+          const double rl = rsqrt_nr(piv);
           if (r >= j && r < bw) {
-            row[j] = (r == j) ? l : sacc / l;
+            row[j] = (r == j) ? piv * rl : sacc * rl;
             sh.Lkk[r][j] = row[j];
+            if (r == j) sh.rdiag[j] = rl;
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           __builtin_amdgcn_wave_barrier();
@@ -645,10 +662,11 @@ __global__ __launch_bounds__(1024) void ba_solve_kernel(BAArgs a, int panel_cap)
       }
     }
     __syncthreads();
+    STAMP(0)
     // ---- 2. panel rows r0..n (row n = rhs)
     const int r0 = k0 + bw;
     const int m = n - r0 + 1;
-    for (int pr = t; pr < m; pr += 1024) {
+    for (int pr = t; pr < m; pr += SOLVE_T) {
       double x[NB];
       double* grow = S + (int64_t)(r0 + pr) * ld + k0;
 #pragma unroll
@@ -660,22 +678,48 @@ __global__ __launch_bounds__(1024) void ba_solve_kernel(BAArgs a, int panel_cap)
 #pragma unroll
           for (int q = 0; q < NB; ++q)
             if (q < j) sacc -= x[q] * sh.Lkk[j][q];
-          x[j] = sacc / sh.Lkk[j][j];
+          x[j] = sacc * sh.rdiag[j];
         }
       }
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
-        if (j < bw) {
-          grow[j] = x[j];
-          if (use_lds_panel) PT[j * panel_cap + pr] = x[j];
-        }
+        if (j < bw) grow[j] = x[j];
+        if (use_lds_panel) PT[j * panel_cap + pr] = j < bw ? x[j] : 0.0;
       }
     }
     __syncthreads();
-    // ---- 3. trailing update: rows rr in [0,m), cols cc <= rr, cc < m-1 (the rhs row has no column)
-    {
+    STAMP(1)
+    // ---- 3. trailing update A22 -= P P^T on the fp64 matrix cores (v_mfma_f64_16x16x4_f64): 16x16 tiles of the
+    //         lower triangle, one tile per wave at a time, K = 24 = 6 MFMAs; operands straight from the
+    //         transposed panel in LDS (lane l: A[row l&15][k l>>4], B[k l>>4][col l&15]).
+    if (use_lds_panel) {
+      typedef double double4v __attribute__((ext_vector_type(4)));
+      const int wv = t >> 6, ln = t & 63;
+      const int nt = (m + 15) >> 4;
+      const int ntiles = nt * (nt + 1) / 2;
+      for (int q = wv; q < ntiles; q += SOLVE_T / 64) {
+        int ti = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
+        while ((ti + 1) * (ti + 2) / 2 <= q) ++ti;
+        while (ti * (ti + 1) / 2 > q) --ti;
+        const int tj = q - ti * (ti + 1) / 2;
+        double4v c = {0.0, 0.0, 0.0, 0.0};
+        const int ar = 16 * ti + (ln & 15), bc = 16 * tj + (ln & 15), kq = ln >> 4;
+#pragma unroll
+        for (int s4 = 0; s4 < NB / 4; ++s4) {
+          const double av = PT[(4 * s4 + kq) * panel_cap + ar];
+          const double bv = PT[(4 * s4 + kq) * panel_cap + bc];
+          c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
+        }
+        const int cc = 16 * tj + (ln & 15);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int rr = 16 * ti + (ln >> 4) + 4 * r4;
+          if (rr < m && cc <= rr && cc <= m - 2) S[(int64_t)(r0 + rr) * ld + r0 + cc] -= c[r4];
+        }
+      }
+    } else {
       const int tx = t & 31, ty = t >> 5;  // 32 x 32 threads, each a 1 x 4 tile
-      for (int rr = ty; rr < m; rr += 32) {
+      for (int rr = ty; rr < m; rr += SOLVE_T / 32) {
         const int cmax = min(rr, m - 2);  // inclusive
         for (int c4 = tx * 4; c4 <= cmax; c4 += 128) {
           double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
@@ -705,53 +749,89 @@ __global__ __launch_bounds__(1024) void ba_solve_kernel(BAArgs a, int panel_cap)
       }
     }
     __syncthreads();
+    STAMP(2)
   }
 
-  // ---- backward substitution L^T x = y (y = row n), blocks from the last to the first
+  // ---- backward substitution L^T x = y (y = row n).
+  // (i) invert every diagonal block Lkk (lower triangular) in parallel, one wave per block, lane c = column c of
+  //     the inverse by forward substitution; the inverse overwrites the STRICT UPPER part + a side array is not
+  //     needed: it is written to the (unused) upper triangle of S at the block's position, transposed, i.e.
+  //     S[k0+c][k0+j] (j > c) := Linv[j][c], and the inverse's diagonal to Hd (no longer needed).
+  {
+    const int nblk = (n + NB - 1) / NB;
+    const int wv = t >> 6, ln = t & 63;
+    for (int blk = wv; blk < nblk; blk += SOLVE_T / 64) {
+      const int k0 = blk * NB, bw = min(NB, n - k0);
+      if (ln < bw) {
+        const int c = ln;
+        double z[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          if (j < bw && j >= c) {
+            double sacc = (j == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+              if (q < j) sacc -= S[(int64_t)(k0 + j) * ld + k0 + q] * z[q];  // z[q] == 0 for q < c
+            z[j] = sacc / S[(int64_t)(k0 + j) * ld + k0 + j];
+          } else {
+            z[j] = 0.0;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          if (j < bw && j > c) S[(int64_t)(k0 + c) * ld + k0 + j] = z[j];  // upper triangle: Linv[j][c]
+          if (j == c) w.Hd[k0 + c] = z[j];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  STAMP(3)
+  // (ii) blocks from the last to the first: x_k = Lkk^-T y_k (a 24x24 mat-vec, lane j: sum_m Linv[m][j] y[m]),
+  //      then y_c -= sum_m L[k0+m][c] x_k[m] for every earlier column c (coalesced row reads).
   double* yrow = S + (int64_t)n * ld;
   for (int k0 = ((n - 1) / NB) * NB; k0 >= 0; k0 -= NB) {
     const int bw = min(NB, n - k0);
     if (t < WAVE) {
-      // stage the diagonal block in LDS (one coalesced pass), then lane j owns x[j]
-      for (int idx = t; idx < bw * bw; idx += WAVE) {
-        const int rr = idx / bw, cc = idx % bw;
-        if (cc <= rr) sh.Lkk[rr][cc] = S[(int64_t)(k0 + rr) * ld + k0 + cc];
-      }
-      const double yj = t < bw ? yrow[k0 + t] : 0.0;
+      if (t < bw) sh.xk[t] = yrow[k0 + t];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       double xj = 0.0;
-      for (int j = bw - 1; j >= 0; --j) {
-        // s = y[j] - sum_{m>j} L[k0+m][k0+j] * x[m]
-        double part = 0.0;
-        if (t > j && t < bw) part = sh.Lkk[t][j] * xj;
-        part = wave_sum(part);
-        if (t == j) xj = (yj - part) / sh.Lkk[j][j];
+      if (t < bw) {
+        // Linv[m][j] for m > j is stored at S[k0+j][k0+m]; Linv[j][j] in Hd
+        xj = w.Hd[k0 + t] * sh.xk[t];
+        for (int mq = t + 1; mq < bw; ++mq) xj += S[(int64_t)(k0 + t) * ld + k0 + mq] * sh.xk[mq];
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
       if (t < bw) {
         sh.xk[t] = xj;
         yrow[k0 + t] = xj;
       }
     }
     __syncthreads();
-    for (int c = t; c < k0; c += 1024) {
+    for (int c = t; c < k0; c += SOLVE_T) {
       double sacc = 0.0;
       for (int q = 0; q < bw; ++q) sacc += S[(int64_t)(k0 + q) * ld + c] * sh.xk[q];
       yrow[c] -= sacc;
     }
     __syncthreads();
   }
+  STAMP(4)
+  if (dbg && t == 0)
+    printf("[ba_solve n=%d] diag %lld panel %lld trailing %lld invert %lld backsub %lld (x10ns)\n", n, tacc[0], tacc[1],
+           tacc[2], tacc[3], tacc[4]);
   const bool bad = sh.fail != 0;
   if (t == 0 && bad) w.info[2] += 1;
-  for (int dd = t; dd < n; dd += 1024) {
+  for (int dd = t; dd < n; dd += SOLVE_T) {
     double x = yrow[dd];
     if (bad || !(x == x)) x = 0.0;  // zero step on a failed factorisation
     w.dx[dd] = (float)x;
   }
   __syncthreads();
   // retraction: poses X <- Exp(dx) X (retractor.py:27-29), intrinsics (retractor.py:50-62)
-  for (int sl = t; sl < n_free; sl += 1024) {
+  for (int sl = t; sl < n_free; sl += SOLVE_T) {
     const int pidx = w.slot_pose[sl];
     float xi[6];
     for (int q = 0; q < 6; ++q) xi[q] = w.dx[6 * sl + q];
@@ -830,7 +910,7 @@ int run_iters(const BAArgs& a, hipStream_t s) {
     hipError_t e2 = hipMemsetAsync(a.w.Hd, 0, sizeof(double) * nmax, s);
     if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
     ba_accum_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
-    ba_solve_kernel<<<1, 1024, solve_lds, s>>>(a, panel_cap);
+    ba_solve_kernel<<<1, SOLVE_T, solve_lds, s>>>(a, panel_cap, getenv("VIPE_BA_DEBUG_TIMING") ? (long long*)(a.w.Hd + nmax) : nullptr);
     if (!a.p.motion_only) ba_retract_kernel<F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
   }
   return vipe_launch_status();
