@@ -236,6 +236,11 @@ int vipe_scatter(const void* d_src, const int64_t* d_index, void* d_out, int64_t
 int vipe_scatter_mean_rows_f16(const void* d_src, const int64_t* d_ix, void* d_out, int E, int n_out, int64_t inner,
                                void* stream);
 
+/* [fused] deterministic segmented mean (no atomics): out[k] = mean over q in [rowptr[k], rowptr[k+1]) of
+ * src[order[q], :, coff:coff+C]; src [E, rows_per_item, src_ctot] f16, out [n_out, rows_per_item, C] f16. */
+int vipe_segment_mean_nhwc_f16(const void* d_src, int src_ctot, int src_coff, const int* d_order, const int* d_rowptr,
+                               void* d_out, int n_out, int64_t rows_per_item, int C, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * corr_ext  (csrc/corr_ext/correlation_sampler.cpp:82-85, correlation_cuda_kernel.cu:216-330)
  * in1,in2 [B,C,H,W]; out [B,patchH,patchW,oH,oW]; dtype f16/f32.

@@ -381,3 +381,130 @@ def test_conv_halo_tile_kernel_against_torch_fp32():
           "conv_fused")
     ref = F.conv2d(torch.cat([xa, xb], -1).float().cpu().permute(0, 3, 1, 2), w.float(), None, padding=1)
     assert (y.float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < 4e-3
+
+
+# ------------------------------------------------------------------------------------------------ slam_ext geometry kernels
+
+
+def test_frame_distance_depth_filter_projmap_iproj():
+    from oracle import frame_ops
+    from vipe_amd.ext import slam_ext
+    g = make_graph(n=8, height=96, width=128, radius=2, seed=9)
+    intr8 = (g.intrinsics / 8.0).astype(np.float32)
+    ii = np.array([0, 1, 2, 5, 7, 3], dtype=np.int64)
+    jj = np.array([1, 0, 6, 2, 4, 3], dtype=np.int64)
+    z = np.zeros_like(ii)
+    d = slam_ext.frame_distance(T(g.poses), T(g.disps), T(intr8), T(ii), T(jj), T(z), T(z), T(ii), 0.3)
+    ref = frame_ops.frame_distance(g.poses, g.disps, intr8, ii, jj, z, z, ii, 0.3)
+    assert np.abs(d.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
+    assert abs(float(d[5])) < 1e-5  # identical frames: zero induced flow
+    # < 75 % valid -> 1000 (geom_kernels.cu:674): put the target camera far behind the source
+    far = g.poses.copy()
+    far[1, 2] = -100.0
+    d2 = slam_ext.frame_distance(T(far), T(g.disps), T(intr8), T(ii[:1]), T(jj[:1]), T(z[:1]), T(z[:1]), T(ii[:1]), 0.3)
+    assert float(d2[0]) == 1000.0
+    # depth filter: integer counts, bit-exact
+    inds = np.arange(8, dtype=np.int64)
+    thresh = np.full(8, 0.05 / g.disps.mean(), dtype=np.float32)
+    cnt = slam_ext.depth_filter(T(g.poses), T(g.disps), T(intr8[0]), T(inds), T(thresh))
+    ref = frame_ops.depth_filter(g.poses, g.disps, intr8[0], inds, thresh)
+    assert np.mean(cnt.cpu().numpy() == ref) > 0.999  # counts near a threshold can flip with fp32 rounding
+    assert cnt.max() <= 6
+    coords, valid = slam_ext.projmap(T(g.poses), T(g.disps), T(intr8[0]), T(ii), T(jj))
+    rc, rv = frame_ops.projmap(g.poses, g.disps, intr8[0], ii, jj)
+    assert np.abs(coords.cpu().numpy() - rc).max() < 2e-3 and np.array_equal(valid.cpu().numpy(), rv)
+    pts = slam_ext.iproj(T(g.poses), T(g.disps), T(intr8[0]))
+    assert np.abs(pts.cpu().numpy() - frame_ops.iproj(g.poses, g.disps, intr8[0])).max() < 1e-3
+
+
+def test_frame_distance_through_buffer_api():
+    """GraphBuffer.frame_distance_dense_disp (buffer.py:550-593) against the independent oracle reprojection."""
+    from vipe_amd.slam.buffer import GraphBuffer
+    g = make_graph(n=6, height=96, width=128, radius=2, seed=10)
+    buf = GraphBuffer(96, 128, buffer_size=8, device=dev())
+    buf.n_frames = 6
+    buf.poses[:6] = T(g.poses)
+    buf.disps[:6, 0] = T(g.disps)
+    buf.intrinsics[:] = T(g.intrinsics)
+    ii, jj = T(np.array([0, 2, 5])), T(np.array([1, 4, 3]))
+    d = buf.frame_distance_dense_disp(ii, jj, beta=0.3, bidirectional=False).cpu().numpy()[:, 0]
+    z = np.zeros(3, np.int64)
+    o = ogeom.reproject(g.poses, g.disps, (g.intrinsics / 8).astype(np.float32), ose3.se3_identity(1),
+                        np.array([0, 2, 5]), np.array([1, 4, 3]), z, z, np.array([0, 2, 5]))
+    u, v = ogeom.pixel_grid(g.ht, g.wd, np.float32)
+    full = np.sqrt((o["coords"][..., 0] - u) ** 2 + (o["coords"][..., 1] - v) ** 2).mean((1, 2))
+    assert np.all(d > 0.3 * full * 0.99)  # beta-weighted full-motion part is a lower bound
+
+
+# ------------------------------------------------------------------------------------------------ altcorr / scatter / corr_ext
+
+
+def test_altcorr_forward_matches_oracle_and_volume_lookup():
+    from vipe_amd.ext import droid_net_ext
+    rng = np.random.default_rng(11)
+    B, H, W, C = 3, 8, 16, 128
+    f1 = rng.normal(0, 1, (B, H, W, C)).astype(np.float32)
+    f2 = rng.normal(0, 1, (B, H // 2, W // 2, C)).astype(np.float32)
+    coords = np.stack([rng.uniform(-2, W // 2 + 1, (B, 2, H, W)), rng.uniform(-2, H // 2 + 1, (B, 2, H, W))], -1).astype(np.float32)
+    (out,) = droid_net_ext.altcorr_forward(T(f1), T(f2), T(coords), 3)
+    ref = ocorr.altcorr_forward(f1, f2, coords, 3)
+    assert out.shape == (B, 2, 49, H, W)
+    assert np.abs(out.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+def test_altcorr_block_matches_corr_block():
+    """AltCorrBlock (volume-free) == CorrBlock (volume) on the same features, up to fp16 volume rounding."""
+    from vipe_amd.slam.networks import AltCorrBlock, CorrBlock
+    rng = np.random.default_rng(12)
+    N, h, w = 3, 16, 16
+    fm = torch.from_numpy(rng.normal(0, 1, (1, N, 128, h, w)).astype(np.float16)).to(dev())
+    ii, jj = torch.tensor([0, 1, 2], device=dev()), torch.tensor([1, 2, 0], device=dev())
+    coords = torch.from_numpy(np.stack([rng.uniform(0, w - 1, (1, 3, h, w)), rng.uniform(0, h - 1, (1, 3, h, w))], -1)
+                              .astype(np.float32)).to(dev())
+    a = AltCorrBlock(fm)(coords, ii, jj)
+    c = CorrBlock(fm[:, ii], fm[:, jj])(coords)
+    assert a.shape == c.shape == (1, 3, 196, h, w)
+    assert (a.float() - c.float()).abs().max().item() < 0.05
+
+
+def test_scatter_ext_against_torch():
+    from vipe_amd.ext import scatter
+    rng = np.random.default_rng(13)
+    src = torch.from_numpy(rng.normal(0, 1, (4, 50, 6)).astype(np.float32)).to(dev())
+    idx = torch.from_numpy(rng.integers(0, 9, 50)).to(dev())
+    full = idx.view(1, -1, 1).expand_as(src)
+    mx, arg = scatter.scatter_max(src, idx, dim=1, dim_size=10)
+    ref = torch.full((4, 10, 6), float("-inf"), device=dev()).scatter_reduce(1, full, src, "amax")
+    assert torch.equal(mx[:, :9], ref[:, :9]) and torch.all(mx[:, 9] == 0)
+    assert torch.equal(torch.gather(src, 1, arg[:, :9].clamp(max=49)), mx[:, :9])
+    mn, _ = scatter.scatter_min(src, idx, dim=1, dim_size=10)
+    assert torch.equal(mn[:, :9], torch.full((4, 10, 6), float("inf"), device=dev()).scatter_reduce(1, full, src, "amin")[:, :9])
+    ml = scatter.scatter_mul(src, idx, dim=1, dim_size=10)
+    refm = torch.ones((4, 10, 6), device=dev()).scatter_reduce(1, full, src, "prod")
+    assert torch.allclose(ml, refm, rtol=1e-4, atol=1e-6)
+    sm = scatter.scatter_mean(src, idx, dim=1, dim_size=10)
+    refs = torch.zeros((4, 10, 6), device=dev()).scatter_reduce(1, full, src, "mean", include_self=False)
+    assert torch.allclose(sm, refs, atol=1e-5)
+
+
+def test_corr_ext_sampler_against_torch_loops():
+    from vipe_amd.ext import corr_ext
+    torch.manual_seed(14)
+    B, C, H, W = 2, 5, 7, 9
+    a = torch.randn(B, C, H, W, device=dev())
+    b = torch.randn(B, C, H, W, device=dev())
+    kH = kW = 1
+    patch = 5
+    out = corr_ext.forward(a, b, kH, kW, patch, patch, 0, 0, 1, 1, 1, 1, 1, 1)
+    assert out.shape == (B, patch, patch, H, W)
+    bp = torch.nn.functional.pad(b, (2, 2, 2, 2))
+    ref = torch.stack([torch.stack([(a * bp[:, :, ph:ph + H, pw:pw + W]).sum(1) for pw in range(patch)], 1) for ph in range(patch)], 1)
+    assert torch.allclose(out, ref, atol=1e-5)
+    g = torch.randn_like(out)
+    g1, g2 = corr_ext.backward(a, b, g, kH, kW, patch, patch, 0, 0, 1, 1, 1, 1, 1, 1)
+    a_ = a.clone().requires_grad_(True)
+    b_ = b.clone().requires_grad_(True)
+    bp = torch.nn.functional.pad(b_, (2, 2, 2, 2))
+    ref = torch.stack([torch.stack([(a_ * bp[:, :, ph:ph + H, pw:pw + W]).sum(1) for pw in range(patch)], 1) for ph in range(patch)], 1)
+    (ref * g).sum().backward()
+    assert torch.allclose(g1, a_.grad, atol=1e-4) and torch.allclose(g2, b_.grad, atol=1e-4)

@@ -1,0 +1,323 @@
+// API-completeness kernels off the per-iteration hot loop:
+//   altcorr_forward  (droid_net_ext; backend's volume-free correlation, altcorr_kernel.cu:26-138)
+//   scatter          (scatter_ext; atomic scatter sum/mul/min/max + arg pass, scatter_cuda.cu:20-55)
+//   corr sampler     (corr_ext; FlowNet-style local correlation, correlation_cuda_kernel.cu:27-214)
+//   segment mean     ([fused] GraphAgg's scatter_mean over the edges of each source node, droid_net.py:420-421)
+#include "common.cuh"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ altcorr
+// one lane per (b, n, pixel); channels in slabs of 32 (fmap1 slab in registers), each slab's partial dot product
+// is splatted on its own, exactly as the reference kernel orders the additions (altcorr_kernel.cu:50,95-133).
+template <typename T, int R>
+__global__ __launch_bounds__(128) void altcorr_forward_kernel(const T* __restrict__ f1, const T* __restrict__ f2,
+                                                              const float* __restrict__ coords, T* __restrict__ corr,
+                                                              int H1, int W1, int H2, int W2, int N, int C) {
+  constexpr int RD = 2 * R + 1;
+  const int P = H1 * W1;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = blockIdx.y, b = blockIdx.z;
+  if (p >= P) return;
+  const float2 c = reinterpret_cast<const float2*>(coords)[((int64_t)b * N + n) * P + p];
+  const float fx = floorf(c.x), fy = floorf(c.y);
+  const float dx = c.x - fx, dy = c.y - fy;
+  const int bx = (int)fx - R, by = (int)fy - R;
+  float acc[RD * RD];
+#pragma unroll
+  for (int q = 0; q < RD * RD; ++q) acc[q] = 0.0f;
+  const T* a = f1 + ((int64_t)b * P + p) * C;
+  for (int c0 = 0; c0 < C; c0 += 32) {
+    float av[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) av[k] = (c0 + k < C) ? (float)a[c0 + k] : 0.0f;
+#pragma unroll
+    for (int iy = 0; iy <= RD; ++iy) {
+#pragma unroll
+      for (int ix = 0; ix <= RD; ++ix) {
+        const int h2 = by + iy, w2 = bx + ix;
+        float s = 0.0f;
+        if (h2 >= 0 && h2 < H2 && w2 >= 0 && w2 < W2) {
+          const T* g = f2 + (((int64_t)b * H2 + h2) * W2 + w2) * C + c0;
+#pragma unroll
+          for (int k = 0; k < 32; ++k) s += av[k] * ((c0 + k < C) ? (float)g[k] : 0.0f);
+        }
+        if (iy > 0 && ix > 0) acc[(iy - 1) + RD * (ix - 1)] += s * (dy * dx);
+        if (iy > 0 && ix < RD) acc[(iy - 1) + RD * ix] += s * (dy * (1 - dx));
+        if (iy < RD && ix > 0) acc[iy + RD * (ix - 1)] += s * ((1 - dy) * dx);
+        if (iy < RD && ix < RD) acc[iy + RD * ix] += s * ((1 - dy) * (1 - dx));
+      }
+    }
+  }
+  T* o = corr + (((int64_t)b * N + n) * RD * RD) * P + p;
+#pragma unroll
+  for (int q = 0; q < RD * RD; ++q) o[(int64_t)q * P] = (T)acc[q];
+}
+
+// ------------------------------------------------------------------------------------------------ scatter
+template <typename T>
+__device__ __forceinline__ void atomic_combine(T* addr, T v, int reduce);
+
+template <>
+__device__ __forceinline__ void atomic_combine<float>(float* addr, float v, int reduce) {
+  if (reduce == 0 || reduce == 2) { atomicAdd(addr, v); return; }
+  unsigned* ua = reinterpret_cast<unsigned*>(addr);
+  unsigned old = *ua, assumed;
+  do {
+    assumed = old;
+    const float cur = __uint_as_float(assumed);
+    const float nv = reduce == 1 ? cur * v : (reduce == 3 ? fminf(cur, v) : fmaxf(cur, v));
+    old = atomicCAS(ua, assumed, __float_as_uint(nv));
+  } while (old != assumed);
+}
+template <>
+__device__ __forceinline__ void atomic_combine<double>(double* addr, double v, int reduce) {
+  if (reduce == 0 || reduce == 2) { atomicAdd(addr, v); return; }
+  unsigned long long* ua = reinterpret_cast<unsigned long long*>(addr);
+  unsigned long long old = *ua, assumed;
+  do {
+    assumed = old;
+    const double cur = __longlong_as_double(assumed);
+    const double nv = reduce == 1 ? cur * v : (reduce == 3 ? fmin(cur, v) : fmax(cur, v));
+    old = atomicCAS(ua, assumed, (unsigned long long)__double_as_longlong(nv));
+  } while (old != assumed);
+}
+template <>
+__device__ __forceinline__ void atomic_combine<half_t>(half_t* addr, half_t v, int reduce) {
+  // CAS on the enclosing aligned 32-bit word (atomics.cuh:148-300 of the reference does the same)
+  const uintptr_t ad = reinterpret_cast<uintptr_t>(addr);
+  unsigned* ua = reinterpret_cast<unsigned*>(ad & ~(uintptr_t)3);
+  const bool hi = ad & 2;
+  unsigned old = *ua, assumed;
+  do {
+    assumed = old;
+    unsigned short bits = hi ? (unsigned short)(assumed >> 16) : (unsigned short)(assumed & 0xffffu);
+    half_t cur;
+    __builtin_memcpy(&cur, &bits, 2);
+    const float cf = (float)cur, vf = (float)v;
+    const half_t nv = (half_t)(reduce == 0 || reduce == 2 ? cf + vf : reduce == 1 ? cf * vf : reduce == 3 ? fminf(cf, vf) : fmaxf(cf, vf));
+    unsigned short nb;
+    __builtin_memcpy(&nb, &nv, 2);
+    const unsigned nw = hi ? ((assumed & 0xffffu) | ((unsigned)nb << 16)) : ((assumed & 0xffff0000u) | nb);
+    old = atomicCAS(ua, assumed, nw);
+  } while (old != assumed);
+}
+
+template <typename T>
+__global__ void scatter_kernel(const T* __restrict__ src, const int64_t* __restrict__ index, T* __restrict__ out,
+                               int64_t E, int64_t K, int64_t N, int64_t numel, int reduce) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / (E * K), k = i % K;
+    const int64_t idx = index[i];
+    atomic_combine<T>(out + b * N * K + idx * K + k, src[i], reduce);
+  }
+}
+template <typename T>
+__global__ void scatter_arg_kernel(const T* __restrict__ src, const int64_t* __restrict__ index, const T* __restrict__ out,
+                                   int64_t* __restrict__ arg, int64_t E, int64_t K, int64_t N, int64_t numel) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / (E * K), e = (i / K) % E, k = i % K;
+    const int64_t o = b * N * K + index[i] * K + k;
+    if (src[i] == out[o]) arg[o] = e;  // scatter_cuda.cu:50-52 (ties: last writer wins)
+  }
+}
+
+template <typename T>
+int run_scatter(const void* src, const int64_t* index, void* out, int64_t* arg, int64_t outer, int64_t E, int64_t K,
+                int64_t N, int reduce, hipStream_t s) {
+  const int64_t numel = outer * E * K;
+  if (numel == 0) return VIPE_OK;
+  const int blocks = (int)std::min<int64_t>((numel + 255) / 256, 8192);
+  scatter_kernel<T><<<blocks, 256, 0, s>>>((const T*)src, index, (T*)out, E, K, N, numel, reduce);
+  if (reduce >= 3) {
+    if (!arg) return VIPE_EINVAL;
+    scatter_arg_kernel<T><<<blocks, 256, 0, s>>>((const T*)src, index, (const T*)out, arg, E, K, N, numel);
+  }
+  return vipe_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ segment mean
+// out[k, :] = mean over edges e with ix[e] == k of src[e, coff:coff+C]; deterministic (fixed edge order per k).
+__global__ __launch_bounds__(256) void segment_mean_kernel(const half_t* __restrict__ src, int src_ctot, int src_coff,
+                                                           const int* __restrict__ order, const int* __restrict__ rowptr,
+                                                           half_t* __restrict__ out, int64_t rows_per_item /*h*w*/, int C) {
+  typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+  const int k = blockIdx.y;
+  const int beg = rowptr[k], end = rowptr[k + 1];
+  const int c8 = C / 8;
+  const int64_t n8 = rows_per_item * c8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / c8;
+    const int ch = (int)(i % c8) * 8;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = beg; q < end; ++q) {
+      const int e = order[q];
+      const half8 v = *reinterpret_cast<const half8*>(src + ((int64_t)e * rows_per_item + row) * src_ctot + src_coff + ch);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+    }
+    const float inv = 1.0f / (float)max(end - beg, 1);
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)(acc[j] * inv);
+    *reinterpret_cast<half8*>(out + ((int64_t)k * rows_per_item + row) * C + ch) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ corr sampler
+// NCHW inputs, one lane per output element (n, ph, pw, h, w)
+template <typename T>
+__global__ void corr_sampler_forward_kernel(const T* __restrict__ in1, const T* __restrict__ in2, T* __restrict__ out,
+                                            int B, int C, int H, int W, int oH, int oW, int kH, int kW, int patchH,
+                                            int patchW, int padH, int padW, int dilH, int dilW, int dpH, int dpW, int dH,
+                                            int dW) {
+  const int64_t total = (int64_t)B * patchH * patchW * oH * oW;
+  const int radH = dpH * (patchH - 1) / 2, radW = dpW * (patchW - 1) / 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int w = (int)(i % oW), h = (int)((i / oW) % oH);
+    const int pw = (int)((i / ((int64_t)oW * oH)) % patchW), ph = (int)((i / ((int64_t)oW * oH * patchW)) % patchH);
+    const int n = (int)(i / ((int64_t)oW * oH * patchW * patchH));
+    const int si = -padH + h * dH, sj = -padW + w * dW;
+    const int phd = ph * dpH - radH, pwd = pw * dpW - radW;
+    float s = 0.0f;
+    for (int a = 0; a < kH; ++a) {
+      const int i1 = si + a * dilH, i2 = i1 + phd;
+      if (i1 < 0 || i1 >= H || i2 < 0 || i2 >= H) continue;
+      for (int bq = 0; bq < kW; ++bq) {
+        const int j1 = sj + bq * dilW, j2 = j1 + pwd;
+        if (j1 < 0 || j1 >= W || j2 < 0 || j2 >= W) continue;
+        for (int c = 0; c < C; ++c)
+          s += (float)in1[(((int64_t)n * C + c) * H + i1) * W + j1] * (float)in2[(((int64_t)n * C + c) * H + i2) * W + j2];
+      }
+    }
+    out[i] = (T)s;
+  }
+}
+
+__global__ void corr_sampler_backward_kernel(const float* __restrict__ in1, const float* __restrict__ in2,
+                                             const float* __restrict__ gout, float* __restrict__ g1,
+                                             float* __restrict__ g2, int B, int C, int H, int W, int oH, int oW, int kH,
+                                             int kW, int patchH, int patchW, int padH, int padW, int dilH, int dilW,
+                                             int dpH, int dpW, int dH, int dW) {
+  const int64_t total = (int64_t)B * patchH * patchW * oH * oW;
+  const int radH = dpH * (patchH - 1) / 2, radW = dpW * (patchW - 1) / 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int w = (int)(i % oW), h = (int)((i / oW) % oH);
+    const int pw = (int)((i / ((int64_t)oW * oH)) % patchW), ph = (int)((i / ((int64_t)oW * oH * patchW)) % patchH);
+    const int n = (int)(i / ((int64_t)oW * oH * patchW * patchH));
+    const int si = -padH + h * dH, sj = -padW + w * dW;
+    const int phd = ph * dpH - radH, pwd = pw * dpW - radW;
+    const float g = gout[i];
+    for (int a = 0; a < kH; ++a) {
+      const int i1 = si + a * dilH, i2 = i1 + phd;
+      if (i1 < 0 || i1 >= H || i2 < 0 || i2 >= H) continue;
+      for (int bq = 0; bq < kW; ++bq) {
+        const int j1 = sj + bq * dilW, j2 = j1 + pwd;
+        if (j1 < 0 || j1 >= W || j2 < 0 || j2 >= W) continue;
+        for (int c = 0; c < C; ++c) {
+          const int64_t o1 = (((int64_t)n * C + c) * H + i1) * W + j1, o2 = (((int64_t)n * C + c) * H + i2) * W + j2;
+          atomicAdd(g1 + o1, g * in2[o2]);
+          atomicAdd(g2 + o2, g * in1[o1]);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+VIPE_EXPORT int vipe_altcorr_forward(const void* d_fmap1, const void* d_fmap2, const float* d_coords, void* d_corr,
+                                     int B, int H1, int W1, int H2, int W2, int N, int C, int radius, int dtype,
+                                     void* stream) {
+  VIPE_CHECK_ARG(B >= 0 && N >= 0 && H1 > 0 && W1 > 0 && H2 > 0 && W2 > 0 && C > 0 && B <= 65535 && N <= 65535);
+  if (B == 0 || N == 0) return VIPE_OK;
+  VIPE_CHECK_ARG(d_fmap1 && d_fmap2 && d_coords && d_corr);
+  if (radius != 3) return VIPE_EUNSUPPORTED;
+  dim3 grid((H1 * W1 + 127) / 128, N, B);
+  hipStream_t s = as_stream(stream);
+  if (dtype == VIPE_F32)
+    altcorr_forward_kernel<float, 3><<<grid, 128, 0, s>>>((const float*)d_fmap1, (const float*)d_fmap2, d_coords,
+                                                          (float*)d_corr, H1, W1, H2, W2, N, C);
+  else if (dtype == VIPE_F16)
+    altcorr_forward_kernel<half_t, 3><<<grid, 128, 0, s>>>((const half_t*)d_fmap1, (const half_t*)d_fmap2, d_coords,
+                                                           (half_t*)d_corr, H1, W1, H2, W2, N, C);
+  else return VIPE_EINVAL;
+  return vipe_launch_status();
+}
+
+VIPE_EXPORT int vipe_altcorr_backward(const float*, const float*, const float*, const float*, float*, float*, int, int,
+                                      int, int, int, int, int, int, void*) {
+  return VIPE_EUNSUPPORTED;  // training only; the SLAM system runs under torch.no_grad (system.py:207)
+}
+
+VIPE_EXPORT int vipe_scatter(const void* d_src, const int64_t* d_index, void* d_out, int64_t* d_arg_out, int64_t outer,
+                             int64_t src_dim, int64_t inner, int64_t out_dim, int reduce, int dtype, void* stream) {
+  VIPE_CHECK_ARG(outer >= 0 && src_dim >= 0 && inner >= 0 && out_dim >= 0 && reduce >= 0 && reduce <= 4);
+  if (outer * src_dim * inner == 0) return VIPE_OK;
+  VIPE_CHECK_ARG(d_src && d_index && d_out);
+  hipStream_t s = as_stream(stream);
+  switch (dtype) {
+    case VIPE_F16: return run_scatter<half_t>(d_src, d_index, d_out, d_arg_out, outer, src_dim, inner, out_dim, reduce, s);
+    case VIPE_F32: return run_scatter<float>(d_src, d_index, d_out, d_arg_out, outer, src_dim, inner, out_dim, reduce, s);
+    case VIPE_F64: return run_scatter<double>(d_src, d_index, d_out, d_arg_out, outer, src_dim, inner, out_dim, reduce, s);
+  }
+  return VIPE_EINVAL;
+}
+
+VIPE_EXPORT int vipe_segment_mean_nhwc_f16(const void* d_src, int src_ctot, int src_coff, const int* d_order,
+                                           const int* d_rowptr, void* d_out, int n_out, int64_t rows_per_item, int C,
+                                           void* stream) {
+  VIPE_CHECK_ARG(n_out >= 0 && rows_per_item > 0 && C > 0 && C % 8 == 0 && src_ctot % 8 == 0 && src_coff % 8 == 0);
+  if (n_out == 0) return VIPE_OK;
+  VIPE_CHECK_ARG(d_src && d_order && d_rowptr && d_out && n_out <= 65535);
+  const int64_t n8 = rows_per_item * (C / 8);
+  dim3 grid((int)std::min<int64_t>((n8 + 255) / 256, 1024), n_out);
+  segment_mean_kernel<<<grid, 256, 0, as_stream(stream)>>>((const half_t*)d_src, src_ctot, src_coff, d_order, d_rowptr,
+                                                           (half_t*)d_out, rows_per_item, C);
+  return vipe_launch_status();
+}
+
+VIPE_EXPORT int vipe_scatter_mean_rows_f16(const void*, const int64_t*, void*, int, int, int64_t, void*) {
+  return VIPE_EUNSUPPORTED;  // superseded by vipe_segment_mean_nhwc_f16 (CSR built once per edge set)
+}
+
+VIPE_EXPORT int vipe_corr_sampler_forward(const void* d_in1, const void* d_in2, void* d_out, int B, int C, int H, int W,
+                                          int kH, int kW, int patchH, int patchW, int padH, int padW, int dilH, int dilW,
+                                          int dil_patchH, int dil_patchW, int dH, int dW, int dtype, void* stream) {
+  VIPE_CHECK_ARG(B >= 0 && C > 0 && H > 0 && W > 0 && kH > 0 && kW > 0 && patchH > 0 && patchW > 0 && dH > 0 && dW > 0);
+  const int oH = (H + 2 * padH - ((kH - 1) * dilH + 1)) / dH + 1, oW = (W + 2 * padW - ((kW - 1) * dilW + 1)) / dW + 1;
+  const int64_t total = (int64_t)B * patchH * patchW * oH * oW;
+  if (total <= 0) return VIPE_OK;
+  VIPE_CHECK_ARG(d_in1 && d_in2 && d_out);
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
+  hipStream_t s = as_stream(stream);
+  if (dtype == VIPE_F32)
+    corr_sampler_forward_kernel<float><<<blocks, 256, 0, s>>>((const float*)d_in1, (const float*)d_in2, (float*)d_out, B, C,
+                                                              H, W, oH, oW, kH, kW, patchH, patchW, padH, padW, dilH, dilW,
+                                                              dil_patchH, dil_patchW, dH, dW);
+  else if (dtype == VIPE_F16)
+    corr_sampler_forward_kernel<half_t><<<blocks, 256, 0, s>>>((const half_t*)d_in1, (const half_t*)d_in2, (half_t*)d_out,
+                                                               B, C, H, W, oH, oW, kH, kW, patchH, patchW, padH, padW, dilH,
+                                                               dilW, dil_patchH, dil_patchW, dH, dW);
+  else return VIPE_EINVAL;
+  return vipe_launch_status();
+}
+
+VIPE_EXPORT int vipe_corr_sampler_backward(const void* d_in1, const void* d_in2, const void* d_grad_out, void* d_grad1,
+                                           void* d_grad2, int B, int C, int H, int W, int kH, int kW, int patchH,
+                                           int patchW, int padH, int padW, int dilH, int dilW, int dil_patchH,
+                                           int dil_patchW, int dH, int dW, int dtype, void* stream) {
+  if (dtype != VIPE_F32) return VIPE_EUNSUPPORTED;
+  VIPE_CHECK_ARG(B >= 0 && C > 0 && H > 0 && W > 0);
+  const int oH = (H + 2 * padH - ((kH - 1) * dilH + 1)) / dH + 1, oW = (W + 2 * padW - ((kW - 1) * dilW + 1)) / dW + 1;
+  const int64_t total = (int64_t)B * patchH * patchW * oH * oW;
+  if (total <= 0) return VIPE_OK;
+  VIPE_CHECK_ARG(d_in1 && d_in2 && d_grad_out && d_grad1 && d_grad2);
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
+  corr_sampler_backward_kernel<<<blocks, 256, 0, as_stream(stream)>>>(
+      (const float*)d_in1, (const float*)d_in2, (const float*)d_grad_out, (float*)d_grad1, (float*)d_grad2, B, C, H, W, oH,
+      oW, kH, kW, patchH, patchW, padH, padW, dilH, dilW, dil_patchH, dil_patchW, dH, dW);
+  return vipe_launch_status();
+}

@@ -124,7 +124,9 @@ class FactorGraph:
         if self._plan is None:
             pi, qi, di, pj, qj, _ = self.buffer.expand_edge_multiview(self.ii, self.jj)
             du, dix = torch.unique(di, return_inverse=True)
+            from .update_engine import segment_csr
             self._plan = dict(pi=pi, qi=qi, di=di, pj=pj, qj=qj, du=du, dix=dix, n_src=int(du.numel()),
+                              csr=segment_csr(dix, int(du.numel())),
                               t0=int(max(1, self.ii.min().item() + 1)),
                               t1=int(max(self.ii.max().item(), self.jj.max().item()) + 1))
         return self._plan
@@ -147,7 +149,7 @@ class FactorGraph:
         eng = self.update_op.engine(self.device)
         if eng.backend == "hip":
             self.net_n, dw, eta, _ = eng.forward_nhwc(self.net_n, self.xbuf, corr, motn, ix=P["dix"], n_src=P["n_src"],
-                                                      net_out=self._net_spare())
+                                                      net_out=self._net_spare(), csr=P["csr"])
             delta, weight = dw[None, ..., 0:2], dw[None, ..., 2:4].clone()
         else:  # A/B baseline: reference-shaped NCHW call
             f_net, delta, weight, eta, _ = eng.forward(

@@ -49,6 +49,15 @@ class _Packed:
         self.flops_per_pixel = 2.0 * self.cout * self.cin * self.kh * self.kw
 
 
+def segment_csr(ix, n_src):
+    """(order, rowptr) int32 device tensors grouping the edges by source slot (stable)."""
+    order = torch.argsort(ix, stable=True).to(torch.int32).contiguous()
+    counts = torch.bincount(ix, minlength=n_src)
+    rowptr = torch.zeros(n_src + 1, dtype=torch.int32, device=ix.device)
+    rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return order, rowptr
+
+
 class UpdateEngine:
     def __init__(self, module, device, backend=None):
         self.device = device
@@ -117,7 +126,7 @@ class UpdateEngine:
         return t
 
     @torch.no_grad()
-    def forward_nhwc(self, net, xbuf, corr, motn, ix=None, n_src=None, net_out=None, want_upmask=False):
+    def forward_nhwc(self, net, xbuf, corr, motn, ix=None, n_src=None, net_out=None, want_upmask=False, csr=None):
         """The operator on channels-last state.
 
         net  [E,h,w,128] f16 hidden state;  xbuf [E,h,w,320] f16 with the context features `inp` in channels
@@ -155,12 +164,14 @@ class UpdateEngine:
         if ix is not None:
             if n_src is None:  # the reference syncs here too (scatter.py:40: int(index.max()) + 1)
                 n_src = int(ix.max().item()) + 1 if ix.numel() else 0
-            # scatter_mean over the edges of each source node (droid_net.py:420-421)
-            acc = torch.zeros((n_src, H, W, 128), dtype=torch.float32, device=self.device)
-            acc.index_add_(0, ix, hbuf[..., 256:384].float())
-            cnt = torch.zeros(n_src, dtype=torch.float32, device=self.device).index_add_(
-                0, ix, torch.ones(E, device=self.device))
-            agg = (acc / cnt.clamp(min=1).view(-1, 1, 1, 1)).to(torch.float16)
+            # scatter_mean over the edges of each source node (droid_net.py:420-421): deterministic segmented mean
+            # over a CSR of the edges (built once per edge set by the caller, or here)
+            if csr is None:
+                csr = segment_csr(ix, n_src)
+            order, rowptr = csr
+            agg = self._buf("agg", (n_src, H, W, 128))
+            check(lib().vipe_segment_mean_nhwc_f16(ptr(hbuf), 384, 256, ptr(order), ptr(rowptr), ptr(agg), n_src, H * W,
+                                                   128, stream_ptr(hbuf)), "segment_mean")
             a2 = self._buf("a2", (n_src, H, W, 128))
             eta = torch.empty((n_src, H, W), dtype=torch.float32, device=self.device)
             self._conv(self.agg2, agg, 0, n_src, H, W, y=a2, act="relu")
