@@ -1,0 +1,77 @@
+"""N>1 path on CPU: world_size-2 gloo processes, clip sharding + the single result gather."""
+
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from vipe_amd.driver.clip_shard import ClipResult, gather_results, run_sharded, shard_clips
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_clips, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def process(cid):
+        if cid == 3:
+            raise ValueError("malformed clip")  # per-clip isolation (system.py:298-299 analogue)
+        f = 5 + cid  # ragged trajectory lengths
+        poses = torch.zeros(f, 7)
+        poses[:, 0] = cid
+        poses[:, 1] = torch.arange(f)
+        poses[:, 6] = 1
+        return ClipResult(cid, poses, torch.tensor([100.0 + cid, 100.0, 64.0, 48.0]))
+
+    res = run_sharded(n_clips, process, f_max=16)
+    q.put((rank, [(r.clip_id, r.ok, tuple(r.poses.shape), float(r.poses[:, 1].sum()) if r.ok else -1.0,
+                   float(r.intrinsics[0])) for r in res]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_assignment_is_a_partition():
+    for n, w in [(8, 8), (5, 2), (1, 4), (0, 3), (17, 8)]:
+        parts = [shard_clips(n, r, w) for r in range(w)]
+        flat = sorted(c for p in parts for c in p)
+        assert flat == list(range(n))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_two_rank_gloo_gather():
+    world, n_clips = 2, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_clips, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert outs[0] == outs[1], "every rank must receive the same gathered list"
+    got = outs[0]
+    assert [g[0] for g in got] == [0, 1, 2, 3, 4]
+    for cid, ok, shape, s, fx in got:
+        if cid == 3:
+            assert not ok and shape == (0, 7)
+        else:
+            f = 5 + cid
+            assert ok and shape == (f, 7) and s == sum(range(f)) and fx == 100.0 + cid
+
+
+def test_single_process_gather_is_identity():
+    r = [ClipResult(1, torch.ones(3, 7), torch.arange(4.0)), ClipResult(0, torch.zeros(2, 7), torch.zeros(4))]
+    out = gather_results(r, n_clips=2, f_max=4)
+    assert [o.clip_id for o in out] == [0, 1] and out[1].poses.shape == (3, 7)
