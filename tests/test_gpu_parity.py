@@ -508,3 +508,19 @@ def test_corr_ext_sampler_against_torch_loops():
     ref = torch.stack([torch.stack([(a_ * bp[:, :, ph:ph + H, pw:pw + W]).sum(1) for pw in range(patch)], 1) for ph in range(patch)], 1)
     (ref * g).sum().backward()
     assert torch.allclose(g1, a_.grad, atol=1e-4) and torch.allclose(g2, b_.grad, atol=1e-4)
+
+
+def test_corr_pyramid_lookup_row_kernel_bit_exact():
+    """Widths that are multiples of 64 take the 8-lanes-per-pixel kernel: bit-exact vs the oracle, both layouts,
+    windows hanging over every border."""
+    from vipe_amd.ext import droid_net_ext
+    rng = np.random.default_rng(21)
+    E, h, w = 2, 8, 64
+    levels = [T(rng.normal(0, 1, (E, h, w, h >> i, w >> i)).astype(np.float16)) for i in range(4)]
+    coords = np.stack([rng.uniform(-6, w + 5, (E, h, w)), rng.uniform(-6, h + 5, (E, h, w))], -1).astype(np.float32)
+    coords[0, 0, :8] = np.stack([np.arange(8) * 8.0, np.arange(8) * 1.0], -1)  # integer coords, every chunk phase
+    ref = ocorr.corr_lookup([lv.cpu().numpy() for lv in levels], coords[None], 3)[0]  # [E,196,h,w]
+    out = droid_net_ext.corr_pyramid_lookup(levels, T(coords), 3)
+    assert np.array_equal(out.cpu().numpy().view(np.uint16), ref.view(np.uint16))
+    nhwc = droid_net_ext.corr_pyramid_lookup_nhwc(levels, T(coords), 3, 200)
+    assert torch.equal(nhwc[..., :196].permute(0, 3, 1, 2), out) and torch.count_nonzero(nhwc[..., 196:]) == 0
