@@ -45,7 +45,6 @@ struct ConvArgs {
   const half_t* zbuf;                          // [M,128] (Q)
   half_t* y2; int y2_ctot, y2_coff;            // second output (ZR: r*net)
   float* fout;                                 // GLO: glo_sum [B,Cout]; HEADS: [M,4]; ETA: [M]
-  int dbg;                                     // diagnostic builds only (VIPE_CONV_EXP): 1 no DMA, 2 no LDS reads, 4 no barrier
 };
 
 constexpr int BNP = 128;  // pixels per tile
@@ -480,8 +479,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
       const unsigned char* bw = ldsW + cur * BMC * 128;
       const int dy = tap / a.KW - ph, dx = tap % a.KW - pw;
       // 1. LDS-DMAs of the steps ahead (hidden from hipcc's waitcnt bookkeeping, counted by hand below)
-      if (a.dbg & 1) {
-      } else if (pipe) {
+      if (pipe) {
         issueW_step(step + 2, (step + 2) % 3);
         bool issued = false;
         if (c + 1 < csteps) {
@@ -506,10 +504,10 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
         half8 wf[TM], xf[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          wf[i] = *reinterpret_cast<const half8*>(bw + ((a.dbg & 2) ? 0 : swz((wm * TM + i) * 32 + lrow, kk * 2 + lhalf)));
+          wf[i] = *reinterpret_cast<const half8*>(bw + swz((wm * TM + i) * 32 + lrow, kk * 2 + lhalf));
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          xf[j] = *reinterpret_cast<const half8*>(bx + ((a.dbg & 2) ? 0 : swz(rx0 + j * 32, kk * 2 + lhalf)));
+          xf[j] = *reinterpret_cast<const half8*>(bx + swz(rx0 + j * 32, kk * 2 + lhalf));
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -518,11 +516,96 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
       }
       if (pipe) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (!(a.dbg & 4)) __syncthreads();
+      __syncthreads();
     }
   }
+  // ---- epilogue through LDS: the accumulator layout (lane = pixel, registers = 4-cout groups) would store 8-byte
+  // pieces at a 256-byte stride (64 segments per wave instruction).  Stage the fp32 tile [256 px][128 co] in LDS
+  // (row pitch 132 floats: the 16-lane write groups hit 64 distinct banks), then every lane handles 8 consecutive
+  // channels of one pixel: 16-byte loads of net / z, 16-byte stores, 256 contiguous bytes per pixel.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#include "conv_epilogue.inc"
+  __syncthreads();
+  {
+    constexpr int PITCH = 132;
+    float* stage = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int pl = wn * 64 + j * 32 + lrow, co = wm * 64 + i * 32 + 8 * g + 4 * lhalf;
+          *reinterpret_cast<float4*>(stage + pl * PITCH + co) =
+              make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        }
+    __syncthreads();
+    const int ch = (tid & 15) * 8, co = cout0 + ch;
+    const int e = (int)(pix0 / HW);  // the tile lies inside one image
+    float bv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      bv[q] = (co + q < a.Cout) ? a.bias[co + q] : 0.0f;
+      if (a.extra && co + q < a.Cout) bv[q] += a.extra[(int64_t)e * a.extra_stride + a.extra_off + co + q];
+    }
+    float gsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 2
+    for (int it = 0; it < BP / 32; ++it) {
+      const int pl = (tid >> 4) + 32 * it;
+      const int64_t m = pix0 + pl;
+      const float4 v0 = *reinterpret_cast<const float4*>(stage + pl * PITCH + ch);
+      const float4 v1 = *reinterpret_cast<const float4*>(stage + pl * PITCH + ch + 4);
+      float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
+      half8 o;
+      half_t* dst = nullptr;
+      if (a.epi == EPI_PLAIN) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = (half_t)act_apply(v[q], a.act);
+        dst = a.y + m * a.y_ctot + a.y_coff + co;
+      } else if (a.epi == EPI_GLO) {
+        const half8 nv = *reinterpret_cast<const half8*>(a.net + m * a.net_ctot + a.net_coff + co);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) gsum[q] += (float)(half_t)act_apply(v[q], VIPE_ACT_SIGMOID) * (float)nv[q];
+      } else if (a.epi == EPI_ZR) {
+        if (co < 128) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) o[q] = (half_t)act_apply(v[q], VIPE_ACT_SIGMOID);
+          dst = a.y + m * a.y_ctot + a.y_coff + co;
+        } else {
+          const half8 nv = *reinterpret_cast<const half8*>(a.net + m * a.net_ctot + a.net_coff + co - 128);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) o[q] = (half_t)((float)(half_t)act_apply(v[q], VIPE_ACT_SIGMOID) * (float)nv[q]);
+          dst = a.y2 + m * a.y2_ctot + a.y2_coff + co - 128;
+        }
+      } else if (a.epi == EPI_Q) {
+        const half8 nv = *reinterpret_cast<const half8*>(a.net + m * a.net_ctot + a.net_coff + co);
+        const half8 zv = *reinterpret_cast<const half8*>(a.zbuf + m * 128 + co);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float qq = (float)(half_t)tanhf(v[q]);
+          const float z = (float)zv[q];
+          o[q] = (half_t)((1.0f - z) * (float)nv[q] + z * qq);  // droid_net.py:399
+        }
+        dst = a.y + m * a.y_ctot + a.y_coff + co;
+      }
+      if (dst) {
+        if (co + 8 <= a.Cout) {
+          *reinterpret_cast<half8*>(dst) = o;
+        } else {
+          for (int q = 0; q < 8 && co + q < a.Cout; ++q) dst[q] = o[q];
+        }
+      }
+    }
+    if (a.epi == EPI_GLO) {
+      // lanes l, l^16, l^32, l^48 hold the same 8 channels (4 different pixels): fold, then one atomic per channel
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float t = gsum[q];
+        t += __shfl_xor(t, 16, WAVE);
+        t += __shfl_xor(t, 32, WAVE);
+        if (lane < 16 && co + q < a.Cout) atomicAdd(a.fout + (int64_t)e * a.Cout + co + q, t);
+      }
+    }
+  }
 }
 
 // OIHW (fp16 or fp32) -> packed [K_pad/64][Cout_pad][64] fp16, k = tap*Cin_pad + c (generic) or tap*4 + c (Cin == 4)
@@ -607,7 +690,6 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
                     getenv("VIPE_AMD_CONV_NOHALO") == nullptr;
   if (halo) {
     static bool hattr = false;
-    a.dbg = getenv("VIPE_CONV_EXP") ? atoi(getenv("VIPE_CONV_EXP")) : 0;
     const size_t lds = 3 * 128 * 128 + 2 * HALO_LDS_ROWS * 128 + 2048;
     if (!hattr) {
       (void)hipFuncSetAttribute((const void*)conv_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
