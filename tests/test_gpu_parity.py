@@ -524,3 +524,90 @@ def test_corr_pyramid_lookup_row_kernel_bit_exact():
     assert np.array_equal(out.cpu().numpy().view(np.uint16), ref.view(np.uint16))
     nhwc = droid_net_ext.corr_pyramid_lookup_nhwc(levels, T(coords), 3, 200)
     assert torch.equal(nhwc[..., :196].permute(0, 3, 1, 2), out) and torch.count_nonzero(nhwc[..., 196:]) == 0
+
+
+# ------------------------------------------------------------------------------------------------ factor graph (composition)
+
+
+def _tiny_graph(n=5, seed=41):
+    from vipe_amd.slam.buffer import GraphBuffer
+    from vipe_amd.slam.factor_graph import FactorGraph
+    from vipe_amd.slam.networks import UpdateModule
+    g = make_graph(n=n, height=128, width=128, radius=2, seed=seed)  # 16x16 grid: 4 pyramid levels exist
+    buf = GraphBuffer(128, 128, buffer_size=8, device=dev())
+    buf.n_frames = n
+    buf.poses[:n] = T(g.poses)
+    buf.disps[:n, 0] = T(g.disps)
+    buf.intrinsics[:] = T(g.intrinsics)
+    gen = torch.Generator().manual_seed(seed)
+    buf.fmaps[:n, 0] = torch.randn(n, 128, 16, 16, generator=gen).half().to(dev())
+    buf.nets[:n, 0] = torch.randn(n, 128, 16, 16, generator=gen).tanh().half().to(dev())
+    buf.inps[:n, 0] = torch.randn(n, 128, 16, 16, generator=gen).relu().half().to(dev())
+    torch.manual_seed(0)
+    um = UpdateModule().eval()
+    graph = FactorGraph(um, buf, dev(), max_factors=-1)
+    graph.add_factors(torch.from_numpy(g.ii), torch.from_numpy(g.jj))
+    return g, buf, graph, um
+
+
+def test_factor_graph_update_matches_oracle_composition():
+    """One FactorGraph.update (factor_graph.py:231-314) against the same iteration composed from oracle pieces:
+    reproject -> pyramid lookup (bit-exact input to the GRU) -> fp32 UpdateModule -> fp64 BA.  The GRU runs in fp16
+    on the device, so targets/weights agree to fp16 noise and the BA result to a few 1e-3 of the step."""
+    from oracle import update_module as oum
+    g, buf, graph, um = _tiny_graph()
+    n, E = 5, len(g.ii)
+    poses0, disps0 = buf.poses[:n].cpu().numpy().copy(), buf.disps[:n, 0].cpu().numpy().copy()
+    target0 = graph.target[0].cpu().numpy().copy()
+    levels = [lv.cpu().numpy() for lv in graph.corr.corr_pyramid]
+    net0 = graph.f_net.float().cpu()
+    inp0 = graph.inp.float().cpu()
+    graph.update(t0=1, t1=n, itrs=2)
+    torch.cuda.synchronize()
+    # ---- oracle composition
+    z = np.zeros_like(g.ii)
+    intr8 = (g.intrinsics / 8.0).astype(np.float32)
+    rig = ose3.se3_identity(1)
+    o = ogeom.reproject(poses0, disps0, intr8, rig, g.ii, g.jj, z, z, g.ii)
+    coords1 = o["coords"]
+    u, v = ogeom.pixel_grid(16, 16, np.float32)
+    grid = np.stack([u, v], -1)
+    motn = np.clip(np.concatenate([coords1 - grid, target0 - coords1], -1).transpose(0, 3, 1, 2), -64, 64)
+    corr = ocorr.corr_lookup(levels, coords1[None], 3)  # fp16, bit-exact with the device lookup
+    ix = torch.from_numpy(np.unique(g.ii, return_inverse=True)[1])
+    sd = {k: w.float() for k, w in um.state_dict().items()}
+    with torch.no_grad():
+        net2, delta, weight, eta, _ = oum.update_forward(sd, net0, inp0, torch.from_numpy(corr).float(),
+                                                         torch.from_numpy(motn).float()[None].half().float(), ix)
+    tgt = coords1 + delta[0].numpy()
+    assert np.abs(graph.target[0].cpu().numpy() - tgt).max() < 0.05
+    assert np.abs(graph.weight[0].cpu().numpy() - weight[0].numpy()).max() < 0.02
+    assert np.abs(graph.f_net.float().cpu().numpy() - net2.numpy()).max() < 0.03
+    damping = np.full((n, 1, 16, 16), 1e-6)
+    damping[np.unique(g.ii), 0] = eta[0].numpy()
+    op, od, _, _ = oba.bundle_adjustment(poses0, disps0[:, None], np.zeros_like(disps0)[:, None], g.intrinsics, rig,
+                                         graph.target[0].cpu().numpy().reshape(E, -1, 2),
+                                         graph.weight[0].cpu().numpy().reshape(E, -1, 2), damping, g.ii, g.jj, t0=1, t1=n,
+                                         n_iters=2, pose_damping=1e-3, pose_ep=0.1)
+    # same targets/weights (device values) into the oracle BA -> isolates the BA: 1e-4 relative
+    assert np.abs(buf.poses[:n].cpu().numpy() - op).max() < 2e-4
+    assert np.abs(buf.disps[:n, 0].cpu().numpy() - od[:, 0]).max() < 2e-4 * np.abs(od).max() + 1e-3 * np.abs(
+        graph.damping[:n].cpu().numpy() - damping[:, 0]).max()
+    assert int(graph.age.min()) == 1
+
+
+def test_factor_graph_update_batch_runs_and_reduces_energy():
+    g, buf, graph, um = _tiny_graph(seed=43)
+    n = 5
+    graph.target = T(g.target)[None].contiguous()
+    graph.weight = T(g.weight)[None].contiguous()
+    rig = ose3.se3_identity(1)
+    graph.update_batch(itrs=4, steps=1, optimize_intrinsics=False, optimize_rig_rotation=False)
+    torch.cuda.synchronize()
+    p, d = buf.poses[:n].cpu().numpy(), buf.disps[:n].cpu().numpy()
+    tg, wg = graph.target[0].cpu().numpy(), graph.weight[0].cpu().numpy()
+    assert np.isfinite(p).all() and np.isfinite(d).all()
+    # the BA step decreased the energy of the factors it was given
+    e_before = oba.energy(g.poses, g.disps[:, None], g.intrinsics, rig, tg, wg, g.ii, g.jj)
+    e_after = oba.energy(p, d, g.intrinsics, rig, tg, wg, g.ii, g.jj)
+    assert e_after < e_before

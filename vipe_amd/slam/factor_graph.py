@@ -9,7 +9,7 @@ scatter_mean's index.max(), every _tmult_mat_elements and the CPU spsolve).
 import torch
 
 from ..ext import slam_ext
-from .networks import CorrBlock
+from .networks import AltCorrBlock, CorrBlock
 
 
 class FactorGraph:
@@ -175,3 +175,56 @@ class FactorGraph:
         buf.bundle_adjustment(target.view(E, -1, 2), weight.view(E, -1, 2), self.damping, ii, jj, t0,
                               t1 if not fixed_motion else t0, itrs, 1e-3, 0.1, motion_only, limited_disp, False, False)
         self.age += 1
+
+    @torch.no_grad()
+    def update_batch(self, itrs, steps, optimize_intrinsics, optimize_rig_rotation, solver_verbose=False):
+        """Backend update (hot loop B, factor_graph.py:316-394): volume-free correlation (AltCorrBlock over the
+        buffer's feature maps), the flow-update operator applied in chunks of 8 source keyframes, then ONE dense BA
+        over all edges with `itrs` Gauss-Newton iterations (t0 = 1, t1 = n_frames, pose damping 1e-5 / 1e-2)."""
+        assert self.net_n is not None
+        buf = self.buffer
+        t = buf.n_frames
+        corr_op = AltCorrBlock(buf.flattened_fmaps[None])
+        eng = self.update_op.engine(self.device)
+        P = self._edge_plan()
+        V = buf.n_views
+        for _ in range(steps):
+            coords1, motn = slam_ext.reproject_motion_nhwc(buf.poses, buf.flattened_disps, buf.intrinsics, buf.rig,
+                                                           P["pi"], P["qi"], P["pj"], P["qj"], P["di"],
+                                                           self.target[0].contiguous(), camera=buf.camera_type)
+            s = 8
+            assert self.jj.max() >= self.ii.max()
+            for i in range(0, int(self.jj.max()) + 1, s):
+                v = (self.ii >= i) & (self.ii < i + s)
+                if not bool(v.any()):
+                    continue
+                v_exp = v.view(-1, 1).repeat(1, V).view(-1)
+                iis, jjs = self.ii[v], self.jj[v]
+                pis, qis, dis, pjs, qjs, djs = buf.expand_edge_multiview(iis, jjs)
+                corr1 = corr_op(coords1[None][:, v_exp], dis, djs)  # [1,n,196,h,w] fp32
+                du, dixs = torch.unique(dis, return_inverse=True)
+                n = int(v_exp.sum())
+                corr_n = torch.zeros((n, self.ht, self.wd, 200), dtype=torch.half, device=self.device)
+                corr_n[..., :196] = corr1[0].permute(0, 2, 3, 1)
+                xb = torch.empty((n, self.ht, self.wd, 320), dtype=torch.half, device=self.device)
+                xb[..., 0:128] = buf.inps[pis, qis].permute(0, 2, 3, 1)
+                if eng.backend == "hip":
+                    net, dw, eta, _ = eng.forward_nhwc(self.net_n[v_exp].contiguous(), xb, corr_n, motn[v_exp].contiguous(),
+                                                       ix=dixs, n_src=int(du.numel()))
+                    delta, weight = dw[..., 0:2], dw[..., 2:4].clone()
+                else:
+                    f_net, delta, weight, eta, _ = eng.forward(
+                        self.net_n[v_exp].permute(0, 3, 1, 2)[None], xb[..., 0:128].permute(0, 3, 1, 2)[None],
+                        corr1.half(), motn[v_exp].permute(0, 3, 1, 2)[None], ix=dixs, skip_upmask=True,
+                        n_src=int(du.numel()))
+                    net = f_net[0].permute(0, 2, 3, 1).contiguous()
+                    delta, weight, eta = delta[0].float(), weight[0].float(), eta[0]
+                weight[buf.masks[pis, qis]] = 0.0
+                self.net_n[v_exp] = net
+                self.target[0, v_exp] = coords1[v_exp] + delta
+                self.weight[0, v_exp] = weight
+                self.damping[du] = eta
+            E = self.target.shape[1]
+            buf.bundle_adjustment(self.target.view(E, -1, 2), self.weight.view(E, -1, 2), self.damping, self.ii, self.jj,
+                                  1, t, itrs, 1e-5, 1e-2, False, False, optimize_intrinsics, optimize_rig_rotation,
+                                  verbose=solver_verbose)
