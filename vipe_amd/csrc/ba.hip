@@ -191,6 +191,7 @@ __global__ __launch_bounds__(1024) void ba_plan_kernel(BAArgs a) {
     a.w.info[1] = lds[0];
     a.w.info[2] = 0;
     a.w.info[3] = 6 * n_free + F;
+    a.w.info[4] = 0;  // band width of the reduced pose system in 6x6 blocks (filled below)
   }
   // stable counting sort of the terms by source frame: frame k's owner scans the term list in order
   // (cursor kept in cnt[]: reuse cnt as the running write position)
@@ -208,6 +209,20 @@ __global__ __launch_bounds__(1024) void ba_plan_kernel(BAArgs a) {
         if (stage[i] == k) a.w.order[pos++] = c0 + i;
       cnt[k] = pos;
     }
+  }
+  // Band of the reduced system: two poses couple (directly through H_ij or through the Schur complement of a
+  // source frame) only if they are members {pose of k} + {targets of k's terms} of the same frame k.
+  __syncthreads();
+  for (int k = t; k < nF; k += 1024) {
+    if (!(a.w.fflags[k] & 1)) continue;
+    int lo = 1 << 30, hi = -1;
+    const int si = a.w.pose_slot[k / V];
+    if (si >= 0) { lo = si; hi = si; }
+    for (int q = a.w.rowptr[k]; q < a.w.rowptr[k + 1]; ++q) {
+      const int sj = a.w.pose_slot[(int)a.pj[a.w.order[q]]];
+      if (sj >= 0) { lo = min(lo, sj); hi = max(hi, sj); }
+    }
+    if (hi >= 0) atomicMax(&a.w.info[4], hi - lo);
   }
 }
 
@@ -227,9 +242,9 @@ __device__ __forceinline__ void s_add(const BAWs& w, int row, int col, double v)
 template <int N>
 __device__ __forceinline__ float block_reduce(float (&vals)[N], float* red /* [NWAVE][N] */) {
 #pragma unroll
-  for (int i = 0; i < N; ++i) vals[i] = wave_sum(vals[i]);
+  for (int i = 0; i < N; ++i) vals[i] = wave_sum_to_lane63(vals[i]);
   __syncthreads();  // previous consumers of `red` are done
-  if (lane_id() == 0) {
+  if (lane_id() == 63) {
 #pragma unroll
     for (int i = 0; i < N; ++i) red[wave_id() * N + i] = vals[i];
   }
@@ -575,7 +590,7 @@ __global__ __launch_bounds__(TILE) void ba_accum_kernel(BAArgs a) {
 //     3. trailing update A22 -= P P^T: 1x4 register tiles per thread, panel from LDS, S read-modify-write in
 //        32-byte row segments.
 //   Then blocked backward substitution L^T x = y and the pose / intrinsics retraction.
-constexpr int NB = 24;
+constexpr int NB = 12;
 constexpr int SOLVE_T = 512;  // 8 waves: up to 256 VGPRs per lane, no spills in the register-resident phases
 
 struct SolveLds {
@@ -617,6 +632,9 @@ __global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_c
   }
   __syncthreads();
   const bool use_lds_panel = (n + 1) <= panel_cap;
+  const int npose_rows = 6 * n_free;
+  // band of the pose part in 6x6 blocks (plan kernel); the scalar fallback path treats the system as dense
+  const int bandblk = use_lds_panel ? w.info[4] : n;
 
   for (int k0 = 0; k0 < n; k0 += NB) {
     const int bw = min(NB, n - k0);
@@ -664,11 +682,17 @@ __global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_c
     __syncthreads();
     STAMP(0)
     // ---- 2. panel rows r0..n (row n = rhs)
+    // Rows below the block that can be nonzero in these columns: the band [r0, e1) of pose rows plus the dense
+    // tail [t0, n] (intrinsics rows and the rhs row).  Compact panel index pr -> global row prow(pr).
     const int r0 = k0 + bw;
-    const int m = n - r0 + 1;
+    const int e1 = r0 < npose_rows ? min(npose_rows, 6 * ((k0 + bw - 1) / 6 + bandblk + 1)) : r0;
+    const int t0 = max(r0, npose_rows);
+    const int nb1 = max(e1 - r0, 0);
+    const int m = nb1 + (n - t0 + 1);
+    auto prow = [&](int pr) { return pr < nb1 ? r0 + pr : t0 + (pr - nb1); };
     for (int pr = t; pr < m; pr += SOLVE_T) {
       double x[NB];
-      double* grow = S + (int64_t)(r0 + pr) * ld + k0;
+      double* grow = S + (int64_t)prow(pr) * ld + k0;
 #pragma unroll
       for (int j = 0; j < NB; ++j) x[j] = j < bw ? grow[j] : 0.0;
 #pragma unroll
@@ -714,7 +738,7 @@ __global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_c
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
           const int rr = 16 * ti + (ln >> 4) + 4 * r4;
-          if (rr < m && cc <= rr && cc <= m - 2) S[(int64_t)(r0 + rr) * ld + r0 + cc] -= c[r4];
+          if (rr < m && cc <= rr && cc <= m - 2) S[(int64_t)prow(rr) * ld + prow(cc)] -= c[r4];
         }
       }
     } else {
@@ -811,7 +835,9 @@ __global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_c
       }
     }
     __syncthreads();
-    for (int c = t; c < k0; c += SOLVE_T) {
+    // rows of this block are zero left of the band (pose rows only; tail rows are dense)
+    const int c_lo = (k0 + bw <= npose_rows) ? max(0, 6 * (k0 / 6 - bandblk)) : 0;
+    for (int c = c_lo + t; c < k0; c += SOLVE_T) {
       double sacc = 0.0;
       for (int q = 0; q < bw; ++q) sacc += S[(int64_t)(k0 + q) * ld + c] * sh.xk[q];
       yrow[c] -= sacc;

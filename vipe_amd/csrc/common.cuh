@@ -31,6 +31,22 @@ __device__ __forceinline__ T wave_sum(T v) {
   return v;
 }
 
+// Wave-wide float sum on the DPP path (one VALU instruction per step instead of a ds_bpermute round trip):
+// xor-1 / xor-2 quad permutes, half-row and row mirrors give every lane its 16-lane row sum, row_bcast15/31 carry
+// the row sums forward so that LANE 63 holds the total (other lanes hold partial sums).
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+#define VIPE_DPP_ADD(ctrl, rmask)                                                                          \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, true))
+  VIPE_DPP_ADD(0xB1, 0xf);   // quad_perm [1,0,3,2]
+  VIPE_DPP_ADD(0x4E, 0xf);   // quad_perm [2,3,0,1]
+  VIPE_DPP_ADD(0x141, 0xf);  // row_half_mirror
+  VIPE_DPP_ADD(0x140, 0xf);  // row_mirror
+  VIPE_DPP_ADD(0x142, 0xa);  // row_bcast15 -> rows 1, 3
+  VIPE_DPP_ADD(0x143, 0xc);  // row_bcast31 -> rows 2, 3
+#undef VIPE_DPP_ADD
+  return v;
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
