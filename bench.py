@@ -177,6 +177,15 @@ def main():
         flops_per_launch = tot_fl / len(rec)
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12
 
+    # HBM traffic of the dominant kernel per launch, from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+    # profiles/r01_summary.json; counters cannot be collected from inside the timed process)
+    traffic = None
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_summary.json")))["conv_halo_kernel"]
+        traffic = (prof["hbm_read_MB_per_launch"] + prof["hbm_write_MB_per_launch"]) * 1e6
+    except Exception:  # noqa: BLE001
+        pass
+
     if rank == 0:
         out = {
             "metric": "dense-BA+flow update iters/s, 512x384 48-KF graph",
@@ -195,7 +204,7 @@ def main():
                                    f"(radius-3 bidirectional), 3 GN iterations per update, one clip per GPU",
                        "conv_backend": args.conv, "parallelism": f"clip-sharded x{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP16_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP16_TFLOPS, "traffic": traffic,
                          "kernel": "conv_halo_kernel (NHWC fp16 implicit-GEMM conv on MFMA 32x32x16, all launches with "
                                    "Cout >= 128 of the flow-update operator)",
                          "avg_launch_ms": gate_ms, "flops_per_launch": flops_per_launch,

@@ -377,14 +377,18 @@ __device__ __forceinline__ void glds16_off(const void* base, unsigned voff_bytes
 #endif
 }
 
+template <int BMC>
 __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
-  constexpr int BMC = 128, TM = 2, TN = 2, BP = HALO_TH * HALO_TW;
+  // BMC = 128: waves = 2 cout halves x 4 image rows, wave tile 64 couts x 64 px; BMC = 64: 32 couts x 64 px;
+  // BMC = 32: waves = 4 rows x 2 half rows, wave tile 32 couts x 32 px (flow / confidence heads, eta)
+  constexpr int TM = BMC >= 128 ? 2 : 1, TN = BMC == 32 ? 1 : 2, BP = HALO_TH * HALO_TW;
   extern __shared__ __align__(16) unsigned char lds[];
-  unsigned char* ldsW = lds;                          // [3][128 rows * 128 B] weight ring
+  unsigned char* ldsW = lds;                          // [3][BMC rows * 128 B] weight ring
   unsigned char* ldsX = lds + 3 * BMC * 128;          // [2][400 rows * 128 B] halo double buffer, then 2 KiB sink
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;  // cout half, image row of the tile
+  const int wm = BMC == 32 ? 0 : (wave >> 2), wn = wave & 3;  // cout half, image row of the tile
+  const int pxh = BMC == 32 ? (wave >> 2) * 32 : 0;           // BMC = 32: which half of the row
   const int L = xcd_remap(blockIdx.x, gridDim.x);
   const int tile = L / gy, cout0 = (L % gy) * BMC;
   const int tiles_per_img = a.H / HALO_TH;
@@ -397,10 +401,14 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
   const int r8 = lane >> 3, sl = lane & 7;
 
   // ---- descriptors
+  // every wave issues exactly two weight DMAs per step (real pieces first, then dummies) so the hand-counted
+  // vmcnt below is the same for every tile shape: BMC/8 pieces of 1 KiB over 8 waves
+  constexpr int WPW = BMC / 64;  // real pieces per wave: 2, 1, or (BMC = 32) one for waves 0..3
+  const int nwreal = BMC == 32 ? (wave < 4 ? 1 : 0) : WPW;
   unsigned woff[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    const int row = (wave * 2 + q) * 8 + r8;
+    const int row = ((BMC == 128 ? wave * 2 + q : wave) * 8 + r8) % BMC;
     woff[q] = (unsigned)(row * BK + ((sl ^ ((row >> 1) & 7)) << 3)) * 2u;
   }
   unsigned xo0[HALO_XP], xo1[HALO_XP];
@@ -420,19 +428,25 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
     xo1[i] = ok ? (unsigned)((pix * a.x1_ctot + a.x1_coff + k8 * 8 - a.split) * 2) : BAD;
   }
   const half_t* zp = reinterpret_cast<const half_t*>(g_zero_page);
+  // LDS byte addresses as integers (one generic->LDS cast in the whole kernel)
+  const unsigned ldsW_a = lds_address(lds), ldsX_a = ldsW_a + 3 * BMC * 128;
+  const unsigned dummy_a = ldsX_a + 2 * HALO_LDS_ROWS * 128;  // 2 KiB sink for the count-keeping dummy DMAs
 
   auto issueW = [&](int tap, int c, int buf) {
     const half_t* wb = a.w + ((int64_t)(tap * csteps + c) * a.Cout_pad + cout0) * BK;
-    const unsigned lw = lds_address(ldsW + buf * BMC * 128) + wave * 2048;
+    const unsigned lw = (ldsW_a + buf * BMC * 128) + (BMC == 128 ? wave * 2048 : (wave * 1024) % (BMC * 128));
 #pragma unroll
-    for (int q = 0; q < 2; ++q) glds16_off(wb, woff[q], lw + q * 1024);
+    for (int q = 0; q < 2; ++q) {
+      if (q < nwreal) glds16_off(wb, woff[q], lw + q * 1024);
+      else glds16(zp, dummy_a + q * 1024);
+    }
   };
   auto issueX = [&](int c, int i, int buf) {
     const int c0 = c * BK;
     const bool s0 = c0 < a.split;
     const unsigned off = s0 ? xo0[i] : xo1[i];
     const bool ok = off != BAD && (c0 + xk8[i] < a.Cin);
-    const unsigned lx = lds_address(ldsX + buf * HALO_LDS_ROWS * 128) + (wave + 8 * i) * 1024;
+    const unsigned lx = (ldsX_a + buf * HALO_LDS_ROWS * 128) + (wave + 8 * i) * 1024;
     // invalid lanes read the 16-byte zero page
     const char* src = reinterpret_cast<const char*>(s0 ? a.x0 : a.x1) + (off + (unsigned)c0 * 2u);
     glds16(ok ? (const void*)src : (const void*)zp, lx);
@@ -453,13 +467,12 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
   // 1x1 (one tap per chunk): prefetch distance 1 with a full drain per step.
   const bool pipe = ntaps >= HALO_XP + 2;
   const int nsteps = csteps * ntaps;
-  unsigned char* dummy = ldsX + 2 * HALO_LDS_ROWS * 128;  // 2 KiB sink for the count-keeping dummy DMAs
   auto issueW_step = [&](int sidx, int buf) {  // weights of global step sidx (chunk-major) or dummies past the end
     if (sidx < nsteps) {
       issueW(sidx % ntaps, sidx / ntaps, buf);
     } else {
-      glds16(zp, lds_address(dummy));
-      glds16(zp, lds_address(dummy) + 1024);
+      glds16(zp, dummy_a);
+      glds16(zp, dummy_a + 1024);
     }
   };
 #pragma unroll
@@ -487,7 +500,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
           for (int i = 0; i < HALO_XP; ++i)
             if (i == tap && wave + 8 * i < HALO_PIECES) { issueX(c + 1, i, (c + 1) & 1); issued = true; }
         }
-        if (!issued) glds16(zp, lds_address(dummy));
+        if (!issued) glds16(zp, dummy_a);
       } else {
         if (step + 1 < nsteps) issueW_step(step + 1, cur ^ 1);
         if (tap == 0 && c + 1 < csteps) {
@@ -498,7 +511,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
       }
       // 2. fragments + matrix cores, k-substep by k-substep (hipcc interleaves the ds_reads of substep kk+1 with the
       //    MFMAs of substep kk and inserts counted lgkmcnt waits)
-      const int rx0 = (wn + dy + 1) * HALO_PITCH + (lrow + dx + 1);
+      const int rx0 = (wn + dy + 1) * HALO_PITCH + (pxh + lrow + dx + 1);
 #pragma unroll
       for (int kk = 0; kk < BK / 16; ++kk) {
         half8 wf[TM], xf[TN];
@@ -526,7 +539,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   {
-    constexpr int PITCH = 132;
+    constexpr int PITCH = BMC + 4, CPP = BMC / 8;  // floats per staged pixel row, 8-channel chunks per pixel
     float* stage = reinterpret_cast<float*>(lds);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -534,12 +547,12 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int pl = wn * 64 + j * 32 + lrow, co = wm * 64 + i * 32 + 8 * g + 4 * lhalf;
+          const int pl = wn * 64 + pxh + j * 32 + lrow, co = wm * (TM * 32) + i * 32 + 8 * g + 4 * lhalf;
           *reinterpret_cast<float4*>(stage + pl * PITCH + co) =
               make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
         }
     __syncthreads();
-    const int ch = (tid & 15) * 8, co = cout0 + ch;
+    const int ch = (tid % CPP) * 8, co = cout0 + ch;
     const int e = (int)(pix0 / HW);  // the tile lies inside one image
     float bv[8];
 #pragma unroll
@@ -549,8 +562,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
     }
     float gsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 2
-    for (int it = 0; it < BP / 32; ++it) {
-      const int pl = (tid >> 4) + 32 * it;
+    for (int it = 0; it < BP * CPP / 512; ++it) {
+      const int pl = tid / CPP + (512 / CPP) * it;
       const int64_t m = pix0 + pl;
       const float4 v0 = *reinterpret_cast<const float4*>(stage + pl * PITCH + ch);
       const float4 v1 = *reinterpret_cast<const float4*>(stage + pl * PITCH + ch + 4);
@@ -586,6 +599,17 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
           o[q] = (half_t)((1.0f - z) * (float)nv[q] + z * qq);  // droid_net.py:399
         }
         dst = a.y + m * a.y_ctot + a.y_coff + co;
+      } else if (a.epi == EPI_HEADS) {
+        // cout 0,1: delta; cout 2,3: sigmoid -> weight (droid_net.py:486-490); written as float [M,4]
+        if (ch == 0)
+          *reinterpret_cast<float4*>(a.fout + m * 4) =
+              make_float4((float)(half_t)v[0], (float)(half_t)v[1], (float)(half_t)act_apply(v[2], VIPE_ACT_SIGMOID),
+                          (float)(half_t)act_apply(v[3], VIPE_ACT_SIGMOID));
+      } else if (a.epi == EPI_ETA) {
+        if (ch == 0) {  // 0.01 * softplus (droid_net.py:410,429)
+          const float sp = v[0] > 20.0f ? v[0] : log1pf(__expf(v[0]));
+          a.fout[m] = 0.01f * (float)(half_t)sp;
+        }
       }
       if (dst) {
         if (co + 8 <= a.Cout) {
@@ -685,19 +709,24 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
     attr = true;
   }
   const bool glds = !small && a.KH * a.KW <= 32 && getenv("VIPE_AMD_CONV_REGSTAGE") == nullptr;
-  const bool halo = glds && cp >= 128 && a.W == HALO_TW && a.H % HALO_TH == 0 && a.KH <= 3 && a.KW <= 3 &&
+  const bool halo = glds && a.W == HALO_TW && a.H % HALO_TH == 0 && a.KH <= 3 && a.KW <= 3 &&
                     (int64_t)a.B * a.H * a.W * (a.x0_ctot > a.x1_ctot ? a.x0_ctot : a.x1_ctot) * 2 < (1ll << 32) &&
                     getenv("VIPE_AMD_CONV_NOHALO") == nullptr;
   if (halo) {
     static bool hattr = false;
-    const size_t lds = 3 * 128 * 128 + 2 * HALO_LDS_ROWS * 128 + 2048;
+    const int bmc = cp >= 128 ? 128 : cp;
+    const size_t lds = 3 * (size_t)bmc * 128 + 2 * HALO_LDS_ROWS * 128 + 2048;
     if (!hattr) {
-      (void)hipFuncSetAttribute((const void*)conv_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)conv_halo_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 128 + 2 * HALO_LDS_ROWS * 128 + 2048);
+      (void)hipFuncSetAttribute((const void*)conv_halo_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 128 + 2 * HALO_LDS_ROWS * 128 + 2048);
+      (void)hipFuncSetAttribute((const void*)conv_halo_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32 * 128 + 2 * HALO_LDS_ROWS * 128 + 2048);
       hattr = true;
     }
-    const int gy = cp / 128;
+    const int gy = cp >= 128 ? cp / 128 : 1;
     const int tiles = (int)(M / (HALO_TH * HALO_TW));
-    conv_halo_kernel<<<dim3(tiles * gy), 512, lds, s>>>(a, gy);
+    if (bmc == 128) conv_halo_kernel<128><<<dim3(tiles * gy), 512, lds, s>>>(a, gy);
+    else if (bmc == 64) conv_halo_kernel<64><<<dim3(tiles), 512, lds, s>>>(a, 1);
+    else conv_halo_kernel<32><<<dim3(tiles), 512, lds, s>>>(a, 1);
     return vipe_launch_status();
   }
   if (cp >= 128) {
