@@ -19,6 +19,8 @@
 //     the concatenations of the reference are never materialised.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.cuh"
 
 namespace {
@@ -377,7 +379,7 @@ __device__ __forceinline__ void glds16_off(const void* base, unsigned voff_bytes
 #endif
 }
 
-template <int BMC>
+template <int BMC, int KS>
 __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
   // BMC = 128: waves = 2 cout halves x 4 image rows, wave tile 64 couts x 64 px; BMC = 64: 32 couts x 64 px;
   // BMC = 32: waves = 4 rows x 2 half rows, wave tile 32 couts x 32 px (flow / confidence heads, eta)
@@ -432,15 +434,6 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
   const unsigned ldsW_a = lds_address(lds), ldsX_a = ldsW_a + 3 * BMC * 128;
   const unsigned dummy_a = ldsX_a + 2 * HALO_LDS_ROWS * 128;  // 2 KiB sink for the count-keeping dummy DMAs
 
-  auto issueW = [&](int tap, int c, int buf) {
-    const half_t* wb = a.w + ((int64_t)(tap * csteps + c) * a.Cout_pad + cout0) * BK;
-    const unsigned lw = (ldsW_a + buf * BMC * 128) + (BMC == 128 ? wave * 2048 : (wave * 1024) % (BMC * 128));
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (q < nwreal) glds16_off(wb, woff[q], lw + q * 1024);
-      else glds16(zp, dummy_a + q * 1024);
-    }
-  };
   auto issueX = [&](int c, int i, int buf) {
     const int c0 = c * BK;
     const bool s0 = c0 < a.split;
@@ -460,75 +453,103 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  // ---- pipeline.  3x3: weights run 2 steps ahead through a 3-deep ring, every step issues exactly 3 LDS-DMAs
-  // per wave (2 weight pieces, then 1 halo piece of the next chunk or a dummy), so "s_waitcnt vmcnt(4)" at the end
-  // of step s retires W(s+1) while W(s+2) and the two newest halo pieces stay in flight; a halo piece issued at
-  // step s has landed by the end of step s+2, i.e. pieces issued at taps 0..6 are complete when the chunk ends.
-  // 1x1 (one tap per chunk): prefetch distance 1 with a full drain per step.
-  const bool pipe = ntaps >= HALO_XP + 2;
-  const int nsteps = csteps * ntaps;
-  auto issueW_step = [&](int sidx, int buf) {  // weights of global step sidx (chunk-major) or dummies past the end
-    if (sidx < nsteps) {
-      issueW(sidx % ntaps, sidx / ntaps, buf);
-    } else {
-      glds16(zp, dummy_a);
-      glds16(zp, dummy_a + 1024);
+  // ---- pipeline.  3x3 (KS = 3): the 9 taps are FULLY UNROLLED, so the ring positions ((9c + tap) % 3 = tap % 3),
+  // the tap offsets and the descriptor registers of the halo piece issued at each tap are compile-time constants
+  // (the K-step is instruction-issue bound: runtime divisions / compare chains per step cost more than the MFMAs).
+  // Weights run 2 steps ahead through the 3-deep ring; every step issues exactly 3 LDS-DMAs per wave (2 weight
+  // slots, then 1 halo piece of the next chunk or a dummy), so "s_waitcnt vmcnt(4)" at the end of step s retires
+  // W(s+1) while W(s+2) and the two newest halo pieces stay in flight; a halo piece issued at step s has landed by
+  // the end of step s+2, i.e. pieces issued at taps 0..6 are complete when the chunk ends.
+  // 1x1 (KS = 1, one tap per chunk): prefetch distance 1 with a full drain per step.
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  const int64_t tapstride = (int64_t)csteps * a.Cout_pad * BK;  // weight elements between consecutive taps
+  auto mma_step = [&](const unsigned char* bw, const unsigned char* bx, int dy, int dx) {
+    const int rx0 = (wn + dy + 1) * HALO_PITCH + (pxh + lrow + dx + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      half8 wf[TM], xf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        wf[i] = *reinterpret_cast<const half8*>(bw + swz((wm * TM + i) * 32 + lrow, kk * 2 + lhalf));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        xf[j] = *reinterpret_cast<const half8*>(bx + swz(rx0 + j * 32, kk * 2 + lhalf));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
   };
+  auto issueW_at = [&](const half_t* wb, int buf) {  // two weight slots (real pieces, then dummies)
+    const unsigned lw = (ldsW_a + buf * BMC * 128) + (BMC == 128 ? wave * 2048 : (wave * 1024) % (BMC * 128));
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (q < nwreal) glds16_off(wb, woff[q], lw + q * 1024);
+      else glds16(zp, dummy_a + q * 1024);
+    }
+  };
+  auto issueW_dummy = [&]() {
+    glds16(zp, dummy_a);
+    glds16(zp, dummy_a + 1024);
+  };
+  const half_t* wtile0 = a.w + (int64_t)cout0 * BK;  // + (tap * csteps + c) * Cout_pad * BK
+
 #pragma unroll
   for (int i = 0; i < HALO_XP; ++i)
     if (wave + 8 * i < HALO_PIECES) issueX(0, i, 0);
-  issueW_step(0, 0);
-  if (pipe) issueW_step(1, 1);
+  issueW_at(wtile0, 0);
+  if constexpr (KS == 3) issueW_at(wtile0 + tapstride, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  const int lrow = lane & 31, lhalf = lane >> 5;
-  int step = 0;
-  for (int c = 0; c < csteps; ++c) {
-    const unsigned char* bx = ldsX + (c & 1) * HALO_LDS_ROWS * 128;
-    for (int tap = 0; tap < ntaps; ++tap, ++step) {
-      const int cur = pipe ? step % 3 : (step & 1);
-      const unsigned char* bw = ldsW + cur * BMC * 128;
-      const int dy = tap / a.KW - ph, dx = tap % a.KW - pw;
-      // 1. LDS-DMAs of the steps ahead (hidden from hipcc's waitcnt bookkeeping, counted by hand below)
-      if (pipe) {
-        issueW_step(step + 2, (step + 2) % 3);
-        bool issued = false;
-        if (c + 1 < csteps) {
-#pragma unroll
-          for (int i = 0; i < HALO_XP; ++i)
-            if (i == tap && wave + 8 * i < HALO_PIECES) { issueX(c + 1, i, (c + 1) & 1); issued = true; }
+  if constexpr (KS == 3) {
+    for (int c = 0; c < csteps; ++c) {
+      const unsigned char* bx = ldsX + (c & 1) * HALO_LDS_ROWS * 128;
+      const half_t* wc = wtile0 + (int64_t)c * a.Cout_pad * BK;
+      const bool more = c + 1 < csteps;
+      auto tap_step = [&](auto TAPC) {
+        constexpr int TAP = decltype(TAPC)::value;
+        constexpr int T2 = TAP + 2;
+        // 1. LDS-DMAs of step + 2 (hidden from hipcc's waitcnt bookkeeping, counted by hand below)
+        if constexpr (T2 < 9) {
+          issueW_at(wc + T2 * tapstride, T2 % 3);
+        } else {
+          if (more) issueW_at(wc + (int64_t)a.Cout_pad * BK + (T2 - 9) * tapstride, T2 % 3);
+          else issueW_dummy();
         }
-        if (!issued) glds16(zp, dummy_a);
-      } else {
-        if (step + 1 < nsteps) issueW_step(step + 1, cur ^ 1);
-        if (tap == 0 && c + 1 < csteps) {
-#pragma unroll
-          for (int i = 0; i < HALO_XP; ++i)
-            if (wave + 8 * i < HALO_PIECES) issueX(c + 1, i, (c + 1) & 1);
+        if constexpr (TAP < HALO_XP) {
+          if (more && wave + 8 * TAP < HALO_PIECES) issueX(c + 1, TAP, (c + 1) & 1);
+          else glds16(zp, dummy_a);
+        } else {
+          glds16(zp, dummy_a);
         }
+        // 2. fragments + matrix cores
+        mma_step(ldsW + (TAP % 3) * BMC * 128, bx, TAP / 3 - 1, TAP % 3 - 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __syncthreads();
+      };
+      tap_step(std::integral_constant<int, 0>{});
+      tap_step(std::integral_constant<int, 1>{});
+      tap_step(std::integral_constant<int, 2>{});
+      tap_step(std::integral_constant<int, 3>{});
+      tap_step(std::integral_constant<int, 4>{});
+      tap_step(std::integral_constant<int, 5>{});
+      tap_step(std::integral_constant<int, 6>{});
+      tap_step(std::integral_constant<int, 7>{});
+      tap_step(std::integral_constant<int, 8>{});
+    }
+  } else {
+    for (int c = 0; c < csteps; ++c) {
+      const unsigned char* bx = ldsX + (c & 1) * HALO_LDS_ROWS * 128;
+      if (c + 1 < csteps) {
+        issueW_at(wtile0 + (int64_t)(c + 1) * a.Cout_pad * BK, (c + 1) & 1);
+#pragma unroll
+        for (int i = 0; i < HALO_XP; ++i)
+          if (wave + 8 * i < HALO_PIECES) issueX(c + 1, i, (c + 1) & 1);
       }
-      // 2. fragments + matrix cores, k-substep by k-substep (hipcc interleaves the ds_reads of substep kk+1 with the
-      //    MFMAs of substep kk and inserts counted lgkmcnt waits)
-      const int rx0 = (wn + dy + 1) * HALO_PITCH + (pxh + lrow + dx + 1);
-#pragma unroll
-      for (int kk = 0; kk < BK / 16; ++kk) {
-        half8 wf[TM], xf[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-          wf[i] = *reinterpret_cast<const half8*>(bw + swz((wm * TM + i) * 32 + lrow, kk * 2 + lhalf));
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          xf[j] = *reinterpret_cast<const half8*>(bx + swz(rx0 + j * 32, kk * 2 + lhalf));
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-      }
-      if (pipe) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      mma_step(ldsW + (c & 1) * BMC * 128, bx, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
   }
@@ -709,7 +730,7 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
     attr = true;
   }
   const bool glds = !small && a.KH * a.KW <= 32 && getenv("VIPE_AMD_CONV_REGSTAGE") == nullptr;
-  const bool halo = glds && a.W == HALO_TW && a.H % HALO_TH == 0 && a.KH <= 3 && a.KW <= 3 &&
+  const bool halo = glds && a.W == HALO_TW && a.H % HALO_TH == 0 && a.KH == a.KW && (a.KH == 1 || a.KH == 3) &&
                     (int64_t)a.B * a.H * a.W * (a.x0_ctot > a.x1_ctot ? a.x0_ctot : a.x1_ctot) * 2 < (1ll << 32) &&
                     getenv("VIPE_AMD_CONV_NOHALO") == nullptr;
   if (halo) {
@@ -717,16 +738,27 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
     const int bmc = cp >= 128 ? 128 : cp;
     const size_t lds = 3 * (size_t)bmc * 128 + 2 * HALO_LDS_ROWS * 128 + 2048;
     if (!hattr) {
-      (void)hipFuncSetAttribute((const void*)conv_halo_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 128 + 2 * HALO_LDS_ROWS * 128 + 2048);
-      (void)hipFuncSetAttribute((const void*)conv_halo_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 128 + 2 * HALO_LDS_ROWS * 128 + 2048);
-      (void)hipFuncSetAttribute((const void*)conv_halo_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32 * 128 + 2 * HALO_LDS_ROWS * 128 + 2048);
+      const int x = 2 * HALO_LDS_ROWS * 128 + 2048;
+      (void)hipFuncSetAttribute((const void*)conv_halo_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 128 + x);
+      (void)hipFuncSetAttribute((const void*)conv_halo_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 128 + x);
+      (void)hipFuncSetAttribute((const void*)conv_halo_kernel<32, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32 * 128 + x);
+      (void)hipFuncSetAttribute((const void*)conv_halo_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 128 + x);
+      (void)hipFuncSetAttribute((const void*)conv_halo_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 128 + x);
+      (void)hipFuncSetAttribute((const void*)conv_halo_kernel<32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32 * 128 + x);
       hattr = true;
     }
     const int gy = cp >= 128 ? cp / 128 : 1;
     const int tiles = (int)(M / (HALO_TH * HALO_TW));
-    if (bmc == 128) conv_halo_kernel<128><<<dim3(tiles * gy), 512, lds, s>>>(a, gy);
-    else if (bmc == 64) conv_halo_kernel<64><<<dim3(tiles), 512, lds, s>>>(a, 1);
-    else conv_halo_kernel<32><<<dim3(tiles), 512, lds, s>>>(a, 1);
+    const dim3 grid(tiles * gy);
+    if (a.KH == 3) {
+      if (bmc == 128) conv_halo_kernel<128, 3><<<grid, 512, lds, s>>>(a, gy);
+      else if (bmc == 64) conv_halo_kernel<64, 3><<<grid, 512, lds, s>>>(a, 1);
+      else conv_halo_kernel<32, 3><<<grid, 512, lds, s>>>(a, 1);
+    } else {
+      if (bmc == 128) conv_halo_kernel<128, 1><<<grid, 512, lds, s>>>(a, gy);
+      else if (bmc == 64) conv_halo_kernel<64, 1><<<grid, 512, lds, s>>>(a, 1);
+      else conv_halo_kernel<32, 1><<<grid, 512, lds, s>>>(a, 1);
+    }
     return vipe_launch_status();
   }
   if (cp >= 128) {
