@@ -611,3 +611,20 @@ def test_factor_graph_update_batch_runs_and_reduces_energy():
     e_before = oba.energy(g.poses, g.disps[:, None], g.intrinsics, rig, tg, wg, g.ii, g.jj)
     e_after = oba.energy(p, d, g.intrinsics, rig, tg, wg, g.ii, g.jj)
     assert e_after < e_before
+
+
+def test_dense_ba_non_banded_graph_takes_global_memory_solver():
+    """Long-range (loop-closure-like) edges make the reduced system dense: it no longer fits the LDS band solver and
+    the blocked global-memory Cholesky (fp64 MFMA trailing update) must give the same answer as the fp64 oracle."""
+    g = make_graph(n=30, height=96, width=128, radius=2, extra_edges=60, seed=77)
+    bk = dict(t0=1, t1=30, n_iters=2, pose_damping=1e-5, pose_ep=1e-2, motion_only=False, limited_disp=False,
+              optimize_intrinsics=True)
+    p, d, k, info = run_hip_ba(g, g.intrinsics, "pinhole", bk)
+    E = len(g.ii)
+    op, od, ok_, _ = oba.bundle_adjustment(g.poses, g.disps[:, None], g.disps_sens[:, None], g.intrinsics,
+                                           ose3.se3_identity(1), g.target.reshape(E, -1, 2), g.weight.reshape(E, -1, 2),
+                                           g.eta[:, None], g.ii, g.jj, **bk)
+    assert info[0] == 29 and info[3] == 175 and info[2] == 0
+    assert np.abs(p - op).max() <= 1e-4 * max(1.0, np.abs(op).max())
+    assert np.abs(d - od[:, 0]).max() <= 1e-4 * np.abs(od).max()
+    assert np.abs(k - ok_).max() <= 1e-4 * np.abs(ok_).max()

@@ -578,6 +578,232 @@ __global__ __launch_bounds__(TILE) void ba_accum_kernel(BAArgs a) {
   }
 }
 
+// 1/sqrt(x) in fp64: hardware estimate + 2 Newton steps (avoids the long sqrt / divide sequences on the
+// factorisation's critical path)
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * (1.5 - 0.5 * x * r * r);
+  r = r * (1.5 - 0.5 * x * r * r);
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------ solve (LDS band)
+
+// Retraction shared by both solve kernels: poses X <- Exp(dx) X (retractor.py:27-29), intrinsics (retractor.py:50-62)
+__device__ __forceinline__ void apply_retraction(const BAArgs& a, int t, int nthreads, int n_free) {
+  const BAWs& w = a.w;
+  for (int sl = t; sl < n_free; sl += nthreads) {
+    const int pidx = w.slot_pose[sl];
+    float xi[6];
+    for (int q = 0; q < 6; ++q) xi[q] = w.dx[6 * sl + q];
+    lie::SE3<float> X(a.poses + 7 * pidx);
+    (lie::SE3<float>::exp(xi) * X).store(a.poses + 7 * pidx);
+  }
+  if (a.p.optimize_intrinsics && t == 0) {
+    const int F = 1 + a.D;
+    const float df = w.dx[6 * n_free];
+    for (int vq = 0; vq < a.p.n_views; ++vq) {
+      float* I = a.intr + vq * (4 + a.D);
+      if (I[0] > 0) { I[0] += df; I[1] += df; if (F > 1) I[4] += 0.01f * w.dx[6 * n_free + 1]; }
+    }
+  }
+}
+
+// When the reduced system is banded (sliding-window / neighbourhood graphs: two poses couple only through a shared
+// source frame) and its band fits the 160 KB of LDS, the whole factorisation runs out of LDS: every dependent step
+// then costs an LDS round trip (~100 cycles) instead of an L2 round trip (~2000), which is what bounds this
+// latency-critical kernel.  Storage: pose row r keeps columns [lo(r), r], lo(r) = 6 * max(0, r/6 - bandblk), at
+// pitch WB + 1 doubles; the dense tail rows (intrinsics, then the rhs) are kept full length.  Block size 6 = one
+// pose.  Sets info[5] = 1 when it solved the system (the global-memory kernel launched after it then exits).
+constexpr int BAND_T = 512;
+
+__global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds_doubles) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* const L = reinterpret_cast<double*>(smem_raw);
+  const vipe_ba_params& prm = a.p;
+  const BAWs& w = a.w;
+  const int t = threadIdx.x;
+  const int n = w.info[3], n_free = w.info[0], bandblk = w.info[4];
+  const int ld = w.ld;
+  const int npr = 6 * n_free, ntail = n - npr + 1;  // tail rows: intrinsics rows, then the rhs row
+  const int WB = 6 * (bandblk + 1), WBP = WB + 1;
+  // LDS carve: band [npr][WBP], tail [ntail][n + 1], blk[6][7], rd[6], xs[6], flags
+  const int need = npr * WBP + ntail * (n + 1) + 64;
+  if (t == 0) w.info[5] = 0;
+  if (n == 0 || need > lds_doubles) return;
+  double* const Bd = L;
+  double* const Tl = L + npr * WBP;
+  double* const blk = Tl + ntail * (n + 1);  // 6x7
+  double* const rd = blk + 42;
+  double* const xs = rd + 6;
+  int* const failp = reinterpret_cast<int*>(xs + 6);
+  const double* S = w.S;
+  auto lo = [&](int r) { return 6 * max(0, r / 6 - bandblk); };
+  auto bref = [&](int r, int c) -> double& { return Bd[r * WBP + (c - lo(r))]; };
+  auto tref = [&](int q, int c) -> double& { return Tl[q * (n + 1) + c]; };
+
+  // ---- load (with LM damping on the diagonal, matrix.py:179-186)
+  if (t == 0) *failp = 0;
+  for (int idx = t; idx < npr * WBP; idx += BAND_T) {
+    const int r = idx / WBP, k = idx % WBP, c = lo(r) + k;
+    double v = 0.0;
+    if (c <= r) {
+      v = S[(int64_t)r * ld + c];
+      if (c == r) v += (double)prm.pose_ep + (double)prm.pose_damping * w.Hd[r];
+    }
+    Bd[idx] = v;
+  }
+  for (int idx = t; idx < ntail * (n + 1); idx += BAND_T) {
+    const int q = idx / (n + 1), c = idx % (n + 1), r = npr + q;
+    double v = 0.0;
+    if (c <= r && c < n) {
+      v = S[(int64_t)r * ld + c];
+      if (c == r) v += 1e-6 + 1e-6 * w.Hd[r];
+    }
+    Tl[idx] = v;
+  }
+  __syncthreads();
+
+  // ---- factorisation, one pose block (6 columns) per step
+  for (int kb = 0; kb < n_free; ++kb) {
+    const int j0 = 6 * kb;
+    if (t == 0) {  // 6x6 diagonal block
+      double A[6][6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) A[i][j] = bref(j0 + i, j0 + j);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        double d = A[j][j];
+#pragma unroll
+        for (int m = 0; m < j; ++m) d -= A[j][m] * A[j][m];
+        if (!(d > 0.0)) { *failp = 1; d = 1.0; }
+        const double rl = rsqrt_nr(d);
+        A[j][j] = d * rl;
+        rd[j] = rl;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+          double sacc = A[i][j];
+#pragma unroll
+          for (int m = 0; m < j; ++m) sacc -= A[i][m] * A[j][m];
+          A[i][j] = sacc * rl;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) { bref(j0 + i, j0 + j) = A[i][j]; blk[i * 7 + j] = A[i][j]; }
+    }
+    __syncthreads();
+    // panel: pose rows (j0+6 .. re) and all tail rows: x = a Lkk^-T
+    const int re = min(npr, 6 * (kb + bandblk + 1));
+    const int nr = max(re - (j0 + 6), 0);
+    for (int pr = t; pr < nr + ntail; pr += BAND_T) {
+      double* row = pr < nr ? &bref(j0 + 6 + pr, j0) : &tref(pr - nr, j0);
+      double x[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        double sacc = row[j];
+#pragma unroll
+        for (int m = 0; m < j; ++m) sacc -= x[m] * blk[j * 7 + m];
+        x[j] = sacc * rd[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) row[j] = x[j];
+    }
+    __syncthreads();
+    // trailing update over the affected rows: (a, b) with b <= a; pose rows index 0..nr-1, tail rows nr..nr+ntail-1
+    const int na = nr + ntail;
+    for (int idx = t; idx < na * na; idx += BAND_T) {
+      const int ia = idx / na, ib = idx % na;
+      if (ib > ia) continue;
+      const bool ta = ia >= nr, tb = ib >= nr;
+      if (tb && ib - nr == ntail - 1) continue;  // the rhs row has no column
+      const double* pa = ta ? &tref(ia - nr, j0) : &bref(j0 + 6 + ia, j0);
+      const double* pb = tb ? &tref(ib - nr, j0) : &bref(j0 + 6 + ib, j0);
+      double sacc = 0.0;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) sacc += pa[m] * pb[m];
+      const int cb = tb ? npr + (ib - nr) : j0 + 6 + ib;  // global column of b
+      if (ta) tref(ia - nr, cb) -= sacc;
+      else bref(j0 + 6 + ia, cb) -= sacc;
+    }
+    __syncthreads();
+  }
+  // ---- tail columns (intrinsics unknowns), unblocked
+  const int F = ntail - 1;
+  for (int f = 0; f < F; ++f) {
+    const int cf = npr + f;
+    if (t == 0) {
+      double d = tref(f, cf);
+      if (!(d > 0.0)) { *failp = 1; d = 1.0; }
+      const double rl = rsqrt_nr(d);
+      tref(f, cf) = d * rl;
+      for (int q = f + 1; q < ntail; ++q) tref(q, cf) *= rl;
+      for (int q = f + 1; q < ntail; ++q)
+        for (int q2 = f + 1; q2 <= q && q2 < ntail - 1; ++q2) tref(q, npr + q2) -= tref(q, cf) * tref(q2, cf);
+    }
+    __syncthreads();
+  }
+  // ---- back substitution L^T x = y; y = rhs row (tail row F), solved in place
+  double* y = &tref(F, 0);
+  if (t == 0) {
+    for (int f = F - 1; f >= 0; --f) {
+      double sacc = y[npr + f];
+      for (int q = f + 1; q < F; ++q) sacc -= tref(q, npr + f) * y[npr + q];
+      y[npr + f] = sacc / tref(f, npr + f);
+    }
+  }
+  __syncthreads();
+  for (int kb = n_free - 1; kb >= 0; --kb) {
+    const int j0 = 6 * kb;
+    const int re = min(npr, 6 * (kb + bandblk + 1));
+    const int nr = max(re - (j0 + 6), 0);
+    // s_j = y[j0+j] - sum over rows below (band + intrinsics rows) L[r][j0+j] x[r]: one wave per column j
+    const int wv = t >> 6, ln = t & 63;
+    if (wv < 6) {
+      float dummy = 0.f;
+      (void)dummy;
+      double part = 0.0;
+      for (int q = ln; q < nr + F; q += 64) {
+        const double lv = q < nr ? bref(j0 + 6 + q, j0 + wv) : tref(q - nr, j0 + wv);
+        const double xv = q < nr ? y[j0 + 6 + q] : y[npr + (q - nr)];
+        part += lv * xv;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, WAVE);
+      if (ln == 0) xs[wv] = y[j0 + wv] - part;
+    }
+    __syncthreads();
+    if (t == 0) {
+      double x[6];
+#pragma unroll
+      for (int j = 5; j >= 0; --j) {
+        double sacc = xs[j];
+#pragma unroll
+        for (int m = 5; m > j; --m) sacc -= bref(j0 + m, j0 + j) * x[m];
+        x[j] = sacc / bref(j0 + j, j0 + j);
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) y[j0 + j] = x[j];
+    }
+    __syncthreads();
+  }
+  const bool bad = *failp != 0;
+  if (t == 0) {
+    if (bad) w.info[2] += 1;
+    w.info[5] = 1;
+  }
+  for (int dd = t; dd < n; dd += BAND_T) {
+    double x = y[dd];
+    if (bad || !(x == x)) x = 0.0;
+    w.dx[dd] = (float)x;
+  }
+  __syncthreads();
+  apply_retraction(a, t, BAND_T, n_free);
+}
+
 // ------------------------------------------------------------------------------------------------ solve
 
 // Dense Cholesky solve of the reduced system by ONE workgroup (16 waves), fp64.
@@ -600,14 +826,7 @@ struct SolveLds {
   int fail;
 };
 
-// 1/sqrt(x) in fp64: hardware estimate + 2 Newton steps (avoids the long sqrt / divide sequences on the
-// factorisation's critical path)
-__device__ __forceinline__ double rsqrt_nr(double x) {
-  double r = __builtin_amdgcn_rsq(x);
-  r = r * (1.5 - 0.5 * x * r * r);
-  r = r * (1.5 - 0.5 * x * r * r);
-  return r;
-}
+
 
 __global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_cap, long long* dbg) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -623,7 +842,7 @@ __global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_c
   long long tacc[5] = {0, 0, 0, 0, 0};
 #define STAMP(i) if (dbg && t == 0) { long long tn = wall_clock64(); tacc[i] += tn - tprev; tprev = tn; }
   if (t == 0) sh.fail = 0;
-  if (n == 0) return;
+  if (n == 0 || w.info[5] == 1) return;
   // LM damping on the diagonal: += ep + lambda * diag(H)  (matrix.py:179-186)
   for (int dd = t; dd < n; dd += SOLVE_T) {
     const bool pose = dd < 6 * n_free;
@@ -856,22 +1075,7 @@ __global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_c
     w.dx[dd] = (float)x;
   }
   __syncthreads();
-  // retraction: poses X <- Exp(dx) X (retractor.py:27-29), intrinsics (retractor.py:50-62)
-  for (int sl = t; sl < n_free; sl += SOLVE_T) {
-    const int pidx = w.slot_pose[sl];
-    float xi[6];
-    for (int q = 0; q < 6; ++q) xi[q] = w.dx[6 * sl + q];
-    lie::SE3<float> X(a.poses + 7 * pidx);
-    (lie::SE3<float>::exp(xi) * X).store(a.poses + 7 * pidx);
-  }
-  if (prm.optimize_intrinsics && t == 0) {
-    const int F = 1 + a.D;
-    const float df = w.dx[6 * n_free];
-    for (int vq = 0; vq < prm.n_views; ++vq) {
-      float* I = a.intr + vq * (4 + a.D);
-      if (I[0] > 0) { I[0] += df; I[1] += df; if (F > 1) I[4] += 0.01f * w.dx[6 * n_free + 1]; }
-    }
-  }
+  apply_retraction(a, t, SOLVE_T, n_free);
 }
 
 // ------------------------------------------------------------------------------------------------ retract
@@ -926,8 +1130,10 @@ int run_iters(const BAArgs& a, hipStream_t s) {
   int panel_cap = (int)std::min<size_t>(nmax + 1, (150 * 1024 - fixed) / (NB * sizeof(double)));
   panel_cap = (panel_cap + 3) & ~3;
   const size_t solve_lds = fixed + (size_t)NB * panel_cap * sizeof(double);
+  const size_t band_lds = 158 * 1024;
   static bool attr_set = false;
   if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)ba_solve_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
@@ -936,6 +1142,7 @@ int run_iters(const BAArgs& a, hipStream_t s) {
     hipError_t e2 = hipMemsetAsync(a.w.Hd, 0, sizeof(double) * nmax, s);
     if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
     ba_accum_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
+    ba_solve_band_kernel<<<1, BAND_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)));
     ba_solve_kernel<<<1, SOLVE_T, solve_lds, s>>>(a, panel_cap, getenv("VIPE_BA_DEBUG_TIMING") ? (long long*)(a.w.Hd + nmax) : nullptr);
     if (!a.p.motion_only) ba_retract_kernel<F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
   }
