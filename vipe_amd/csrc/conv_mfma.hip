@@ -561,30 +561,44 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
   __syncthreads();
   {
     constexpr int PITCH = BMC + 4, CPP = BMC / 8;  // floats per staged pixel row, 8-channel chunks per pixel
+    constexpr int NIT = BP * CPP / 512, PSTEP = 512 / CPP;
     float* stage = reinterpret_cast<float*>(lds);
+    const int ch = (tid % CPP) * 8, co = cout0 + ch, pl0 = tid / CPP;
+    // the epilogue's global operands (hidden state, update gate) do not depend on the staged tile: issue every
+    // load now so that their latency overlaps the staging writes and the barrier instead of serialising the loop
+    const bool want_net = a.epi == EPI_GLO || a.epi == EPI_Q || (a.epi == EPI_ZR && co >= 128);
+    const bool want_z = a.epi == EPI_Q;
+    half8 nvv[NIT], zvv[NIT];
+    {
+      const int cn = a.epi == EPI_ZR ? co - 128 : co;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int pl = wn * 64 + pxh + j * 32 + lrow, co = wm * (TM * 32) + i * 32 + 8 * g + 4 * lhalf;
-          *reinterpret_cast<float4*>(stage + pl * PITCH + co) =
-              make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-        }
-    __syncthreads();
-    const int ch = (tid % CPP) * 8, co = cout0 + ch;
-    const int e = (int)(pix0 / HW);  // the tile lies inside one image
+      for (int it = 0; it < NIT; ++it) {
+        const int64_t m = pix0 + pl0 + PSTEP * it;
+        if (want_net) nvv[it] = *reinterpret_cast<const half8*>(a.net + m * a.net_ctot + a.net_coff + cn);
+        if (want_z) zvv[it] = *reinterpret_cast<const half8*>(a.zbuf + m * 128 + co);
+      }
+    }
     float bv[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       bv[q] = (co + q < a.Cout) ? a.bias[co + q] : 0.0f;
       if (a.extra && co + q < a.Cout) bv[q] += a.extra[(int64_t)e * a.extra_stride + a.extra_off + co + q];
     }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int pl = wn * 64 + pxh + j * 32 + lrow, cs = wm * (TM * 32) + i * 32 + 8 * g + 4 * lhalf;
+          *reinterpret_cast<float4*>(stage + pl * PITCH + cs) =
+              make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        }
+    __syncthreads();
     float gsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 2
-    for (int it = 0; it < BP * CPP / 512; ++it) {
-      const int pl = tid / CPP + (512 / CPP) * it;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int pl = pl0 + PSTEP * it;
       const int64_t m = pix0 + pl;
       const float4 v0 = *reinterpret_cast<const float4*>(stage + pl * PITCH + ch);
       const float4 v1 = *reinterpret_cast<const float4*>(stage + pl * PITCH + ch + 4);
@@ -596,28 +610,25 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
         for (int q = 0; q < 8; ++q) o[q] = (half_t)act_apply(v[q], a.act);
         dst = a.y + m * a.y_ctot + a.y_coff + co;
       } else if (a.epi == EPI_GLO) {
-        const half8 nv = *reinterpret_cast<const half8*>(a.net + m * a.net_ctot + a.net_coff + co);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) gsum[q] += (float)(half_t)act_apply(v[q], VIPE_ACT_SIGMOID) * (float)nv[q];
+        for (int q = 0; q < 8; ++q) gsum[q] += (float)(half_t)act_apply(v[q], VIPE_ACT_SIGMOID) * (float)nvv[it][q];
       } else if (a.epi == EPI_ZR) {
         if (co < 128) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) o[q] = (half_t)act_apply(v[q], VIPE_ACT_SIGMOID);
           dst = a.y + m * a.y_ctot + a.y_coff + co;
         } else {
-          const half8 nv = *reinterpret_cast<const half8*>(a.net + m * a.net_ctot + a.net_coff + co - 128);
 #pragma unroll
-          for (int q = 0; q < 8; ++q) o[q] = (half_t)((float)(half_t)act_apply(v[q], VIPE_ACT_SIGMOID) * (float)nv[q]);
+          for (int q = 0; q < 8; ++q)
+            o[q] = (half_t)((float)(half_t)act_apply(v[q], VIPE_ACT_SIGMOID) * (float)nvv[it][q]);
           dst = a.y2 + m * a.y2_ctot + a.y2_coff + co - 128;
         }
       } else if (a.epi == EPI_Q) {
-        const half8 nv = *reinterpret_cast<const half8*>(a.net + m * a.net_ctot + a.net_coff + co);
-        const half8 zv = *reinterpret_cast<const half8*>(a.zbuf + m * 128 + co);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const float qq = (float)(half_t)tanhf(v[q]);
-          const float z = (float)zv[q];
-          o[q] = (half_t)((1.0f - z) * (float)nv[q] + z * qq);  // droid_net.py:399
+          const float z = (float)zvv[it][q];
+          o[q] = (half_t)((1.0f - z) * (float)nvv[it][q] + z * qq);  // droid_net.py:399
         }
         dst = a.y + m * a.y_ctot + a.y_coff + co;
       } else if (a.epi == EPI_HEADS) {
@@ -641,13 +652,16 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
       }
     }
     if (a.epi == EPI_GLO) {
-      // lanes l, l^16, l^32, l^48 hold the same 8 channels (4 different pixels): fold, then one atomic per channel
+      // threads with equal tid % CPP hold the same 8 channels (different pixels): fold them through LDS (the staged
+      // tile is dead after the barrier), then ONE atomic per channel and workgroup
+      __syncthreads();
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        float t = gsum[q];
-        t += __shfl_xor(t, 16, WAVE);
-        t += __shfl_xor(t, 32, WAVE);
-        if (lane < 16 && co + q < a.Cout) atomicAdd(a.fout + (int64_t)e * a.Cout + co + q, t);
+      for (int q = 0; q < 8; ++q) stage[(tid / CPP) * (BMC + 1) + ch + q] = gsum[q];
+      __syncthreads();
+      if (tid < BMC) {
+        float t = 0.0f;
+        for (int r = 0; r < 512 / CPP; ++r) t += stage[r * (BMC + 1) + tid];
+        if (cout0 + tid < a.Cout) atomicAdd(a.fout + (int64_t)e * a.Cout + cout0 + tid, t);
       }
     }
   }
