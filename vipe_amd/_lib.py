@@ -67,11 +67,12 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("VIPE_AMD_LIB", LIB_PATH)  # override: diagnostic builds of the same library
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"{LIB_PATH} is missing - the HIP backend is mandatory (there is no CPU fallback). "
+                f"{path} is missing - the HIP backend is mandatory (there is no CPU fallback). "
                 "Build it with `python -m vipe_amd.build` (hipcc --offload-arch=gfx950).")
-        L = ctypes.CDLL(LIB_PATH)
+        L = ctypes.CDLL(path)
         for name, (restype, argtypes) in parse_header().items():
             fn = getattr(L, name)  # AttributeError here means header and library disagree
             fn.restype = restype

@@ -208,6 +208,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 // Out-of-image taps / channels >= Cin read a 16-byte zero page instead.  Blocks are remapped so that
 // consecutive logical tiles (and the cout tiles of one pixel tile) run on the same XCD and share its L2.
 __device__ __attribute__((aligned(16))) unsigned char g_zero_page[64];
+#ifdef VIPE_CONV_STAMPS
+// diagnostic build only (scratch/conv_stamps.py): per-workgroup phase stamps {s_memrealtime, s_memtime} x 5
+__device__ unsigned long long* g_stamps = nullptr;
+#define CONV_STAMP(k)                                                                   \
+  do {                                                                                  \
+    if (g_stamps && threadIdx.x == 0) {                                                 \
+      g_stamps[(size_t)blockIdx.x * 12 + 2 * (k)] = __builtin_amdgcn_s_memrealtime();   \
+      g_stamps[(size_t)blockIdx.x * 12 + 2 * (k) + 1] = __builtin_amdgcn_s_memtime();   \
+    }                                                                                   \
+  } while (0)
+#else
+#define CONV_STAMP(k)
+#endif
 
 // 16 bytes per lane, global -> LDS (wave-uniform LDS byte address + lane * 16), as inline asm: hipcc orders every
 // later LDS read behind a visible LDS-DMA with s_waitcnt vmcnt(0), which would serialise load and compute; hidden
@@ -371,10 +384,13 @@ __device__ __forceinline__ void glds16_off(const void* base, unsigned voff_bytes
 #if defined(__HIP_DEVICE_COMPILE__)
   unsigned keep;
   const unsigned lb = __builtin_amdgcn_readfirstlane(lds_addr);
+  const uint64_t bu = (uint64_t)base;  // wave-uniform by construction; make that explicit for the "s" constraint
+  const uint64_t bs = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(bu >> 32)) << 32) |
+                      (unsigned)__builtin_amdgcn_readfirstlane((int)bu);
   asm volatile(
       "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
       : "=&s"(keep)
-      : "v"(voff_bytes), "s"(base), "s"(lb)
+      : "v"(voff_bytes), "s"(bs), "s"(lb)
       : "memory");
 #endif
 }
@@ -388,6 +404,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
   unsigned char* ldsW = lds;                          // [3][BMC rows * 128 B] weight ring
   unsigned char* ldsX = lds + 3 * BMC * 128;          // [2][400 rows * 128 B] halo double buffer, then 2 KiB sink
 
+  CONV_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = BMC == 32 ? 0 : (wave >> 2), wn = wave & 3;  // cout half, image row of the tile
   const int pxh = BMC == 32 ? (wave >> 2) * 32 : 0;           // BMC = 32: which half of the row
@@ -502,6 +519,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
   if constexpr (KS == 3) issueW_at(wtile0 + tapstride, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  CONV_STAMP(1);
 
   if constexpr (KS == 3) {
     for (int c = 0; c < csteps; ++c) {
@@ -559,6 +577,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
   // channels of one pixel: 16-byte loads of net / z, 16-byte stores, 256 contiguous bytes per pixel.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  CONV_STAMP(2);
   {
     constexpr int PITCH = BMC + 4, CPP = BMC / 8;  // floats per staged pixel row, 8-channel chunks per pixel
     constexpr int NIT = BP * CPP / 512, PSTEP = 512 / CPP;
@@ -595,6 +614,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
               make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
         }
     __syncthreads();
+    CONV_STAMP(3);
     float gsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -665,6 +685,344 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
       }
     }
   }
+  CONV_STAMP(4);
+}
+
+// ---- Halo-tile kernel, K step 32: TWO workgroups per CU.
+// Same tile (8 waves: 4 image rows x 64 px x BMC couts) and the same halo idea as above, but the channel chunk is 32
+// (64-byte LDS rows): halo double buffer 2 x 25 KiB + weight ring 3 x 8 KiB = 75 KiB, so two workgroups share a CU
+// (4 waves per SIMD) and one workgroup's prologue / epilogue / barrier stalls are covered by the other's MFMAs
+// (measured on the 64-channel kernel: 12 us of 27..63 us per workgroup were spent outside the K loop with nothing
+// to overlap them).  The epilogue applies bias + activation in the accumulator layout and stages the tile as fp16
+// (69 KiB), then every lane blends / stores 8 consecutive channels of one pixel.
+// LDS rows are 4 chunks of 16 B; logical chunk c of row r sits at slot c ^ ((r >> 2) & 3): the 16-lane groups of a
+// ds_read_b128 (rows r0 + {0..3, 12..15, 20..27}, one logical chunk) then cover 16 distinct 16-byte slots of the
+// 256-byte bank window for every window shift r0.
+constexpr int H32_PIECES = (HALO_ROWS + 15) / 16;  // 25 one-KiB pieces (16 rows x 64 B) per halo chunk
+constexpr int H32_XBYTES = H32_PIECES * 1024;      // 25600
+constexpr int H32_XP = (H32_PIECES + 7) / 8;       // pieces per wave (4)
+constexpr int H32_BK = 32;
+
+__device__ __forceinline__ int swz32(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
+
+constexpr size_t halo32_lds_bytes(int bmc) { return 3 * (size_t)bmc * 64 + 2 * H32_XBYTES + 1024; }
+
+template <int BMC, int KS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_halo32_kernel(ConvArgs a, int gy) {
+  constexpr int TM = BMC >= 128 ? 2 : 1, TN = BMC == 32 ? 1 : 2, BP = HALO_TH * HALO_TW;
+  constexpr int WSTAGE = BMC * 64;  // bytes per weight ring slot
+  extern __shared__ __align__(16) unsigned char lds[];
+  CONV_STAMP(0);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = BMC == 32 ? 0 : (wave >> 2), wn = wave & 3;  // cout half, image row of the tile
+  const int pxh = BMC == 32 ? (wave >> 2) * 32 : 0;           // BMC = 32: which half of the row
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = L / gy, cout0 = (L % gy) * BMC;
+  const int tiles_per_img = a.H / HALO_TH;
+  const int e = tile / tiles_per_img, y0 = (tile % tiles_per_img) * HALO_TH;
+  const int64_t pix0 = (int64_t)tile * BP;
+  const int cs32 = a.Cin_pad / H32_BK, cs64 = a.Cin_pad / 64;
+  const int r16 = lane >> 2, sl = lane & 3;
+  const int lrow = lane & 31, lhalf = lane >> 5;
+
+  const unsigned ldsW_a = lds_address(lds), ldsX_a = ldsW_a + 3 * WSTAGE;
+  const unsigned sink_a = ldsX_a + 2 * H32_XBYTES;  // 1 KiB sink for the count-keeping dummy DMAs
+  const unsigned char* ldsW = lds;
+  const unsigned char* ldsX = lds + 3 * WSTAGE;
+  const half_t* zp = reinterpret_cast<const half_t*>(g_zero_page);
+
+  // ---- DMA descriptors
+  constexpr int WPIECES = BMC / 16;  // 1-KiB pieces per weight slot: 8 / 4 / 2 -> waves 0..WPIECES-1 carry one each
+  const bool wreal = wave < WPIECES;
+  const int wrow = (wave % WPIECES) * 16 + r16;
+  const unsigned woff = (unsigned)(wrow * 64 + ((sl ^ ((wrow >> 2) & 3)) << 3)) * 2u;
+  const unsigned wdst = ldsW_a + (wave % WPIECES) * 1024;
+  unsigned xo0[H32_XP], xo1[H32_XP];
+  int xk[H32_XP];
+  const unsigned BAD = 0xffffffffu;
+#pragma unroll
+  for (int i = 0; i < H32_XP; ++i) {
+    const int pce = wave + 8 * i;
+    const int r = pce * 16 + r16;
+    const int hy = r / HALO_PITCH, hx = r % HALO_PITCH;
+    const int y = y0 + hy - 1, x = hx - 1;
+    const bool ok = pce < H32_PIECES && r < HALO_ROWS && y >= 0 && y < a.H && x >= 0 && x < a.W;
+    const int k4 = sl ^ ((r >> 2) & 3);
+    xk[i] = k4 * 8;
+    const int64_t pix = ok ? ((int64_t)(e * a.H + y) * a.W + x) : 0;
+    xo0[i] = ok ? (unsigned)((pix * a.x0_ctot + a.x0_coff + k4 * 8) * 2) : BAD;
+    xo1[i] = ok ? (unsigned)((pix * a.x1_ctot + a.x1_coff + k4 * 8 - a.split) * 2) : BAD;
+  }
+  // a 1x1 reads only the tile's own rows: pieces 4..20 hold halo rows 64..335
+  auto piece_used = [&](int i) {
+    const int pce = wave + 8 * i;
+    return pce < H32_PIECES && (KS == 3 || (pce >= 4 && pce <= 20));
+  };
+  auto issueX = [&](int c, int i, int buf) {
+    const int c0 = c * H32_BK;
+    const bool s0 = c0 < a.split;
+    const unsigned off = s0 ? xo0[i] : xo1[i];
+    const bool ok = off != BAD && (c0 + xk[i] < a.Cin);
+    const char* src = reinterpret_cast<const char*>(s0 ? a.x0 : a.x1) + (off + (unsigned)c0 * 2u);
+    glds16(ok ? (const void*)src : (const void*)zp, ldsX_a + buf * H32_XBYTES + (wave + 8 * i) * 1024);
+  };
+  // weights of K-step (tap, c): the 64-byte half (c & 1) of rows cout0.. of packed block tap * cs64 + c / 2
+  auto wsrc = [&](int tap, int c) {
+    return a.w + ((int64_t)(tap * cs64 + (c >> 1)) * a.Cout_pad + cout0) * BK + (c & 1) * H32_BK;
+  };
+  auto issueW = [&](const half_t* wb, int slot) {
+    if (wreal) glds16_off(wb, woff, wdst + slot * WSTAGE);
+    else glds16(zp, sink_a);
+  };
+
+  float16v acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  // fragment read addresses: weights are fixed per lane; the activation window of tap (dy, dx) starts at halo row
+  // (wn + dy + 1) * 66 + pxh + lrow + dx + 1.  kk = 1 flips chunk bit 1 (byte offset ^ 32).
+  const int wa0 = swz32(wm * TM * 32 + lrow, lhalf);
+  auto mma_step = [&](const unsigned char* bw, const unsigned char* bx, int dy, int dx) {
+    const int xa0 = swz32((wn + dy + 1) * HALO_PITCH + (pxh + lrow + dx + 1), lhalf);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      half8 wf[TM], xf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) wf[i] = *reinterpret_cast<const half8*>(bw + ((wa0 ^ (kk << 5)) + i * 2048));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) xf[j] = *reinterpret_cast<const half8*>(bx + ((xa0 ^ (kk << 5)) + j * 2048));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- prologue: halo chunk 0, weights of steps 0 and 1
+#pragma unroll
+  for (int i = 0; i < H32_XP; ++i)
+    if (piece_used(i)) issueX(0, i, 0);
+  issueW(wsrc(0, 0), 0);
+  if constexpr (KS == 3) issueW(wsrc(1, 0), 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  CONV_STAMP(1);
+
+  if constexpr (KS == 3) {
+    // 9 taps fully unrolled: ring slot = tap % 3, tap offsets and the per-tap s_waitcnt count are compile-time.
+    // Every tap issues one weight DMA (step + 2); taps 0..3 also one halo piece of the next chunk (dummies keep the
+    // count when there is nothing to fetch).  At the end of tap t the DMAs younger than W(step + 1) are
+    // {X_t (t < 4), W(step + 2), X_{t-1} (1 <= t <= 4)}: vmcnt(2,3,3,3,2,1,1,1,1).  A halo piece issued at tap t <= 3 has
+    // landed by the end of tap 5, before the chunk ends.
+    for (int c = 0; c < cs32; ++c) {
+      const unsigned char* bx = ldsX + (c & 1) * H32_XBYTES;
+      const bool more = c + 1 < cs32;
+      auto tap_step = [&](auto TAPC) {
+        constexpr int TAP = decltype(TAPC)::value;
+        constexpr int T2 = TAP + 2;
+        if constexpr (T2 < 9) {
+          issueW(wsrc(T2, c), T2 % 3);
+        } else {
+          if (more) issueW(wsrc(T2 - 9, c + 1), T2 % 3);
+          else glds16(zp, sink_a);
+        }
+        if constexpr (TAP < H32_XP) {
+          if (more && piece_used(TAP)) issueX(c + 1, TAP, (c + 1) & 1);
+          else glds16(zp, sink_a);
+        }
+        mma_step(ldsW + (TAP % 3) * WSTAGE, bx, TAP / 3 - 1, TAP % 3 - 1);
+        if constexpr (TAP == 0 || TAP == 4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if constexpr (TAP < 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        __syncthreads();
+      };
+      tap_step(std::integral_constant<int, 0>{});
+      tap_step(std::integral_constant<int, 1>{});
+      tap_step(std::integral_constant<int, 2>{});
+      tap_step(std::integral_constant<int, 3>{});
+      tap_step(std::integral_constant<int, 4>{});
+      tap_step(std::integral_constant<int, 5>{});
+      tap_step(std::integral_constant<int, 6>{});
+      tap_step(std::integral_constant<int, 7>{});
+      tap_step(std::integral_constant<int, 8>{});
+    }
+  } else {
+    for (int c = 0; c < cs32; ++c) {
+      const unsigned char* bx = ldsX + (c & 1) * H32_XBYTES;
+      if (c + 1 < cs32) {
+        issueW(wsrc(0, c + 1), (c + 1) & 1);
+#pragma unroll
+        for (int i = 0; i < H32_XP; ++i)
+          if (piece_used(i)) issueX(c + 1, i, (c + 1) & 1);
+      }
+      mma_step(ldsW + (c & 1) * WSTAGE, bx, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  CONV_STAMP(2);
+
+  // ---- epilogue
+  constexpr int CPP = BMC / 8;  // 8-channel chunks per pixel
+  constexpr int NIT = BP * CPP / 512, PSTEP = 512 / CPP;
+  const int ch = (tid % CPP) * 8, co = cout0 + ch, pl0 = tid / CPP;
+  if constexpr (BMC >= 64) {
+    constexpr int PITCH = BMC + 8;  // halves per staged pixel
+    half_t* stage = reinterpret_cast<half_t*>(lds);
+    auto stage_all = [&](auto ACTC) {
+      constexpr int ACT = decltype(ACTC)::value;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int cl = wm * (TM * 32) + i * 32 + 8 * g + 4 * lhalf, cg = cout0 + cl;
+          float4 b = *reinterpret_cast<const float4*>(a.bias + cg);
+          if (a.extra && cg + 4 <= a.Cout) {
+            const float4 x = *reinterpret_cast<const float4*>(a.extra + (int64_t)e * a.extra_stride + a.extra_off + cg);
+            b.x += x.x; b.y += x.y; b.z += x.z; b.w += x.w;
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int pl = wn * 64 + j * 32 + lrow;
+            half4 h;
+            h[0] = (half_t)act_apply(acc[i][j][4 * g] + b.x, ACT);
+            h[1] = (half_t)act_apply(acc[i][j][4 * g + 1] + b.y, ACT);
+            h[2] = (half_t)act_apply(acc[i][j][4 * g + 2] + b.z, ACT);
+            h[3] = (half_t)act_apply(acc[i][j][4 * g + 3] + b.w, ACT);
+            *reinterpret_cast<half4*>(stage + pl * PITCH + cl) = h;
+          }
+        }
+    };
+    const int actsel = a.epi == EPI_PLAIN ? a.act : (a.epi == EPI_Q ? VIPE_ACT_TANH : VIPE_ACT_SIGMOID);
+    if (actsel == VIPE_ACT_RELU) stage_all(std::integral_constant<int, VIPE_ACT_RELU>{});
+    else if (actsel == VIPE_ACT_SIGMOID) stage_all(std::integral_constant<int, VIPE_ACT_SIGMOID>{});
+    else if (actsel == VIPE_ACT_TANH) stage_all(std::integral_constant<int, VIPE_ACT_TANH>{});
+    else stage_all(std::integral_constant<int, VIPE_ACT_NONE>{});
+    // global operands of the blend (hidden state, update gate): issued before the barrier
+    const bool want_net = a.epi == EPI_GLO || a.epi == EPI_Q || (a.epi == EPI_ZR && co >= 128);
+    const bool want_z = a.epi == EPI_Q;
+    half8 nvv[NIT], zvv[NIT];
+    {
+      const int cn = a.epi == EPI_ZR ? co - 128 : co;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int64_t m = pix0 + pl0 + PSTEP * it;
+        if (want_net) nvv[it] = *reinterpret_cast<const half8*>(a.net + m * a.net_ctot + a.net_coff + cn);
+        if (want_z) zvv[it] = *reinterpret_cast<const half8*>(a.zbuf + m * 128 + co);
+      }
+    }
+    __syncthreads();
+    CONV_STAMP(3);
+    float gsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int pl = pl0 + PSTEP * it;
+      const int64_t m = pix0 + pl;
+      const half8 sv = *reinterpret_cast<const half8*>(stage + pl * PITCH + ch);
+      half8 o = sv;
+      half_t* dst = nullptr;
+      if (a.epi == EPI_PLAIN) {
+        dst = a.y + m * a.y_ctot + a.y_coff + co;
+      } else if (a.epi == EPI_GLO) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) gsum[q] += (float)sv[q] * (float)nvv[it][q];
+      } else if (a.epi == EPI_ZR) {
+        if (co < 128) {
+          dst = a.y + m * a.y_ctot + a.y_coff + co;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) o[q] = (half_t)((float)sv[q] * (float)nvv[it][q]);
+          dst = a.y2 + m * a.y2_ctot + a.y2_coff + co - 128;
+        }
+      } else if (a.epi == EPI_Q) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float z = (float)zvv[it][q];
+          o[q] = (half_t)((1.0f - z) * (float)nvv[it][q] + z * (float)sv[q]);  // droid_net.py:399
+        }
+        dst = a.y + m * a.y_ctot + a.y_coff + co;
+      }
+      if (dst) {
+        if (co + 8 <= a.Cout) {
+          *reinterpret_cast<half8*>(dst) = o;
+        } else {
+          for (int q = 0; q < 8 && co + q < a.Cout; ++q) dst[q] = o[q];
+        }
+      }
+    }
+    if (a.epi == EPI_GLO) {
+      // threads with equal tid % CPP hold the same 8 channels (different pixels): fold through LDS, then ONE
+      // atomic per channel and workgroup
+      float* red = reinterpret_cast<float*>(lds);
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 8; ++q) red[(tid / CPP) * (BMC + 1) + ch + q] = gsum[q];
+      __syncthreads();
+      if (tid < BMC) {
+        float t = 0.0f;
+        for (int r = 0; r < 512 / CPP; ++r) t += red[r * (BMC + 1) + tid];
+        if (cout0 + tid < a.Cout) atomicAdd(a.fout + (int64_t)e * a.Cout + cout0 + tid, t);
+      }
+    }
+  } else {
+    // BMC = 32 (flow / confidence heads, eta, narrow plain convs): fp32 staging, activation after it
+    constexpr int PITCH = BMC + 4;
+    float* stage = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int pl = wn * 64 + pxh + lrow, cs = 8 * g + 4 * lhalf;
+      *reinterpret_cast<float4*>(stage + pl * PITCH + cs) =
+          make_float4(acc[0][0][4 * g], acc[0][0][4 * g + 1], acc[0][0][4 * g + 2], acc[0][0][4 * g + 3]);
+    }
+    __syncthreads();
+    CONV_STAMP(3);
+    float bv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      bv[q] = a.bias[co + q];
+      if (a.extra && co + q < a.Cout) bv[q] += a.extra[(int64_t)e * a.extra_stride + a.extra_off + co + q];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int pl = pl0 + PSTEP * it;
+      const int64_t m = pix0 + pl;
+      const float4 v0 = *reinterpret_cast<const float4*>(stage + pl * PITCH + ch);
+      const float4 v1 = *reinterpret_cast<const float4*>(stage + pl * PITCH + ch + 4);
+      const float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3],
+                          v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
+      if (a.epi == EPI_HEADS) {
+        // cout 0,1: delta; cout 2,3: sigmoid -> weight (droid_net.py:486-490); written as float [M,4]
+        if (ch == 0)
+          *reinterpret_cast<float4*>(a.fout + m * 4) =
+              make_float4((float)(half_t)v[0], (float)(half_t)v[1], (float)(half_t)act_apply(v[2], VIPE_ACT_SIGMOID),
+                          (float)(half_t)act_apply(v[3], VIPE_ACT_SIGMOID));
+      } else if (a.epi == EPI_ETA) {
+        if (ch == 0) {  // 0.01 * softplus (droid_net.py:410,429)
+          const float sp = v[0] > 20.0f ? v[0] : log1pf(__expf(v[0]));
+          a.fout[m] = 0.01f * (float)(half_t)sp;
+        }
+      } else {
+        half_t* dst = a.y + m * a.y_ctot + a.y_coff + co;
+        half8 o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = (half_t)act_apply(v[q], a.act);
+        if (co + 8 <= a.Cout) {
+          *reinterpret_cast<half8*>(dst) = o;
+        } else {
+          for (int q = 0; q < 8 && co + q < a.Cout; ++q) dst[q] = o[q];
+        }
+      }
+    }
+  }
+  CONV_STAMP(4);
 }
 
 // OIHW (fp16 or fp32) -> packed [K_pad/64][Cout_pad][64] fp16, k = tap*Cin_pad + c (generic) or tap*4 + c (Cin == 4)
@@ -695,6 +1053,13 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // ---- C ABI ------------------------------------------------------------------------------------------------
 
 extern "C" {
+
+#ifdef VIPE_CONV_STAMPS
+VIPE_EXPORT int vipe_diag_set_conv_stamps(void* d_buf) {
+  unsigned long long* p = (unsigned long long*)d_buf;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p));
+}
+#endif
 
 // Geometry helpers shared with the Python side: padded sizes of the packed weight tensor.
 VIPE_EXPORT int vipe_conv_packed_dims(int Cout, int Cin, int KH, int KW, int* cout_pad, int* cin_pad, int* k_pad) {
@@ -747,6 +1112,33 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
   const bool halo = glds && a.W == HALO_TW && a.H % HALO_TH == 0 && a.KH == a.KW && (a.KH == 1 || a.KH == 3) &&
                     (int64_t)a.B * a.H * a.W * (a.x0_ctot > a.x1_ctot ? a.x0_ctot : a.x1_ctot) * 2 < (1ll << 32) &&
                     getenv("VIPE_AMD_CONV_NOHALO") == nullptr;
+  if (halo && (a.split >= a.Cin || a.split % H32_BK == 0) && getenv("VIPE_AMD_CONV_HALO64") == nullptr) {
+    static bool h32attr = false;
+    const int bmc = cp >= 128 ? 128 : cp;
+    if (!h32attr) {
+      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(128));
+      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(64));
+      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<32, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(32));
+      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(128));
+      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(64));
+      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(32));
+      h32attr = true;
+    }
+    const int gy = cp >= 128 ? cp / 128 : 1;
+    const int tiles = (int)(M / (HALO_TH * HALO_TW));
+    const dim3 grid(tiles * gy);
+    const size_t lds = halo32_lds_bytes(bmc);
+    if (a.KH == 3) {
+      if (bmc == 128) conv_halo32_kernel<128, 3><<<grid, 512, lds, s>>>(a, gy);
+      else if (bmc == 64) conv_halo32_kernel<64, 3><<<grid, 512, lds, s>>>(a, 1);
+      else conv_halo32_kernel<32, 3><<<grid, 512, lds, s>>>(a, 1);
+    } else {
+      if (bmc == 128) conv_halo32_kernel<128, 1><<<grid, 512, lds, s>>>(a, gy);
+      else if (bmc == 64) conv_halo32_kernel<64, 1><<<grid, 512, lds, s>>>(a, 1);
+      else conv_halo32_kernel<32, 1><<<grid, 512, lds, s>>>(a, 1);
+    }
+    return vipe_launch_status();
+  }
   if (halo) {
     static bool hattr = false;
     const int bmc = cp >= 128 ? 128 : cp;
