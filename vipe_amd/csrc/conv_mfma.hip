@@ -28,6 +28,7 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
+typedef float float4v __attribute__((ext_vector_type(4)));
 
 enum Epi { EPI_PLAIN = 0, EPI_GLO = 1, EPI_ZR = 2, EPI_Q = 3, EPI_HEADS = 4, EPI_ETA = 5 };
 
@@ -703,13 +704,22 @@ constexpr int H32_XBYTES = H32_PIECES * 1024;      // 25600
 constexpr int H32_XP = (H32_PIECES + 7) / 8;       // pieces per wave (4)
 constexpr int H32_BK = 32;
 
-__device__ __forceinline__ int swz32(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
+// chunk swizzle of a 64-byte row.  32x32x16 fragments (16-lane read groups = rows r0 + {0..3, 12..15, 20..27}, one
+// logical chunk): c ^ ((r >> 2) & 3).  16x16x32 fragments (read groups = rows r0 + {0..3, 12..15} with chunk kc and
+// rows r0 + {4..11} with chunk kc ^ 1): c ^ 2 * ((r >> 2) & 1) - both cover 16 distinct 16-byte slots for every r0.
+template <bool M16>
+__device__ __forceinline__ int swzf(int row) { return M16 ? ((row >> 2) & 1) << 1 : (row >> 2) & 3; }
+template <bool M16>
+__device__ __forceinline__ int swz32(int row, int c) { return row * 64 + ((c ^ swzf<M16>(row)) << 4); }
 
 constexpr size_t halo32_lds_bytes(int bmc) { return 3 * (size_t)bmc * 64 + 2 * H32_XBYTES + 1024; }
 
-template <int BMC, int KS>
+template <int BMC, int KS, bool M16>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_halo32_kernel(ConvArgs a, int gy) {
+  // M16: v_mfma_f32_16x16x32_f16 (one instruction per 32-channel step and 16 x 16 tile; the chip holds a higher
+  // clock on this shape, MI355X_MICROARCH.md 'DVFS give-back' (7)); otherwise 32x32x16.
   constexpr int TM = BMC >= 128 ? 2 : 1, TN = BMC == 32 ? 1 : 2, BP = HALO_TH * HALO_TW;
+  constexpr int MI = TM * 2, NJ = TN * 2;  // 16 x 16 tiles per wave (M16)
   constexpr int WSTAGE = BMC * 64;  // bytes per weight ring slot
   extern __shared__ __align__(16) unsigned char lds[];
   CONV_STAMP(0);
@@ -736,11 +746,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   constexpr int WPIECES = BMC / 16;  // 1-KiB pieces per weight slot: 8 / 4 / 2 -> waves 0..WPIECES-1 carry one each
   const bool wreal = wave < WPIECES;
   const int wrow = (wave % WPIECES) * 16 + r16;
-  const unsigned woff = (unsigned)(wrow * 64 + ((sl ^ ((wrow >> 2) & 3)) << 3)) * 2u;
+  const unsigned woff = (unsigned)(wrow * 64 + ((sl ^ swzf<M16>(wrow)) << 3)) * 2u;
   const unsigned wdst = ldsW_a + (wave % WPIECES) * 1024;
-  unsigned xo0[H32_XP], xo1[H32_XP];
-  int xk[H32_XP];
-  const unsigned BAD = 0xffffffffu;
+  // halo pieces: one VGPR each (pixel index of this lane's halo row, or -1 outside the image); the lane's channel
+  // chunk is the same for every piece because (16 * piece) >> 2 is a multiple of 4
+  int xpix[H32_XP];
+  const int xk = (sl ^ swzf<M16>(r16)) * 8;
 #pragma unroll
   for (int i = 0; i < H32_XP; ++i) {
     const int pce = wave + 8 * i;
@@ -748,11 +759,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int hy = r / HALO_PITCH, hx = r % HALO_PITCH;
     const int y = y0 + hy - 1, x = hx - 1;
     const bool ok = pce < H32_PIECES && r < HALO_ROWS && y >= 0 && y < a.H && x >= 0 && x < a.W;
-    const int k4 = sl ^ ((r >> 2) & 3);
-    xk[i] = k4 * 8;
-    const int64_t pix = ok ? ((int64_t)(e * a.H + y) * a.W + x) : 0;
-    xo0[i] = ok ? (unsigned)((pix * a.x0_ctot + a.x0_coff + k4 * 8) * 2) : BAD;
-    xo1[i] = ok ? (unsigned)((pix * a.x1_ctot + a.x1_coff + k4 * 8 - a.split) * 2) : BAD;
+    xpix[i] = ok ? (e * a.H + y) * a.W + x : -1;
   }
   // a 1x1 reads only the tile's own rows: pieces 4..20 hold halo rows 64..335
   auto piece_used = [&](int i) {
@@ -761,10 +768,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   };
   auto issueX = [&](int c, int i, int buf) {
     const int c0 = c * H32_BK;
-    const bool s0 = c0 < a.split;
-    const unsigned off = s0 ? xo0[i] : xo1[i];
-    const bool ok = off != BAD && (c0 + xk[i] < a.Cin);
-    const char* src = reinterpret_cast<const char*>(s0 ? a.x0 : a.x1) + (off + (unsigned)c0 * 2u);
+    const bool s0 = c0 < a.split;  // wave-uniform
+    const int ctot = s0 ? a.x0_ctot : a.x1_ctot;
+    const int cb = (s0 ? a.x0_coff : a.x1_coff - a.split) + c0;
+    const bool ok = xpix[i] >= 0 && (c0 + xk < a.Cin);
+    const unsigned off = ((unsigned)xpix[i] * (unsigned)ctot + (unsigned)(cb + xk)) * 2u;
+    const char* src = reinterpret_cast<const char*>(s0 ? a.x0 : a.x1) + off;
     glds16(ok ? (const void*)src : (const void*)zp, ldsX_a + buf * H32_XBYTES + (wave + 8 * i) * 1024);
   };
   // weights of K-step (tap, c): the 64-byte half (c & 1) of rows cout0.. of packed block tap * cs64 + c / 2
@@ -776,31 +785,59 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     else glds16(zp, sink_a);
   };
 
-  float16v acc[TM][TN];
+  float16v acc[M16 ? 1 : TM][M16 ? 1 : TN];
+  float4v acc16[M16 ? MI : 1][M16 ? NJ : 1];
+  if constexpr (M16) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < NJ; ++j) acc16[i][j] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+  } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  }
 
   // fragment read addresses: weights are fixed per lane; the activation window of tap (dy, dx) starts at halo row
-  // (wn + dy + 1) * 66 + pxh + lrow + dx + 1.  kk = 1 flips chunk bit 1 (byte offset ^ 32).
-  const int wa0 = swz32(wm * TM * 32 + lrow, lhalf);
-  auto mma_step = [&](const unsigned char* bw, const unsigned char* bx, int dy, int dx) {
-    const int xa0 = swz32((wn + dy + 1) * HALO_PITCH + (pxh + lrow + dx + 1), lhalf);
+  // (wn + dy + 1) * 66 + pxh + dx + 1.
+  const int l16 = lane & 15, lk = lane >> 4;
+  const int wa0 = M16 ? swz32<true>(wm * MI * 16 + l16, lk) : swz32<false>(wm * TM * 32 + lrow, lhalf);
+  // Rl = this lane's halo row of the (-1, -1) window; the caller passes it through an empty asm once per chunk so
+  // that the nine per-tap addresses are recomputed (5 VALU each) instead of being hoisted into 9+ VGPRs (spills)
+  const int Rl0 = wn * HALO_PITCH + pxh + (M16 ? l16 : lrow);
+  auto mma_step = [&](const unsigned char* bw, const unsigned char* bx, int Rl, int dy, int dx) {
+    const int rb = Rl + (dy + 1) * HALO_PITCH + (dx + 1);
+    if constexpr (M16) {
+      const int xa0 = swz32<true>(rb, lk);
+      half8 wf[MI];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      half8 wf[TM], xf[TN];
+      for (int i = 0; i < MI; ++i) wf[i] = *reinterpret_cast<const half8*>(bw + (wa0 + i * 1024));
 #pragma unroll
-      for (int i = 0; i < TM; ++i) wf[i] = *reinterpret_cast<const half8*>(bw + ((wa0 ^ (kk << 5)) + i * 2048));
+      for (int j = 0; j < NJ; ++j) {
+        const half8 xf = *reinterpret_cast<const half8*>(bx + (xa0 + j * 1024));
 #pragma unroll
-      for (int j = 0; j < TN; ++j) xf[j] = *reinterpret_cast<const half8*>(bx + ((xa0 ^ (kk << 5)) + j * 2048));
+        for (int i = 0; i < MI; ++i)
+          acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf, acc16[i][j], 0, 0, 0);
+      }
+    } else {
+      // kk = 1 flips chunk bit 1 (byte offset ^ 32)
+      const int xa0 = swz32<false>(rb, lhalf);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int kk = 0; kk < 2; ++kk) {
+        half8 wf[TM], xf[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i) wf[i] = *reinterpret_cast<const half8*>(bw + ((wa0 ^ (kk << 5)) + i * 2048));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) xf[j] = *reinterpret_cast<const half8*>(bx + ((xa0 ^ (kk << 5)) + j * 2048));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      }
     }
   };
 
@@ -823,6 +860,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int c = 0; c < cs32; ++c) {
       const unsigned char* bx = ldsX + (c & 1) * H32_XBYTES;
       const bool more = c + 1 < cs32;
+      int Rl = Rl0;
+      asm volatile("" : "+v"(Rl));
       auto tap_step = [&](auto TAPC) {
         constexpr int TAP = decltype(TAPC)::value;
         constexpr int T2 = TAP + 2;
@@ -836,7 +875,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           if (more && piece_used(TAP)) issueX(c + 1, TAP, (c + 1) & 1);
           else glds16(zp, sink_a);
         }
-        mma_step(ldsW + (TAP % 3) * WSTAGE, bx, TAP / 3 - 1, TAP % 3 - 1);
+        mma_step(ldsW + (TAP % 3) * WSTAGE, bx, Rl, TAP / 3 - 1, TAP % 3 - 1);
         if constexpr (TAP == 0 || TAP == 4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else if constexpr (TAP < 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
@@ -861,7 +900,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int i = 0; i < H32_XP; ++i)
           if (piece_used(i)) issueX(c + 1, i, (c + 1) & 1);
       }
-      mma_step(ldsW + (c & 1) * WSTAGE, bx, 0, 0);
+      mma_step(ldsW + (c & 1) * WSTAGE, bx, Rl0, 0, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
@@ -879,27 +918,45 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     half_t* stage = reinterpret_cast<half_t*>(lds);
     auto stage_all = [&](auto ACTC) {
       constexpr int ACT = decltype(ACTC)::value;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int cl = wm * (TM * 32) + i * 32 + 8 * g + 4 * lhalf, cg = cout0 + cl;
-          float4 b = *reinterpret_cast<const float4*>(a.bias + cg);
-          if (a.extra && cg + 4 <= a.Cout) {
-            const float4 x = *reinterpret_cast<const float4*>(a.extra + (int64_t)e * a.extra_stride + a.extra_off + cg);
-            b.x += x.x; b.y += x.y; b.z += x.z; b.w += x.w;
-          }
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const int pl = wn * 64 + j * 32 + lrow;
-            half4 h;
-            h[0] = (half_t)act_apply(acc[i][j][4 * g] + b.x, ACT);
-            h[1] = (half_t)act_apply(acc[i][j][4 * g + 1] + b.y, ACT);
-            h[2] = (half_t)act_apply(acc[i][j][4 * g + 2] + b.z, ACT);
-            h[3] = (half_t)act_apply(acc[i][j][4 * g + 3] + b.w, ACT);
-            *reinterpret_cast<half4*>(stage + pl * PITCH + cl) = h;
-          }
+      auto put = [&](int cl, int pl, float4 b, float v0, float v1, float v2, float v3) {
+        half4 h;
+        h[0] = (half_t)act_apply(v0 + b.x, ACT);
+        h[1] = (half_t)act_apply(v1 + b.y, ACT);
+        h[2] = (half_t)act_apply(v2 + b.z, ACT);
+        h[3] = (half_t)act_apply(v3 + b.w, ACT);
+        *reinterpret_cast<half4*>(stage + pl * PITCH + cl) = h;
+      };
+      auto bias4 = [&](int cl) {
+        const int cg = cout0 + cl;
+        float4 b = *reinterpret_cast<const float4*>(a.bias + cg);
+        if (a.extra && cg + 4 <= a.Cout) {
+          const float4 x = *reinterpret_cast<const float4*>(a.extra + (int64_t)e * a.extra_stride + a.extra_off + cg);
+          b.x += x.x; b.y += x.y; b.z += x.z; b.w += x.w;
         }
+        return b;
+      };
+      if constexpr (M16) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int cl = wm * (MI * 16) + i * 16 + 4 * lk;
+          const float4 b = bias4(cl);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            put(cl, wn * 64 + j * 16 + l16, b, acc16[i][j][0], acc16[i][j][1], acc16[i][j][2], acc16[i][j][3]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int cl = wm * (TM * 32) + i * 32 + 8 * g + 4 * lhalf;
+            const float4 b = bias4(cl);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              put(cl, wn * 64 + j * 32 + lrow, b, acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2],
+                  acc[i][j][4 * g + 3]);
+          }
+      }
     };
     const int actsel = a.epi == EPI_PLAIN ? a.act : (a.epi == EPI_Q ? VIPE_ACT_TANH : VIPE_ACT_SIGMOID);
     if (actsel == VIPE_ACT_RELU) stage_all(std::integral_constant<int, VIPE_ACT_RELU>{});
@@ -976,11 +1033,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // BMC = 32 (flow / confidence heads, eta, narrow plain convs): fp32 staging, activation after it
     constexpr int PITCH = BMC + 4;
     float* stage = reinterpret_cast<float*>(lds);
+    if constexpr (M16) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int pl = wn * 64 + pxh + lrow, cs = 8 * g + 4 * lhalf;
-      *reinterpret_cast<float4*>(stage + pl * PITCH + cs) =
-          make_float4(acc[0][0][4 * g], acc[0][0][4 * g + 1], acc[0][0][4 * g + 2], acc[0][0][4 * g + 3]);
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          *reinterpret_cast<float4*>(stage + (wn * 64 + pxh + j * 16 + l16) * PITCH + i * 16 + 4 * lk) =
+              make_float4(acc16[i][j][0], acc16[i][j][1], acc16[i][j][2], acc16[i][j][3]);
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int pl = wn * 64 + pxh + lrow, cs = 8 * g + 4 * lhalf;
+        *reinterpret_cast<float4*>(stage + pl * PITCH + cs) =
+            make_float4(acc[0][0][4 * g], acc[0][0][4 * g + 1], acc[0][0][4 * g + 2], acc[0][0][4 * g + 3]);
+      }
     }
     __syncthreads();
     CONV_STAMP(3);
@@ -1116,26 +1182,37 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
     static bool h32attr = false;
     const int bmc = cp >= 128 ? 128 : cp;
     if (!h32attr) {
-      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(128));
-      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(64));
-      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<32, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(32));
-      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(128));
-      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(64));
-      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(32));
+      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<128, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(128));
+      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<64, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(64));
+      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<32, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(32));
+      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<128, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(128));
+      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<64, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(64));
+      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<32, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(32));
       h32attr = true;
     }
     const int gy = cp >= 128 ? cp / 128 : 1;
     const int tiles = (int)(M / (HALO_TH * HALO_TW));
     const dim3 grid(tiles * gy);
     const size_t lds = halo32_lds_bytes(bmc);
+    static const bool m32 = getenv("VIPE_AMD_CONV_MFMA32") != nullptr;  // A/B: 32x32x16 fragments
+    if (m32) {
+      static bool a32 = false;
+      if (!a32) {
+        (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<128, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(128));
+        (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<128, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(128));
+        a32 = true;
+      }
+    }
     if (a.KH == 3) {
-      if (bmc == 128) conv_halo32_kernel<128, 3><<<grid, 512, lds, s>>>(a, gy);
-      else if (bmc == 64) conv_halo32_kernel<64, 3><<<grid, 512, lds, s>>>(a, 1);
-      else conv_halo32_kernel<32, 3><<<grid, 512, lds, s>>>(a, 1);
+      if (bmc == 128 && m32) conv_halo32_kernel<128, 3, false><<<grid, 512, lds, s>>>(a, gy);
+      else if (bmc == 128) conv_halo32_kernel<128, 3, true><<<grid, 512, lds, s>>>(a, gy);
+      else if (bmc == 64) conv_halo32_kernel<64, 3, true><<<grid, 512, lds, s>>>(a, 1);
+      else conv_halo32_kernel<32, 3, true><<<grid, 512, lds, s>>>(a, 1);
     } else {
-      if (bmc == 128) conv_halo32_kernel<128, 1><<<grid, 512, lds, s>>>(a, gy);
-      else if (bmc == 64) conv_halo32_kernel<64, 1><<<grid, 512, lds, s>>>(a, 1);
-      else conv_halo32_kernel<32, 1><<<grid, 512, lds, s>>>(a, 1);
+      if (bmc == 128 && m32) conv_halo32_kernel<128, 1, false><<<grid, 512, lds, s>>>(a, gy);
+      else if (bmc == 128) conv_halo32_kernel<128, 1, true><<<grid, 512, lds, s>>>(a, gy);
+      else if (bmc == 64) conv_halo32_kernel<64, 1, true><<<grid, 512, lds, s>>>(a, 1);
+      else conv_halo32_kernel<32, 1, true><<<grid, 512, lds, s>>>(a, 1);
     }
     return vipe_launch_status();
   }
