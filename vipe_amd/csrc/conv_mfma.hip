@@ -1091,6 +1091,108 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   CONV_STAMP(4);
 }
 
+// ---- 7x7, 4 input channels (the flow encoder's first conv, droid_net.py:447): K = 49 taps x 4 = 196 -> 224.
+// The whole packed weight tensor (4 blocks of [128 cout][64 k], 64 KiB) is brought to LDS once by LDS-DMA; the
+// (4 + 6) x (64 + 6) pixel halo of the tile (8 B per pixel, 5.5 KiB) is staged through registers.  A 16x16x32
+// B fragment is two taps x 4 channels per lane = two ds_read_b64 from the halo; no K pipeline is needed (7 steps).
+constexpr int C7_PW = HALO_TW + 6, C7_ROWS = HALO_TH + 6;  // 70 x 10 halo pixels
+constexpr int C7_WBYTES = 4 * 128 * 128;                    // 65536
+constexpr int C7_XBYTES = ((C7_PW * C7_ROWS * 8 + 15) / 16) * 16;
+constexpr int C7_LDS = (C7_WBYTES + C7_XBYTES) > (256 * 136 * 2) ? (C7_WBYTES + C7_XBYTES) : (256 * 136 * 2);
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv7x7_c4_kernel(ConvArgs a, int gy) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = L / gy, cout0 = (L % gy) * 128;
+  const int tiles_per_img = a.H / HALO_TH;
+  const int e = tile / tiles_per_img, y0 = (tile % tiles_per_img) * HALO_TH;
+  const int64_t pix0 = (int64_t)tile * (HALO_TH * HALO_TW);
+  const int l16 = lane & 15, lk = lane >> 4;
+  const unsigned ldsW_a = lds_address(lds);
+  unsigned char* ldsX = lds + C7_WBYTES;
+
+  // weights: 64 one-KiB pieces (8 rows x 128 B), 8 per wave; swizzle applied on the source chunk
+  {
+    const int r8 = lane >> 3, sl = lane & 7;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int pce = wave * 8 + q;          // 0..63: block pce / 16, rows (pce % 16) * 8 ..
+      const int blk = pce >> 4, row = (pce & 15) * 8 + r8;
+      const half_t* src = a.w + ((int64_t)blk * a.Cout_pad + cout0 + row) * 64 + ((sl ^ ((row >> 1) & 7)) << 3);
+      glds16(src, ldsW_a + pce * 1024);
+    }
+  }
+  // halo pixels (zero outside the image)
+  for (int i = tid; i < C7_PW * C7_ROWS; i += 512) {
+    const int hy = i / C7_PW, hx = i % C7_PW;
+    const int y = y0 + hy - 3, x = hx - 3;
+    uint2 v = make_uint2(0u, 0u);
+    if (y >= 0 && y < a.H && x >= 0 && x < a.W)
+      v = *reinterpret_cast<const uint2*>(a.x0 + ((int64_t)(e * a.H + y) * a.W + x) * a.x0_ctot + a.x0_coff);
+    *reinterpret_cast<uint2*>(ldsX + i * 8) = v;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  float4v acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+  typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int st = 0; st < 7; ++st) {
+    half8 wf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      wf[i] = *reinterpret_cast<const half8*>(lds + (st >> 1) * 16384 + swz(wm * 64 + i * 16 + l16, (st & 1) * 4 + lk));
+    // this lane's two taps (k = 8 lk .. 8 lk + 7 of the step); taps >= 49 carry zero weights: read tap 48 (finite)
+    const int t0 = min(st * 8 + lk * 2, 48), t1 = min(st * 8 + lk * 2 + 1, 48);
+    const int o0 = ((wn + t0 / 7) * C7_PW + l16 + t0 % 7) * 8, o1 = ((wn + t1 / 7) * C7_PW + l16 + t1 % 7) * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const half4v lo = *reinterpret_cast<const half4v*>(ldsX + o0 + j * 128);
+      const half4v hi = *reinterpret_cast<const half4v*>(ldsX + o1 + j * 128);
+      const half8 xf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf, acc[i][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  // epilogue: bias + activation in the accumulator layout, fp16 tile through LDS, 16-byte NHWC stores
+  constexpr int PITCH = 136;
+  half_t* stage = reinterpret_cast<half_t*>(lds);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cl = wm * 64 + i * 16 + 4 * lk;
+    const float4 b = *reinterpret_cast<const float4*>(a.bias + cout0 + cl);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      half4 h;
+      h[0] = (half_t)act_apply(acc[i][j][0] + b.x, a.act);
+      h[1] = (half_t)act_apply(acc[i][j][1] + b.y, a.act);
+      h[2] = (half_t)act_apply(acc[i][j][2] + b.z, a.act);
+      h[3] = (half_t)act_apply(acc[i][j][3] + b.w, a.act);
+      *reinterpret_cast<half4*>(stage + (wn * 64 + j * 16 + l16) * PITCH + cl) = h;
+    }
+  }
+  __syncthreads();
+  const int ch = (tid & 15) * 8, co = cout0 + ch;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int pl = (tid >> 4) + 32 * it;
+    const half8 o = *reinterpret_cast<const half8*>(stage + pl * PITCH + ch);
+    half_t* dst = a.y + (pix0 + pl) * a.y_ctot + a.y_coff + co;
+    if (co + 8 <= a.Cout) {
+      *reinterpret_cast<half8*>(dst) = o;
+    } else {
+      for (int q = 0; q < 8 && co + q < a.Cout; ++q) dst[q] = o[q];
+    }
+  }
+}
+
 // OIHW (fp16 or fp32) -> packed [K_pad/64][Cout_pad][64] fp16, k = tap*Cin_pad + c (generic) or tap*4 + c (Cin == 4)
 __global__ void pack_weights_kernel(const void* __restrict__ src, half_t* __restrict__ dst, int Cout, int Cin, int KH,
                                     int KW, int Cout_pad, int Cin_pad, int K_pad, int src_f32, int smallcin) {
@@ -1242,6 +1344,17 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
       else if (bmc == 64) conv_halo_kernel<64, 1><<<grid, 512, lds, s>>>(a, 1);
       else conv_halo_kernel<32, 1><<<grid, 512, lds, s>>>(a, 1);
     }
+    return vipe_launch_status();
+  }
+  if (small && a.KH == 7 && a.KW == 7 && a.W == HALO_TW && a.H % HALO_TH == 0 && cp % 128 == 0 && kp == 256 &&
+      a.epi == EPI_PLAIN && a.extra == nullptr && getenv("VIPE_AMD_CONV_NO7X7") == nullptr) {
+    static bool a7 = false;
+    if (!a7) {
+      (void)hipFuncSetAttribute((const void*)conv7x7_c4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C7_LDS);
+      a7 = true;
+    }
+    const int gy = cp / 128;
+    conv7x7_c4_kernel<<<dim3((int)(M / (HALO_TH * HALO_TW)) * gy), 512, C7_LDS, s>>>(a, gy);
     return vipe_launch_status();
   }
   if (cp >= 128) {
