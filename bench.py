@@ -144,10 +144,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # ---- roofline of the dominant kernel: conv_mfma_kernel<128,2,2,false> (every 1x1 / 3x3 convolution of the
-    # flow-update operator with >= 128 output channels: corr0, corr2, w, z|r, q, delta0|weight0|agg1, agg2).
-    # Every launch of that instantiation in a few extra steps is bracketed by events on the launch stream;
-    # achieved = (algorithmic flops of those launches) / (their summed duration).
+    # ---- roofline of the dominant kernel: conv_halo32_kernel<128, 3, true> (every 3x3 convolution of the
+    # flow-update operator with >= 128 output channels: corr2, z|r, q, delta0|weight0|agg1, agg2 - 5 launches per
+    # step, ~50 % of the step).  Every launch of that instantiation in a few extra steps is bracketed by events on
+    # the launch stream; achieved = (algorithmic flops of those launches) / (their summed duration).
     eng = graph.update_op.engine(device)
     rec = []
     achieved = gate_ms = float("nan")
@@ -157,7 +157,7 @@ def main():
 
         def timed(pk, x0, x0_coff, B, H, W, *a, **k):
             cin = k.get("cin") or pk.cin
-            if pk.cout > 64 and pk.cin != 4:
+            if pk.cout > 64 and pk.kh == 3:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 orig(pk, x0, x0_coff, B, H, W, *a, **k)
@@ -171,17 +171,17 @@ def main():
             step()
         torch.cuda.synchronize()
         eng._conv = orig
-        tot_ms = sum(a.elapsed_time(b) for a, b, _ in rec)
+        tot_ms = sum(a.elapsed_time(b) for a, b, _ in rec) or float("nan")
         tot_fl = sum(f for _, _, f in rec)
-        gate_ms = tot_ms / len(rec)
-        flops_per_launch = tot_fl / len(rec)
+        gate_ms = tot_ms / max(1, len(rec))
+        flops_per_launch = tot_fl / max(1, len(rec))
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12
 
     # HBM traffic of the dominant kernel per launch, from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
     # profiles/r01_summary.json; counters cannot be collected from inside the timed process)
     traffic = None
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_summary.json")))["conv_halo_kernel"]
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_summary.json")))["void conv_halo32_kernel<128, 3, true>"]
         traffic = (prof["hbm_read_MB_per_launch"] + prof["hbm_write_MB_per_launch"]) * 1e6
     except Exception:  # noqa: BLE001
         pass
@@ -205,8 +205,8 @@ def main():
                        "conv_backend": args.conv, "parallelism": f"clip-sharded x{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP16_TFLOPS, "traffic": traffic,
-                         "kernel": "conv_halo_kernel (NHWC fp16 implicit-GEMM conv on MFMA 32x32x16, all launches with "
-                                   "Cout >= 128 of the flow-update operator)",
+                         "kernel": "conv_halo32_kernel<128, 3, true> (NHWC fp16 implicit-GEMM 3x3 conv on MFMA 16x16x32, "
+                                   "all launches with Cout >= 128 of the flow-update operator)",
                          "avg_launch_ms": gate_ms, "flops_per_launch": flops_per_launch,
                          "launches_per_step": len(rec) // max(1, args.prof_steps)},
         }
