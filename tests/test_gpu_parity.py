@@ -628,3 +628,32 @@ def test_dense_ba_non_banded_graph_takes_global_memory_solver():
     assert np.abs(p - op).max() <= 1e-4 * max(1.0, np.abs(op).max())
     assert np.abs(d - od[:, 0]).max() <= 1e-4 * np.abs(od).max()
     assert np.abs(k - ok_).max() <= 1e-4 * np.abs(ok_).max()
+
+
+@pytest.mark.parametrize("shape", [(3, 48, 64), (1, 16, 128)])
+def test_corr_pyramid_build_fused_kernel(shape):
+    """Row a1 (droid_net.py:56-69,94-102): volume + pooled pyramid in one HIP kernel.  Level 0 against the fp32
+    contraction of the same fp16 inputs (one rounding to half; the summation order of an fp32-accumulating GEMM is
+    not pinned by the reference either), levels 1..3 BIT-EXACT against avg_pool2d's arithmetic (fp32 sum of the
+    window in row-major order, /4, round to half) applied to the kernel's own previous level, and all levels against
+    the library path (hipBLASLt matmul + at::avg_pool2d) the reference would run."""
+    from vipe_amd.ext import droid_net_ext
+
+    E, h, w = shape
+    g = torch.Generator().manual_seed(5)
+    f1 = torch.randn(E, 128, h, w, generator=g).half().to(dev())
+    f2 = torch.randn(E, 128, h, w, generator=g).half().to(dev())
+    lv = droid_net_ext.corr_pyramid_build(f1, f2, 4)
+    assert [tuple(x.shape) for x in lv] == [(E, h, w, h >> i, w >> i) for i in range(4)]
+    ref0 = torch.matmul((f1.float() / 4).reshape(E, 128, h * w).transpose(1, 2), (f2.float() / 4).reshape(E, 128, h * w))
+    d0 = (lv[0].float().reshape(E, h * w, h * w) - ref0).abs()
+    assert float((d0 - ref0.abs() * 2.0 ** -10).max()) <= 2.0 ** -14, "level 0 is not the rounded fp32 contraction"
+    for i in range(3):
+        x = lv[i].float().reshape(-1, h >> i, w >> i)
+        pooled = (((x[:, 0::2, 0::2] + x[:, 0::2, 1::2]) + x[:, 1::2, 0::2]) + x[:, 1::2, 1::2]) / 4.0
+        assert torch.equal(pooled.half().reshape(lv[i + 1].shape), lv[i + 1]), f"level {i + 1} pooling not bit-exact"
+    vol = droid_net_ext.corr_volume(f1, f2).reshape(E * h * w, 1, h, w)
+    for i in range(4):
+        assert float((vol.view(lv[i].shape).float() - lv[i].float()).abs().max()) <= 2e-2
+        if i < 3:
+            vol = torch.nn.functional.avg_pool2d(vol, 2, stride=2)

@@ -1,0 +1,216 @@
+// CorrBlock.corr + pyramid (vipe/slam/networks/droid_net.py:56-69, 94-102) in ONE kernel:
+//   level0[e][p1][p2] = sum_c (f1[e][c][p1] / 4) * (f2[e][c][p2] / 4)        (fp16 in, fp32 accumulate, fp16 out)
+//   level i+1 = avg_pool2d(level i, 2, 2) over the target dims (fp32 sum of the four halves, rounded to half -
+//   the arithmetic of at::native::avg_pool2d on c10::Half), i = 0..2.
+// The reference runs torch.matmul + three avg_pool2d passes that re-read what they just wrote (25 MB/edge written,
+// 8.3 MB/edge re-read and 8.3 MB written again by the pools); here every level-0 tile is pooled while it is still in
+// LDS / registers, so HBM sees the algorithmic 26.7 MB/edge of writes once.  The kernel is HBM-write bound
+// (2.42 GFLOP/edge is ~1 us of MFMA per edge), so the design optimises store shape, not the matrix pipeline.
+//
+// Mapping.  Workgroup (8 waves) = 64 consecutive source pixels p1 of one edge x ALL target pixels, walked in chunks of
+// 2 target rows x 64 columns.  Feature maps stay in the reference's [C][h*w] layout: both MFMA operands are
+// K-major in memory, so the LDS images are [channel][pixel] rows filled with coalesced 16-byte loads and the
+// 16x16x32 fragments are gathered with ds_read_b64_tr_b16 (hardware transpose read).  Row pitches are 32 bytes past a
+// multiple of 256 and a lane group's 4+4 channels are 4 apart (a consistent K permutation of both operands), so the
+// two blocks of each 32-lane half cover 8 consecutive channel rows = 8 distinct 32-byte bank segments.
+// f2 is the A operand (rows = target pixels): a lane's accumulator registers are then 4 consecutive target pixels of
+// one source pixel -> 8-byte staging writes of the [p1][p2] tile.  The 64-pixel f1 tile is held in registers.
+// Pooling: the thread that stores columns 8s..8s+7 of both chunk rows of source pixel p1 also produces level-1
+// columns 4s..4s+3, keeps them to form level-2 columns 2s, 2s+1 two chunks later and level-3 column s after eight
+// target rows - no cross-thread traffic after the level-0 tile.
+#include "common.cuh"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+constexpr int PB_M = 64;                 // source pixels per workgroup
+constexpr int PB_N = 128;                // target pixels per chunk (2 rows x 64 columns)
+constexpr int PB_C = 128;                // channels
+constexpr int PB_PA = PB_N * 2 + 32;     // byte pitch of the f2 chunk image rows (288)
+constexpr int PB_PB = PB_M * 2 + 32;     // byte pitch of the f1 tile image rows (160)
+constexpr int PB_PS = PB_N + 8;          // halves per staged source pixel (136)
+constexpr int PB_IMGA = PB_C * PB_PA;    // 36864
+constexpr int PB_IMGB = PB_C * PB_PB > PB_M * PB_PS * 2 ? PB_C * PB_PB : PB_M * PB_PS * 2;  // 20480
+constexpr int PB_LDS = PB_IMGA + PB_IMGB;
+
+struct BuildArgs {
+  const half_t* f1;
+  const half_t* f2;
+  half_t* lv[4];
+  int B, h, w, nlev;
+};
+
+__device__ __forceinline__ half8 tr_frag(const unsigned char* img, int byte_off, int pitch16) {
+  // two transposed 4 x 16 blocks, 16 channel rows apart -> the 8 k values of this lane
+  const auto p0 = (const __attribute__((address_space(3))) fp16x4*)(img + byte_off);
+  const auto p1 = (const __attribute__((address_space(3))) fp16x4*)(img + byte_off + pitch16);
+  const fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)p0);
+  const fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)p1);
+  half8 r;
+  r[0] = (half_t)a[0]; r[1] = (half_t)a[1]; r[2] = (half_t)a[2]; r[3] = (half_t)a[3];
+  r[4] = (half_t)b[0]; r[5] = (half_t)b[1]; r[6] = (half_t)b[2]; r[7] = (half_t)b[3];
+  return r;
+}
+
+__device__ __forceinline__ half_t pool4(half_t a, half_t b, half_t c, half_t d) {
+  // at::native avg_pool2d<c10::Half, float>: fp32 sum in window order, divide, round to half
+  return (half_t)((((float)a + (float)b) + (float)c + (float)d) / 4.0f);
+}
+
+__global__ __launch_bounds__(512) void corr_pyramid_build_kernel(BuildArgs a) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  unsigned char* imgA = lds;             // f2 chunk  [128 c][128 p2]
+  unsigned char* imgB = lds + PB_IMGA;   // f1 tile   [128 c][64 p1], later the staged level-0 tile [64 p1][128 p2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int P = a.h * a.w;
+  const int tiles = P / PB_M;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int e = L / tiles, p1_0 = (L % tiles) * PB_M;
+  const half_t* f1 = a.f1 + (int64_t)e * PB_C * P;
+  const half_t* f2 = a.f2 + (int64_t)e * PB_C * P;
+
+  // ---- f1 tile -> LDS -> registers (B operand: columns = source pixels)
+  for (int i = tid; i < PB_C * 8; i += 512) {
+    const int c = i >> 3, s = i & 7;
+    *reinterpret_cast<half8*>(imgB + c * PB_PB + s * 16) = *reinterpret_cast<const half8*>(f1 + (int64_t)c * P + p1_0 + s * 8);
+  }
+  __syncthreads();
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, l16 = lane & 15;
+  const int wn = wave & 3, wp = wave >> 2;  // target-pixel quarter of the chunk, source-pixel half of the tile
+  half8 bf[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      bf[j][kk] = tr_frag(imgB, (kk * 32 + g * 4 + q) * PB_PB + (wp * 32 + j * 16 + 4 * pp) * 2, 16 * PB_PB);
+  const int a_off = (g * 4 + q) * PB_PA + (wn * 32 + 4 * pp) * 2;
+
+  // ---- chunk walk: (8-row group, 64-column segment, row pair)
+  const int csegs = a.w / 64;
+  const int nchunks = (a.h / 2) * csegs;
+  auto chunk_origin = [&](int ch, int& y, int& x0) {
+    const int rp = ch & 3, t = ch >> 2;
+    y = (t / csegs) * 8 + rp * 2;
+    x0 = (t % csegs) * 64;
+  };
+  // this thread's 4 sixteen-byte pieces of a chunk: channel rows tid/16 + 32 k, piece tid % 16 (row rr = piece / 8)
+  half8 pre[4];
+  auto fetch = [&](int ch) {
+    int y, x0;
+    chunk_origin(ch, y, x0);
+    const int pc = tid & 15;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = (tid >> 4) + 32 * k;
+      pre[k] = *reinterpret_cast<const half8*>(f2 + (int64_t)c * P + (y + (pc >> 3)) * a.w + x0 + (pc & 7) * 8);
+    }
+  };
+  auto commit = [&]() {
+    const int pc = tid & 15;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<half8*>(imgA + ((tid >> 4) + 32 * k) * PB_PA + pc * 16) = pre[k];
+  };
+  fetch(0);
+  const int sp1 = tid >> 3, sseg = tid & 7;  // output role: source pixel of the tile, 8-column segment
+  const int64_t p1g = (int64_t)e * P + p1_0 + sp1;
+  half4 l1prev = {0, 0, 0, 0};
+  half_t l2prev[2] = {0, 0};
+  half_t* stage = reinterpret_cast<half_t*>(imgB);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    commit();
+    __syncthreads();  // imgA ready; previous chunk's stage reads are done
+    if (ch + 1 < nchunks) fetch(ch + 1);
+    float4v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      half8 af[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = tr_frag(imgA, a_off + kk * 32 * PB_PA + i * 32, 16 * PB_PA);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j][kk], acc[i][j], 0, 0, 0);
+    }
+    // D: rows = target pixels wn*32 + i*16 + 4g + r, column = source pixel wp*32 + j*16 + l16
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        half4 hv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hv[r] = (half_t)(acc[i][j][r] * 0.0625f);
+        *reinterpret_cast<half4*>(stage + (wp * 32 + j * 16 + l16) * PB_PS + wn * 32 + i * 16 + 4 * g) = hv;
+      }
+    __syncthreads();  // stage ready; imgA free
+    int y, x0;
+    chunk_origin(ch, y, x0);
+    // level 0: 32 contiguous bytes per thread (row sseg / 4 of the pair, columns (sseg % 4) * 16 ..)
+    {
+      const half8 v0 = *reinterpret_cast<const half8*>(stage + sp1 * PB_PS + sseg * 16);
+      const half8 v1 = *reinterpret_cast<const half8*>(stage + sp1 * PB_PS + sseg * 16 + 8);
+      half_t* dst = a.lv[0] + (p1g * a.h + y + (sseg >> 2)) * a.w + x0 + (sseg & 3) * 16;
+      *reinterpret_cast<half8*>(dst) = v0;
+      *reinterpret_cast<half8*>(dst + 8) = v1;
+    }
+    if (a.nlev > 1) {
+      const half8 r0 = *reinterpret_cast<const half8*>(stage + sp1 * PB_PS + sseg * 8);
+      const half8 r1 = *reinterpret_cast<const half8*>(stage + sp1 * PB_PS + 64 + sseg * 8);
+      half4 l1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) l1[k] = pool4(r0[2 * k], r0[2 * k + 1], r1[2 * k], r1[2 * k + 1]);
+      *reinterpret_cast<half4*>(a.lv[1] + (p1g * (a.h >> 1) + (y >> 1)) * (a.w >> 1) + (x0 >> 1) + sseg * 4) = l1;
+      if (a.nlev > 2 && (ch & 1)) {
+        half_t l2[2];
+        l2[0] = pool4(l1prev[0], l1prev[1], l1[0], l1[1]);
+        l2[1] = pool4(l1prev[2], l1prev[3], l1[2], l1[3]);
+        half_t* d2 = a.lv[2] + (p1g * (a.h >> 2) + (y >> 2)) * (a.w >> 2) + (x0 >> 2) + sseg * 2;
+        d2[0] = l2[0];
+        d2[1] = l2[1];
+        if (a.nlev > 3 && (ch & 3) == 3)
+          a.lv[3][(p1g * (a.h >> 3) + (y >> 3)) * (a.w >> 3) + (x0 >> 3) + sseg] = pool4(l2prev[0], l2prev[1], l2[0], l2[1]);
+        l2prev[0] = l2[0];
+        l2prev[1] = l2[1];
+      }
+      l1prev = l1;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+VIPE_EXPORT int vipe_corr_pyramid_build(const void* d_fmap1, const void* d_fmap2, void* const* h_levels, int B, int C,
+                                        int h, int w, int num_levels, void* stream) {
+  VIPE_CHECK_ARG(h_levels && num_levels >= 1 && num_levels <= 4 && B >= 0 && C > 0 && h > 0 && w > 0);
+  if (B == 0) return VIPE_OK;
+  VIPE_CHECK_ARG(d_fmap1 && d_fmap2);
+  for (int i = 0; i < num_levels; ++i) VIPE_CHECK_ARG(h_levels[i]);
+  // tiling of this kernel: 128 channels, 64-column segments, 8-row groups (the DROID feature map at 1/8 of
+  // 512 x 384 and multiples); other shapes take the library GEMM + pooling path on the Python side
+  if (C != PB_C || w % 64 != 0 || h % 8 != 0) return VIPE_EUNSUPPORTED;
+  if ((int64_t)B * h * w / PB_M > 0x7fffffff) return VIPE_EINVAL;
+  BuildArgs a;
+  a.f1 = (const half_t*)d_fmap1;
+  a.f2 = (const half_t*)d_fmap2;
+  for (int i = 0; i < 4; ++i) a.lv[i] = i < num_levels ? (half_t*)h_levels[i] : nullptr;
+  a.B = B; a.h = h; a.w = w; a.nlev = num_levels;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)corr_pyramid_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS);
+    attr = true;
+  }
+  corr_pyramid_build_kernel<<<dim3((unsigned)((int64_t)B * h * w / PB_M)), 512, PB_LDS, as_stream(stream)>>>(a);
+  return vipe_launch_status();
+}
+
+}  // extern "C"

@@ -5,6 +5,5 @@
 VIPE_EXPORT const char* vipe_amd_version(void) { return "vipe_amd 0.1 (gfx950, hipcc)"; }
 VIPE_EXPORT int vipe_amd_abi_version(void) { return 1; }
 
-VIPE_EXPORT int vipe_corr_pyramid_build(const void*, const void*, void* const*, int, int, int, int, int, void*) { return VIPE_EUNSUPPORTED; }
 VIPE_EXPORT int64_t vipe_ba_workspace_bytes(int, int, int, int) { return VIPE_EUNSUPPORTED; }
 VIPE_EXPORT int vipe_ba(float*, float*, const float*, const float*, const float*, const float*, const float*, const int64_t*, const int64_t*, int, int, int, int, int, int, int, int, float, float, int, float*, float*, void*, int64_t, void*) { return VIPE_EUNSUPPORTED; }

@@ -75,8 +75,21 @@ def corr_volume(fmap1, fmap2):
 
 
 def corr_pyramid_build(fmap1, fmap2, num_levels=4):
-    """CorrBlock.__init__ (droid_net.py:56-69): list of [E,h,w,h>>i,w>>i]."""
+    """CorrBlock.__init__ (droid_net.py:56-69): list of [E,h,w,h>>i,w>>i].
+
+    fp16 feature maps with C = 128, w % 64 == 0, h % 8 == 0 (the DROID maps at 1/8 of 512x384 and multiples) go
+    through the fused HIP kernel (volume + the three pooled levels in one pass, `vipe_corr_pyramid_build`); other
+    shapes / dtypes are a plain library GEMM + pooling on the GPU (`corr_volume`, hipBLASLt)."""
     E, C, h, w = fmap1.shape
+    if (fmap1.dtype == torch.float16 and fmap2.dtype == torch.float16 and fmap1.is_cuda and C == 128 and w % 64 == 0
+            and h % 8 == 0 and num_levels <= 4 and (h >> (num_levels - 1)) > 0):
+        check_gpu_contig(fmap1, fmap2)
+        levels = [torch.empty((E, h, w, h >> i, w >> i), dtype=torch.float16, device=fmap1.device)
+                  for i in range(num_levels)]
+        ptrs = (ctypes.c_void_p * num_levels)(*[lv.data_ptr() for lv in levels])
+        check(lib().vipe_corr_pyramid_build(ptr(fmap1), ptr(fmap2), ptrs, E, C, h, w, num_levels, stream_ptr(fmap1)),
+              "corr_pyramid_build")
+        return levels
     vol = corr_volume(fmap1, fmap2).reshape(E * h * w, 1, h, w)
     levels = []
     for i in range(num_levels):
