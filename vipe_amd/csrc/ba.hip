@@ -27,6 +27,7 @@ namespace {
 constexpr int TILE = 256;   // lanes per workgroup = pixels per tile
 constexpr int NWAVE = TILE / WAVE;
 constexpr int TCHUNK = 8;   // terms whose transforms are staged in LDS at a time
+constexpr int AM_DMAX = 6;  // largest source-frame degree the matrix-core accumulate kernel handles
 
 struct BAWs {
   int* rowptr;      // [nF+1] CSR over source disparity frames
@@ -55,6 +56,7 @@ struct BAArgs {
   const int64_t *pi, *qi, *pj, *qj, *di;
   BAWs w;
   int P, nF, D;
+  int force_simple;  // VIPE_BA_ACCUM_SIMPLE: shuffle-reduction accumulate kernel for every graph (A/B, debugging)
 };
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(1024) void ba_plan_kernel(BAArgs a) {
     a.w.info[2] = 0;
     a.w.info[3] = 6 * n_free + F;
     a.w.info[4] = 0;  // band width of the reduced pose system in 6x6 blocks (filled below)
+    a.w.info[6] = 0;  // largest number of terms of one source frame (selects the accumulate kernel)
   }
   // stable counting sort of the terms by source frame: frame k's owner scans the term list in order
   // (cursor kept in cnt[]: reuse cnt as the running write position)
@@ -223,6 +226,7 @@ __global__ __launch_bounds__(1024) void ba_plan_kernel(BAArgs a) {
       if (sj >= 0) { lo = min(lo, sj); hi = max(hi, sj); }
     }
     if (hi >= 0) atomicMax(&a.w.info[4], hi - lo);
+    atomicMax(&a.w.info[6], a.w.rowptr[k + 1] - a.w.rowptr[k]);
   }
 }
 
@@ -265,6 +269,7 @@ __global__ __launch_bounds__(TILE) void ba_accum_kernel(BAArgs a) {
   constexpr int NRED = NT > NK ? NT : NK;
   const vipe_ba_params& prm = a.p;
   const BAWs& w = a.w;
+  if (!a.force_simple && w.info[6] <= AM_DMAX) return;  // the matrix-core kernel owns this graph
   const int k = blockIdx.y;
   const int beg = w.rowptr[k], end = w.rowptr[k + 1];
   if (beg == end) return;
@@ -573,6 +578,372 @@ __global__ __launch_bounds__(TILE) void ba_accum_kernel(BAArgs a) {
           const int gr = base_a + r, gc = base_b + c;
           if (ma != mb || r >= c) s_add(w, gr, gc, -(double)s);
         }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ accumulate (MFMA)
+//
+// Same contract as ba_accum_kernel, but every reduction over pixels runs on the matrix cores instead of DPP + LDS
+// trees (the shuffle version spends ~9.5k DPP adds and ~70 workgroup barriers per tile on 1,281 reduced values):
+//   * R1, per term: the lane (= pixel) writes the rows sqrt(w_c) * [Jj_c(6); r_c; Jf_c(F)] of its pixel for both
+//     residual components c into a wave-private LDS tile [16 rows][2 x 64 pixels]; one chain of 32
+//     v_mfma_f32_16x16x4_f32 (A = B = the tile) yields the Gram matrix = H_jj, -v_j, H_jf, H_ff, -v_f of the term
+//     over the wave's 64 pixels.  Only the TARGET-side blocks are reduced: J_i = M J_j per term (M = -Adj(G_ij)^T,
+//     or I - Adj^T when both ends are views of one pose), so H_ii += M H_jj M^T, H_ij = M H_jj, v_i += M v_j and
+//     H_if += M H_jf are formed from the 6x6 sums by a few lanes afterwards.
+//   * R2, per source frame: rows sqrt(Q) * [E_i; E_j(terms); E_f; w] (Q = 1/C per pixel) go to the same LDS region
+//     [<= 48 rows][64 pixels]; the Schur complement E Q E^T and the reduced rhs E Q w are the lower-triangle tiles of
+//     its Gram matrix (16 MFMAs per 16x16 tile pair).
+// Waves never wait for each other inside the walk: wave-private LDS, LDS float atomics into workgroup accumulators,
+// three workgroup barriers in total.  Exact fp32 products and sums (the f32 MFMA is an fmaf chain).
+// Handles source frames with at most AM_DMAX terms (the radius-3 neighbourhood graph: 6); ba_plan_kernel publishes
+// the largest degree in info[6] and exactly one of the two accumulate kernels runs.
+constexpr int AM_ROWS = 48;             // R2 row capacity: 6 (AM_DMAX + 1) + F + 1 <= 48
+constexpr int AM_P1 = 130;              // float pitch of the R1 tile [16][128]   (= 2 mod 32: conflict-free b32 reads)
+constexpr int AM_P2 = 66;               // float pitch of the R2 image [48][64]
+constexpr int AM_WBUF = AM_ROWS * AM_P2;  // 3168 floats per wave (R1 tile: 16 * 130 = 2080)
+constexpr int AM_SP = AM_ROWS + 1;
+
+struct TermGeomM {
+  TermGeom g;
+  float Mi[36];  // J_i = Mi J_j
+};
+
+constexpr size_t accum_mfma_lds() {
+  return sizeof(float) * (NWAVE * AM_WBUF + AM_ROWS * AM_SP + AM_DMAX * 256 + 64) + AM_DMAX * sizeof(TermGeomM);
+}
+
+typedef float float4m __attribute__((ext_vector_type(4)));
+
+template <int CAM, int F>
+__global__ __launch_bounds__(TILE) void ba_accum_mfma_kernel(BAArgs a) {
+  constexpr int FF = F > 0 ? F : 1;
+  constexpr int RPT = F > 0 ? 16 : 8;  // R1 rows per term: 6 J, r, F Jf (padded)
+  constexpr int TPT = 16 / RPT;        // terms per R1 tile
+  const vipe_ba_params& prm = a.p;
+  const BAWs& w = a.w;
+  if (a.force_simple || w.info[6] > AM_DMAX) return;
+  const int k = blockIdx.y;
+  const int beg = w.rowptr[k], end = w.rowptr[k + 1];
+  if (beg == end) return;
+  const int deg = end - beg;
+  const int P = a.P, V = prm.n_views, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p_raw = blockIdx.x * TILE + tid;
+  const bool inb = p_raw < P;
+  const int p = inb ? p_raw : P - 1;
+  const int flags = w.fflags[k];
+  const bool dfree = flags & 2;
+  const int pose_i = k / V, qi = k % V;
+  const int si = w.pose_slot[pose_i];
+  const bool fi = si >= 0;
+  const int n_free = w.info[0], nrow = w.info[3];
+  const int foff = 6 * n_free;
+
+  extern __shared__ __align__(16) float am_smem[];
+  float* wbuf = am_smem + wave * AM_WBUF;       // wave-private
+  float* accS = am_smem + NWAVE * AM_WBUF;      // [48][49] Schur Gram accumulators
+  float* acc1 = accS + AM_ROWS * AM_SP;         // [AM_DMAX][16][16] per-term Gram accumulators
+  float* accI = acc1 + AM_DMAX * 256;           // [64] frame level: H_ii 36, v_i 6, H_if 6F, H_ff 3, v_f F
+  TermGeomM* tg = reinterpret_cast<TermGeomM*>(accI + 64);
+
+  for (int i = tid; i < AM_ROWS * AM_SP + AM_DMAX * 256 + 64; i += TILE) accS[i] = 0.0f;
+  if (tid < deg) {
+    const int e = w.order[beg + tid];
+    const int pi = (int)a.pi[e], pj = (int)a.pj[e], qj = (int)a.qj[e];
+    TermGeomM m;
+    TermGeom& g = m.g;
+    term_transforms(a.poses, a.rig, pi, (int)a.qi[e], pj, qj, g.T, g.G, g.Rr);
+    g.Ij = cam::load_scaled(a.intr + qj * (4 + a.D), a.D, 1.0f / prm.intr_factor);
+    g.e = e;
+    g.merge = (pi == pj);
+    g.rig_adj = !(g.Rr.t[0] == 0.f && g.Rr.t[1] == 0.f && g.Rr.t[2] == 0.f && g.Rr.R[0] == 1.f &&
+                  g.Rr.R[4] == 1.f && g.Rr.R[8] == 1.f);
+    g.sj = g.merge ? -1 : w.pose_slot[pj];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      float ec[6] = {0, 0, 0, 0, 0, 0}, col[6];
+      ec[c] = 1.0f;
+      adjT_apply(g.G, ec, col);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) m.Mi[r * 6 + c] = (g.merge && r == c ? 1.0f : 0.0f) - col[r];
+    }
+    tg[tid] = m;
+  }
+  __syncthreads();
+
+  const cam::Intr Ii = cam::load_scaled(a.intr + qi * (4 + a.D), a.D, 1.0f / prm.intr_factor);
+  const float u = (float)(p % prm.wd), v = (float)(p / prm.wd);
+  const float d = a.disps[(int64_t)k * P + p];
+  float X0, Y0, dX0[FF], dY0[FF];
+  cam::iproj<CAM, F>(Ii, u, v, X0, Y0, dX0, dY0);
+  float C = 0.f, wz = 0.f, Ei[6] = {0, 0, 0, 0, 0, 0}, Efr[FF] = {};
+  const int l16 = lane & 15, kq = lane >> 4;
+
+  for (int t0 = 0; t0 < deg; t0 += TPT) {
+#pragma unroll
+    for (int uu = 0; uu < TPT; ++uu) {
+      const int t = t0 + uu;
+      if (t >= deg) break;  // workgroup-uniform
+      const TermGeom& G = tg[t].g;
+      const int e = G.e;
+      const float X = G.T.R[0] * X0 + G.T.R[1] * Y0 + G.T.R[2] + G.T.t[0] * d;
+      const float Y = G.T.R[3] * X0 + G.T.R[4] * Y0 + G.T.R[5] + G.T.t[1] * d;
+      const float Z = G.T.R[6] * X0 + G.T.R[7] * Y0 + G.T.R[8] + G.T.t[2] * d;
+      float x, y, Jp[2][3], Jfj[2][FF];
+      cam::proj<CAM, true, F>(G.Ij, X, Y, Z, x, y, Jp, Jfj);
+      const int64_t o2 = ((int64_t)e * P + p) * 2;
+      const float2 tgt = *reinterpret_cast<const float2*>(a.target + o2);
+      const float2 wg = *reinterpret_cast<const float2*>(a.weight + o2);
+      const float val = (inb && Z > cam::MIN_DEPTH) ? prm.weight_scale : 0.0f;  // geom.py:263, buffer.py:413
+      const float wc[2] = {val * wg.x, val * wg.y};
+      const float rc[2] = {x - tgt.x, y - tgt.y};
+      float Ja[3][6] = {{d, 0, 0, 0, Z, -Y}, {0, d, 0, -Z, 0, X}, {0, 0, d, Y, -X, 0}};
+      if (G.rig_adj) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          float tmp[6];
+          adjT_apply(G.Rr, Ja[r], tmp);
+#pragma unroll
+          for (int q = 0; q < 6; ++q) Ja[r][q] = tmp[q];
+        }
+      }
+      const bool fj = G.sj >= 0;
+      float Ejv[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float Jj[6], Ji[6], Jf[FF];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Jj[q] = Jp[c][0] * Ja[0][q] + Jp[c][1] * Ja[1][q] + Jp[c][2] * Ja[2][q];
+        const float Jz = Jp[c][0] * G.T.t[0] + Jp[c][1] * G.T.t[1] + Jp[c][2] * G.T.t[2];
+        if constexpr (F > 0) {
+#pragma unroll
+          for (int f = 0; f < F; ++f) {
+            const float ax = G.T.R[0] * dX0[f] + G.T.R[1] * dY0[f];
+            const float ay = G.T.R[3] * dX0[f] + G.T.R[4] * dY0[f];
+            const float az = G.T.R[6] * dX0[f] + G.T.R[7] * dY0[f];
+            Jf[f] = (Jp[c][0] * ax + Jp[c][1] * ay + Jp[c][2] * az + Jfj[c][f]) * (1.0f / prm.intr_factor);
+          }
+        }
+        // R1 rows of this term and component
+        const float sw = sqrtf(wc[c]);
+        float* col = wbuf + (uu * RPT) * AM_P1 + c * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) col[q * AM_P1] = Jj[q] * sw;
+        col[6 * AM_P1] = rc[c] * sw;
+        if constexpr (F > 0) {
+#pragma unroll
+          for (int f = 0; f < F; ++f) col[(7 + f) * AM_P1] = Jf[f] * sw;
+        }
+        // per-pixel disparity quantities
+        if (dfree) {
+          const float wJz = wc[c] * Jz;
+          C += wJz * Jz;
+          wz -= wJz * rc[c];
+          float tmp[6];
+          adjT_apply(G.G, Jj, tmp);
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            Ji[q] = (G.merge ? Jj[q] : 0.0f) - tmp[q];
+            Ei[q] += Ji[q] * wJz;
+          }
+          if constexpr (F > 0) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) Efr[f] += Jf[f] * wJz;
+          }
+#pragma unroll
+          for (int q = 0; q < 6; ++q) Ejv[q] += Jj[q] * wJz;
+        }
+      }
+      if (dfree && fj && inb) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) w.Ej[((int64_t)e * 6 + q) * P + p] = Ejv[q];
+      }
+    }
+    // ---- Gram matrix of the tile over this wave's 64 pixels x 2 components
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float4m g4 = {0.f, 0.f, 0.f, 0.f};
+    const float* arow = wbuf + l16 * AM_P1 + kq;
+#pragma unroll 8
+    for (int s = 0; s < 32; ++s) {
+      const float av = arow[4 * s];
+      g4 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, av, g4, 0, 0, 0);
+    }
+    // D[row = 4 kq + r][col = l16]: keep the diagonal RPT x RPT blocks
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * kq + r;
+      const int tb = row / RPT;
+      if (l16 / RPT == tb && t0 + tb < deg) atomicAdd(&acc1[(t0 + tb) * 256 + (row % RPT) * 16 + (l16 % RPT)], g4[r]);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- finish the disparity block of this pixel: sensor prior, damping (terms.py:258-268, buffer.py:482-489)
+  float sq = 0.0f;
+  const int NR = 6 * (deg + 1) + F + 1;  // R2 rows: pose i, targets, intrinsics, w
+  if (dfree) {
+    const int64_t kp = (int64_t)k * P + p;
+    if (flags & 4) {
+      C += prm.alpha;
+      wz -= prm.alpha * (d - a.sens[kp]);
+    }
+    C += 1e-7f + (0.2f * a.eta[kp] + 1e-7f);
+    if (inb) {
+      w.C[kp] = C;
+      w.wv[kp] = wz;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) w.Ekk[((int64_t)k * 6 + q) * P + p] = Ei[q];
+      if constexpr (F > 0) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) w.Ef[((int64_t)k * 2 + f) * P + p] = Efr[f];
+      }
+      sq = sqrtf(1.0f / C);
+    }
+    // R2 rows, scaled by sqrt(Q)
+    float* col = wbuf + lane;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) col[q * AM_P2] = fi ? Ei[q] * sq : 0.0f;
+    for (int t = 0; t < deg; ++t) {
+      const TermGeom& G = tg[t].g;
+      const bool fj = G.sj >= 0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+        col[(6 * (t + 1) + q) * AM_P2] = (fj && inb) ? w.Ej[((int64_t)G.e * 6 + q) * P + p] * sq : 0.0f;
+    }
+    if constexpr (F > 0) {
+#pragma unroll
+      for (int f = 0; f < F; ++f) col[(6 * (deg + 1) + f) * AM_P2] = Efr[f] * sq;
+    }
+    col[(NR - 1) * AM_P2] = wz * sq;
+    for (int r = NR; r < ((NR + 15) & ~15); ++r) col[r * AM_P2] = 0.0f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int RT = (NR + 15) >> 4;
+    for (int ta = 0; ta < RT; ++ta)
+      for (int tb = 0; tb <= ta; ++tb) {
+        float4m g4 = {0.f, 0.f, 0.f, 0.f};
+        const float* ar = wbuf + (16 * ta + l16) * AM_P2 + kq;
+        const float* br = wbuf + (16 * tb + l16) * AM_P2 + kq;
+#pragma unroll 8
+        for (int s = 0; s < 16; ++s) g4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[4 * s], br[4 * s], g4, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * ta + 4 * kq + r, cc = 16 * tb + l16;
+          if (row < NR && cc <= row) atomicAdd(&accS[row * AM_SP + cc], g4[r]);
+        }
+      }
+  }
+  __syncthreads();
+
+  // ---- per-term blocks from the Gram sums (one wave per term)
+  for (int t = wave; t < deg; t += NWAVE) {
+    const TermGeomM& TG = tg[t];
+    const float* Gm = acc1 + t * 256;  // [16][16]: rows/cols 0..5 J, 6 r, 7.. Jf
+    const float* Mi = TG.Mi;
+    const int sj = TG.g.sj;
+    const bool fj = sj >= 0;
+    const int bj = 6 * sj, bi = 6 * si;
+    float* T1 = wbuf;  // [6][6 + F] scratch: Mi Hjj | Mi Hjf
+    if (lane < 36) {
+      const int r = lane / 6, c = lane % 6;
+      const float hjj = Gm[r * 16 + c];
+      if (fj && r >= c) {
+        s_add(w, bj + r, bj + c, (double)hjj);
+        if (r == c) atomicAdd(&w.Hd[bj + r], (double)hjj);
+      }
+      float t1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) t1 += Mi[r * 6 + q] * Gm[q * 16 + c];
+      T1[r * 8 + c] = t1;
+      if (fi && fj) s_add(w, bi + r, bj + c, (double)t1);  // H_ij = Mi H_jj
+    } else if (lane < 42) {
+      const int q = lane - 36;
+      const float vjn = Gm[q * 16 + 6];  // sum w J_q r  (v_j = -that)
+      if (fj) atomicAdd(&w.S[(int64_t)nrow * w.ld + bj + q], -(double)vjn);
+      if (fi) {
+        float vin = 0.f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) vin += Mi[q * 6 + c] * Gm[c * 16 + 6];
+        atomicAdd(&accI[36 + q], -vin);
+      }
+    } else if (F > 0 && lane < 42 + 6 * F) {
+      const int q = (lane - 42) / FF, f = (lane - 42) % FF;
+      const float hjf = Gm[q * 16 + 7 + f];
+      if (fj) s_add(w, foff + f, bj + q, (double)hjf);
+      if (fi) {
+        float hif = 0.f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) hif += Mi[q * 6 + c] * Gm[c * 16 + 7 + f];
+        atomicAdd(&accI[42 + q * FF + f], hif);
+      }
+    } else if (F > 0 && lane < 42 + 6 * F + F * F) {
+      const int i2 = lane - 42 - 6 * F, f = i2 / FF, f2 = i2 % FF;
+      if (f >= f2) atomicAdd(&accI[42 + 6 * FF + f * FF + f2], Gm[(7 + f) * 16 + 7 + f2]);
+    } else if (F > 0 && lane < 42 + 6 * F + F * F + F) {
+      const int f = lane - 42 - 6 * F - F * F;
+      atomicAdd(&accI[42 + 6 * FF + FF * FF + f], -Gm[(7 + f) * 16 + 6]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (fi && lane < 36) {
+      const int r = lane / 6, c = lane % 6;
+      float hii = 0.f;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) hii += T1[r * 8 + q] * Mi[c * 6 + q];
+      atomicAdd(&accI[r * 6 + c], hii);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+
+  // ---- frame level: H_ii, v_i, H_if, H_ff, v_f
+  {
+    const int bi = 6 * si;
+    if (tid < 36) {
+      const int r = tid / 6, c = tid % 6;
+      if (fi && r >= c) {
+        const double s = (double)accI[r * 6 + c];
+        s_add(w, bi + r, bi + c, s);
+        if (r == c) atomicAdd(&w.Hd[bi + r], s);
+      }
+    } else if (tid < 42) {
+      if (fi) atomicAdd(&w.S[(int64_t)nrow * w.ld + bi + (tid - 36)], (double)accI[tid]);
+    } else if (F > 0 && tid < 42 + 6 * F) {
+      const int q = (tid - 42) / FF, f = (tid - 42) % FF;
+      if (fi) s_add(w, foff + f, bi + q, (double)accI[tid]);
+    } else if (F > 0 && tid < 42 + 6 * F + F * F) {
+      const int i2 = tid - 42 - 6 * F, f = i2 / FF, f2 = i2 % FF;
+      if (f >= f2) {
+        const double s = (double)accI[tid];
+        s_add(w, foff + f, foff + f2, s);
+        if (f == f2) atomicAdd(&w.Hd[foff + f], s);
+      }
+    } else if (F > 0 && tid < 42 + 6 * F + F * F + F) {
+      atomicAdd(&w.S[(int64_t)nrow * w.ld + foff + (tid - 42 - 6 * F - F * F)], (double)accI[tid]);
+    }
+  }
+  // ---- Schur complement of frame k: S -= E Q E^T, g -= E Q w   (solver.py:176-178)
+  if (dfree) {
+    auto gmap = [&](int row) -> int {
+      if (row >= 6 * (deg + 1)) return foff + (row - 6 * (deg + 1));
+      const int m = row / 6, q = row % 6;
+      const int sl = m == 0 ? si : tg[m - 1].g.sj;
+      return sl >= 0 ? 6 * sl + q : -1;
+    };
+    for (int i = tid; i < NR * NR; i += TILE) {
+      const int row = i / NR, cc = i % NR;
+      if (cc > row || cc == NR - 1) continue;
+      const int gc = gmap(cc);
+      if (gc < 0) continue;
+      const float val = accS[row * AM_SP + cc];
+      if (row == NR - 1) {
+        atomicAdd(&w.S[(int64_t)nrow * w.ld + gc], -(double)val);
+      } else {
+        const int gr = gmap(row);
+        if (gr >= 0) s_add(w, gr, gc, -(double)val);
       }
     }
   }
@@ -1137,10 +1508,12 @@ int run_iters(const BAArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
+  (void)hipFuncSetAttribute((const void*)ba_accum_mfma_kernel<CAM, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_mfma_lds());
   for (int it = 0; it < a.p.n_iters; ++it) {
     hipError_t e1 = hipMemsetAsync(a.w.S, 0, sbytes, s);
     hipError_t e2 = hipMemsetAsync(a.w.Hd, 0, sizeof(double) * nmax, s);
     if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
+    ba_accum_mfma_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, accum_mfma_lds(), s>>>(a);
     ba_accum_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
     ba_solve_band_kernel<<<1, BAND_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)));
     ba_solve_kernel<<<1, SOLVE_T, solve_lds, s>>>(a, panel_cap, getenv("VIPE_BA_DEBUG_TIMING") ? (long long*)(a.w.Hd + nmax) : nullptr);
@@ -1178,6 +1551,7 @@ VIPE_EXPORT int vipe_dense_ba(const vipe_ba_params* p, float* d_poses, float* d_
   a.P = p->ht * p->wd;
   a.nF = p->n_poses * p->n_views;
   a.D = p->camera == VIPE_CAM_MEI ? 1 : 0;
+  a.force_simple = getenv("VIPE_BA_ACCUM_SIMPLE") != nullptr;
   hipStream_t s = as_stream(stream);
   int rc = VIPE_OK;
   if (p->M > 0 && p->n_iters > 0) {
