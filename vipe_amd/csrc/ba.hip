@@ -617,6 +617,23 @@ constexpr size_t accum_mfma_lds() {
 
 typedef float float4m __attribute__((ext_vector_type(4)));
 
+#ifdef VIPE_BA_STAMPS
+// diagnostic build only (scratch/ba_stamps.py): per-workgroup phase stamps (s_memrealtime, 10 ns ticks)
+__device__ unsigned long long* g_ba_stamps = nullptr;
+#define BA_STAMP(k)                                                                                           \
+  do {                                                                                                        \
+    if (g_ba_stamps && threadIdx.x == 0)                                                                      \
+      g_ba_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#define SOLVE_STAMP(k)                                                                              \
+  do {                                                                                              \
+    if (g_ba_stamps && threadIdx.x == 0) g_ba_stamps[1 << 16 | (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define BA_STAMP(k)
+#define SOLVE_STAMP(k)
+#endif
+
 template <int CAM, int F>
 __global__ __launch_bounds__(TILE) void ba_accum_mfma_kernel(BAArgs a) {
   constexpr int FF = F > 0 ? F : 1;
@@ -641,6 +658,7 @@ __global__ __launch_bounds__(TILE) void ba_accum_mfma_kernel(BAArgs a) {
   const int n_free = w.info[0], nrow = w.info[3];
   const int foff = 6 * n_free;
 
+  BA_STAMP(0);
   extern __shared__ __align__(16) float am_smem[];
   float* wbuf = am_smem + wave * AM_WBUF;       // wave-private
   float* accS = am_smem + NWAVE * AM_WBUF;      // [48][49] Schur Gram accumulators
@@ -672,6 +690,7 @@ __global__ __launch_bounds__(TILE) void ba_accum_mfma_kernel(BAArgs a) {
     tg[tid] = m;
   }
   __syncthreads();
+  BA_STAMP(1);
 
   const cam::Intr Ii = cam::load_scaled(a.intr + qi * (4 + a.D), a.D, 1.0f / prm.intr_factor);
   const float u = (float)(p % prm.wd), v = (float)(p / prm.wd);
@@ -681,7 +700,24 @@ __global__ __launch_bounds__(TILE) void ba_accum_mfma_kernel(BAArgs a) {
   float C = 0.f, wz = 0.f, Ei[6] = {0, 0, 0, 0, 0, 0}, Efr[FF] = {};
   const int l16 = lane & 15, kq = lane >> 4;
 
+  // target / weight of the next tile's terms are fetched while the current tile is computed (the walk is otherwise
+  // a chain of dependent global-load latencies: measured 5 us per tile)
+  float2 nx_t[TPT], nx_w[TPT];
+  auto prefetch = [&](int t0) {
+#pragma unroll
+    for (int uu = 0; uu < TPT; ++uu) {
+      const int t = min(t0 + uu, deg - 1);
+      const int64_t o2 = ((int64_t)tg[t].g.e * P + p) * 2;
+      nx_t[uu] = *reinterpret_cast<const float2*>(a.target + o2);
+      nx_w[uu] = *reinterpret_cast<const float2*>(a.weight + o2);
+    }
+  };
+  prefetch(0);
   for (int t0 = 0; t0 < deg; t0 += TPT) {
+    float2 cur_t[TPT], cur_w[TPT];
+#pragma unroll
+    for (int uu = 0; uu < TPT; ++uu) { cur_t[uu] = nx_t[uu]; cur_w[uu] = nx_w[uu]; }
+    if (t0 + TPT < deg) prefetch(t0 + TPT);
 #pragma unroll
     for (int uu = 0; uu < TPT; ++uu) {
       const int t = t0 + uu;
@@ -693,9 +729,7 @@ __global__ __launch_bounds__(TILE) void ba_accum_mfma_kernel(BAArgs a) {
       const float Z = G.T.R[6] * X0 + G.T.R[7] * Y0 + G.T.R[8] + G.T.t[2] * d;
       float x, y, Jp[2][3], Jfj[2][FF];
       cam::proj<CAM, true, F>(G.Ij, X, Y, Z, x, y, Jp, Jfj);
-      const int64_t o2 = ((int64_t)e * P + p) * 2;
-      const float2 tgt = *reinterpret_cast<const float2*>(a.target + o2);
-      const float2 wg = *reinterpret_cast<const float2*>(a.weight + o2);
+      const float2 tgt = cur_t[uu], wg = cur_w[uu];
       const float val = (inb && Z > cam::MIN_DEPTH) ? prm.weight_scale : 0.0f;  // geom.py:263, buffer.py:413
       const float wc[2] = {val * wg.x, val * wg.y};
       const float rc[2] = {x - tgt.x, y - tgt.y};
@@ -727,7 +761,7 @@ __global__ __launch_bounds__(TILE) void ba_accum_mfma_kernel(BAArgs a) {
           }
         }
         // R1 rows of this term and component
-        const float sw = sqrtf(wc[c]);
+        const float sw = __builtin_amdgcn_sqrtf(wc[c]);  // v_sqrt_f32 (1 ulp): only splits w between the Gram factors
         float* col = wbuf + (uu * RPT) * AM_P1 + c * 64 + lane;
 #pragma unroll
         for (int q = 0; q < 6; ++q) col[q * AM_P1] = Jj[q] * sw;
@@ -781,6 +815,7 @@ __global__ __launch_bounds__(TILE) void ba_accum_mfma_kernel(BAArgs a) {
     __builtin_amdgcn_wave_barrier();
   }
 
+  BA_STAMP(2);
   // ---- finish the disparity block of this pixel: sensor prior, damping (terms.py:258-268, buffer.py:482-489)
   float sq = 0.0f;
   const int NR = 6 * (deg + 1) + F + 1;  // R2 rows: pose i, targets, intrinsics, w
@@ -800,18 +835,29 @@ __global__ __launch_bounds__(TILE) void ba_accum_mfma_kernel(BAArgs a) {
 #pragma unroll
         for (int f = 0; f < F; ++f) w.Ef[((int64_t)k * 2 + f) * P + p] = Efr[f];
       }
-      sq = sqrtf(1.0f / C);
+      sq = __builtin_amdgcn_rsqf(C);  // sqrt(Q), Q = 1 / C
     }
     // R2 rows, scaled by sqrt(Q)
     float* col = wbuf + lane;
 #pragma unroll
     for (int q = 0; q < 6; ++q) col[q * AM_P2] = fi ? Ei[q] * sq : 0.0f;
-    for (int t = 0; t < deg; ++t) {
-      const TermGeom& G = tg[t].g;
-      const bool fj = G.sj >= 0;
+    {
+      // all E_j rows of this pixel in flight at once (a per-term loop serialises one L2 round trip per term)
+      float ej[AM_DMAX][6];
 #pragma unroll
-      for (int q = 0; q < 6; ++q)
-        col[(6 * (t + 1) + q) * AM_P2] = (fj && inb) ? w.Ej[((int64_t)G.e * 6 + q) * P + p] * sq : 0.0f;
+      for (int t = 0; t < AM_DMAX; ++t) {
+        const bool on = t < deg && tg[min(t, deg - 1)].g.sj >= 0 && inb;
+        const int64_t eb = (int64_t)tg[min(t, deg - 1)].g.e * 6 * P + p;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) ej[t][q] = on ? w.Ej[eb + (int64_t)q * P] : 0.0f;
+      }
+#pragma unroll
+      for (int t = 0; t < AM_DMAX; ++t) {
+        if (t < deg) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) col[(6 * (t + 1) + q) * AM_P2] = ej[t][q] * sq;
+        }
+      }
     }
     if constexpr (F > 0) {
 #pragma unroll
@@ -836,7 +882,9 @@ __global__ __launch_bounds__(TILE) void ba_accum_mfma_kernel(BAArgs a) {
         }
       }
   }
+  BA_STAMP(3);
   __syncthreads();
+  BA_STAMP(4);
 
   // ---- per-term blocks from the Gram sums (one wave per term)
   for (int t = wave; t < deg; t += NWAVE) {
@@ -898,6 +946,7 @@ __global__ __launch_bounds__(TILE) void ba_accum_mfma_kernel(BAArgs a) {
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
+  BA_STAMP(5);
 
   // ---- frame level: H_ii, v_i, H_if, H_ff, v_f
   {
@@ -947,6 +996,7 @@ __global__ __launch_bounds__(TILE) void ba_accum_mfma_kernel(BAArgs a) {
       }
     }
   }
+  BA_STAMP(6);
 }
 
 // 1/sqrt(x) in fp64: hardware estimate + 2 Newton steps (avoids the long sqrt / divide sequences on the
@@ -983,10 +1033,30 @@ __device__ __forceinline__ void apply_retraction(const BAArgs& a, int t, int nth
 // When the reduced system is banded (sliding-window / neighbourhood graphs: two poses couple only through a shared
 // source frame) and its band fits the 160 KB of LDS, the whole factorisation runs out of LDS: every dependent step
 // then costs an LDS round trip (~100 cycles) instead of an L2 round trip (~2000), which is what bounds this
-// latency-critical kernel.  Storage: pose row r keeps columns [lo(r), r], lo(r) = 6 * max(0, r/6 - bandblk), at
-// pitch WB + 1 doubles; the dense tail rows (intrinsics, then the rhs) are kept full length.  Block size 6 = one
-// pose.  Sets info[5] = 1 when it solved the system (the global-memory kernel launched after it then exits).
+// latency-critical kernel.  Storage: pose row r keeps columns [6 (r/6 - bandblk), 6 (r/6) + 5] at pitch WB + 1
+// doubles (so the LDS address of (row j0 + 6 + i, column j0 + m) advances by a constant per block step and every
+// thread's operand addresses are computed once); the dense tail rows (intrinsics, then the rhs) are kept full
+// length.  Block size 6 = one pose.  Per block step: panel (one row per lane), barrier, trailing update (one
+// (row, row) pair per lane, descriptors fixed over the steps) while lane 0 of wave 0 - whose wave owns the 21
+// entries of the NEXT diagonal block - already factors that block (look-ahead), barrier.  The back substitution is
+// run by wave 0 alone: 8 lanes per column, DPP reductions, the 6x6 triangular solve replicated in every lane with
+// stored reciprocal pivots - no workgroup barrier and no division on the dependent chain.
+// Sets info[5] = 1 when it solved the system (the global-memory kernel launched after it then exits).
 constexpr int BAND_T = 512;
+
+#define VIPE_DPP_F64(v, ctrl)                                                                                    \
+  __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(                         \
+                                  0, (int)(__builtin_bit_cast(unsigned long long, v) >> 32), ctrl, 0xf, 0xf, true) \
+                              << 32) |                                                                           \
+                                 (unsigned)__builtin_amdgcn_update_dpp(                                          \
+                                     0, (int)__builtin_bit_cast(unsigned long long, v), ctrl, 0xf, 0xf, true))
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)u, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), lane);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 
 __global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds_doubles) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -997,32 +1067,47 @@ __global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds
   const int n = w.info[3], n_free = w.info[0], bandblk = w.info[4];
   const int ld = w.ld;
   const int npr = 6 * n_free, ntail = n - npr + 1;  // tail rows: intrinsics rows, then the rhs row
-  const int WB = 6 * (bandblk + 1), WBP = WB + 1;
-  // LDS carve: band [npr][WBP], tail [ntail][n + 1], blk[6][7], rd[6], xs[6], flags
-  const int need = npr * WBP + ntail * (n + 1) + 64;
+  const int F = ntail - 1;
+  const int PB = 6 * bandblk, WB = PB + 6, WBP = WB + 1, KS = 6 * WBP;
+  const int npp = PB * (PB + 1) / 2, ntp = ntail * PB, ntt = F == 0 ? 0 : (F == 1 ? 2 : 5);
+  const int npair = npp + ntp + ntt;
+  // LDS carve: band [npr][WBP], tail [ntail][n + 1], rdall [npr], blk[6][7], rd[6], flags
+  const int TL0 = npr * WBP;
+  const int RD0 = TL0 + ntail * (n + 1);
+  const int need = RD0 + npr + 64;
   if (t == 0) w.info[5] = 0;
-  if (n == 0 || need > lds_doubles) return;
-  double* const Bd = L;
-  double* const Tl = L + npr * WBP;
-  double* const blk = Tl + ntail * (n + 1);  // 6x7
-  double* const rd = blk + 42;
-  double* const xs = rd + 6;
-  int* const failp = reinterpret_cast<int*>(xs + 6);
+  if (n == 0 || need > lds_doubles || npair > 21 + 2 * (BAND_T - 64) || PB + ntail > BAND_T || WBP > 64 || F > 2) {
+#ifdef VIPE_BA_STAMPS
+    if (t == 0) printf("band solve skipped: n %d need %d lds %d npair %d PB %d ntail %d F %d bandblk %d\n", n, need, lds_doubles, npair, PB, ntail, F, bandblk);
+#endif
+    return;
+  }
+  double* const Tl = L + TL0;
+  double* const rdall = L + RD0;          // 1 / L[r][r] of the pose rows
+  double* const blk = rdall + npr;        // 6x7: the current diagonal factor block
+  double* const rd = blk + 42;            // its reciprocal pivots
+  int* const failp = reinterpret_cast<int*>(rd + 6);
   const double* S = w.S;
-  auto lo = [&](int r) { return 6 * max(0, r / 6 - bandblk); };
-  auto bref = [&](int r, int c) -> double& { return Bd[r * WBP + (c - lo(r))]; };
+  auto bofs = [&](int r, int c) { return r * WBP + c - 6 * (r / 6) + PB; };
   auto tref = [&](int q, int c) -> double& { return Tl[q * (n + 1) + c]; };
+  SOLVE_STAMP(0);
 
   // ---- load (with LM damping on the diagonal, matrix.py:179-186)
   if (t == 0) *failp = 0;
-  for (int idx = t; idx < npr * WBP; idx += BAND_T) {
-    const int r = idx / WBP, k = idx % WBP, c = lo(r) + k;
-    double v = 0.0;
-    if (c <= r) {
-      v = S[(int64_t)r * ld + c];
-      if (c == r) v += (double)prm.pose_ep + (double)prm.pose_damping * w.Hd[r];
+  {
+    // one band row (WB <= 64 doubles, contiguous in S) per wave and iteration; unrolled so that a dozen row loads are
+    // in flight per wave (the loop is otherwise one L2 round trip per row)
+    const int wv = t >> 6, ln = t & 63;
+#pragma unroll 12
+    for (int r = wv; r < npr; r += BAND_T / 64) {
+      const int c = 6 * (r / 6) - PB + ln;
+      double v = 0.0;
+      if (ln < WB && c >= 0 && c <= r) {
+        v = S[(int64_t)r * ld + c];
+        if (c == r) v += (double)prm.pose_ep + (double)prm.pose_damping * w.Hd[r];
+      }
+      if (ln < WBP) L[r * WBP + ln] = v;
     }
-    Bd[idx] = v;
   }
   for (int idx = t; idx < ntail * (n + 1); idx += BAND_T) {
     const int q = idx / (n + 1), c = idx % (n + 1), r = npr + q;
@@ -1033,45 +1118,97 @@ __global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds
     }
     Tl[idx] = v;
   }
+
+  // ---- per-thread operand descriptors, fixed over the block steps (offsets in doubles from L at step 0 + stride)
+  // panel: thread pr < PB + ntail owns one row below the diagonal block
+  int prow_off = 0, prow_str = 0, prow_ia = -1;  // prow_ia >= 0: pose row offset (valid while 6 kb + 6 + ia < npr)
+  const bool has_prow = t < PB + ntail;
+  if (has_prow) {
+    if (t < PB) { prow_ia = t; prow_off = (6 + t) * WBP - 6 - 6 * (t / 6) + PB; prow_str = KS; }
+    else { prow_off = TL0 + (t - PB) * (n + 1); prow_str = 6; }
+  }
+  // update: pair index t + BAND_T * slot (slot < UPT) -> one (a, b) pair, b <= a: pose-pose, tail-pose, tail-tail
+  constexpr int UPT = 2;
+  int uA[UPT], uB[UPT], uD[UPT], sA[UPT], sB[UPT], sD[UPT], u_ia[UPT], u_ib[UPT];
+  bool has_pair[UPT];
+#pragma unroll
+  for (int sl = 0; sl < UPT; ++sl) {
+    // pairs 0..20 (the next diagonal block) are lanes 0..20 of wave 0 and nothing else runs there: that wave goes
+    // straight on to factor the next block; the other pairs are spread over waves 1..7
+    const int pid = t < 64 ? (sl == 0 && t < 21 ? t : npair) : 21 + (t - 64) + (BAND_T - 64) * sl;
+    has_pair[sl] = pid < npair;
+    uA[sl] = uB[sl] = uD[sl] = sA[sl] = sB[sl] = sD[sl] = 0;
+    u_ia[sl] = u_ib[sl] = -1;
+    if (!has_pair[sl]) continue;
+    if (pid < npp) {
+      int ia = (int)((sqrtf(8.0f * (float)pid + 1.0f) - 1.0f) * 0.5f);
+      while ((ia + 1) * (ia + 2) / 2 <= pid) ++ia;
+      while (ia * (ia + 1) / 2 > pid) --ia;
+      const int ib = pid - ia * (ia + 1) / 2;
+      u_ia[sl] = ia; u_ib[sl] = ib;
+      uA[sl] = (6 + ia) * WBP - 6 - 6 * (ia / 6) + PB; sA[sl] = KS;
+      uB[sl] = (6 + ib) * WBP - 6 - 6 * (ib / 6) + PB; sB[sl] = KS;
+      uD[sl] = (6 + ia) * WBP + ib - 6 * (ia / 6) + PB; sD[sl] = KS;
+    } else if (pid < npp + ntp) {
+      const int u = pid - npp, q = u / PB, ib = u % PB;
+      u_ib[sl] = ib;
+      uA[sl] = TL0 + q * (n + 1); sA[sl] = 6;
+      uB[sl] = (6 + ib) * WBP - 6 - 6 * (ib / 6) + PB; sB[sl] = KS;
+      uD[sl] = TL0 + q * (n + 1) + 6 + ib; sD[sl] = 6;
+    } else {
+      // (q, q2), q2 <= q, q2 < ntail - 1 (the rhs row has no column): F = 1: (0,0) (1,0); F = 2: (0,0) (1,0) (1,1) (2,0) (2,1)
+      const int v = pid - npp - ntp;
+      int q, q2;
+      if (F == 1) { q = v; q2 = 0; }
+      else { q = v == 0 ? 0 : (v <= 2 ? 1 : 2); q2 = v == 0 ? 0 : (v <= 2 ? v - 1 : v - 3); }
+      uA[sl] = TL0 + q * (n + 1); sA[sl] = 6;
+      uB[sl] = TL0 + q2 * (n + 1); sB[sl] = 6;
+      uD[sl] = TL0 + q * (n + 1) + npr + q2; sD[sl] = 0;
+    }
+  }
+  // 6x6 diagonal block of pose kb: factor in registers, publish L (band), blk, rd, rdall
+  auto factor_diag = [&](int kb) {
+    const int j0 = 6 * kb;
+    double* Dk = L + bofs(j0, j0);  // row i of the block at Dk + i * WBP
+    double A[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) A[i][j] = Dk[i * WBP + j];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      double d = A[j][j];
+#pragma unroll
+      for (int m = 0; m < j; ++m) d -= A[j][m] * A[j][m];
+      if (!(d > 0.0)) { *failp = 1; d = 1.0; }
+      const double rl = rsqrt_nr(d);
+      A[j][j] = d * rl;
+      rd[j] = rl;
+      rdall[j0 + j] = rl;
+#pragma unroll
+      for (int i = j + 1; i < 6; ++i) {
+        double sacc = A[i][j];
+#pragma unroll
+        for (int m = 0; m < j; ++m) sacc -= A[i][m] * A[j][m];
+        A[i][j] = sacc * rl;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) { Dk[i * WBP + j] = A[i][j]; blk[i * 7 + j] = A[i][j]; }
+  };
+  __syncthreads();
+  SOLVE_STAMP(1);
+  if (t == 0 && n_free > 0) factor_diag(0);
   __syncthreads();
 
   // ---- factorisation, one pose block (6 columns) per step
   for (int kb = 0; kb < n_free; ++kb) {
     const int j0 = 6 * kb;
-    if (t == 0) {  // 6x6 diagonal block
-      double A[6][6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) A[i][j] = bref(j0 + i, j0 + j);
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        double d = A[j][j];
-#pragma unroll
-        for (int m = 0; m < j; ++m) d -= A[j][m] * A[j][m];
-        if (!(d > 0.0)) { *failp = 1; d = 1.0; }
-        const double rl = rsqrt_nr(d);
-        A[j][j] = d * rl;
-        rd[j] = rl;
-#pragma unroll
-        for (int i = j + 1; i < 6; ++i) {
-          double sacc = A[i][j];
-#pragma unroll
-          for (int m = 0; m < j; ++m) sacc -= A[i][m] * A[j][m];
-          A[i][j] = sacc * rl;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) { bref(j0 + i, j0 + j) = A[i][j]; blk[i * 7 + j] = A[i][j]; }
-    }
-    __syncthreads();
-    // panel: pose rows (j0+6 .. re) and all tail rows: x = a Lkk^-T
-    const int re = min(npr, 6 * (kb + bandblk + 1));
-    const int nr = max(re - (j0 + 6), 0);
-    for (int pr = t; pr < nr + ntail; pr += BAND_T) {
-      double* row = pr < nr ? &bref(j0 + 6 + pr, j0) : &tref(pr - nr, j0);
+    // panel: x = a Lkk^-T for every row below the block (pose rows inside the band, all tail rows)
+    if (has_prow && (prow_ia < 0 || j0 + 6 + prow_ia < npr)) {
+      double* row = L + prow_off + kb * prow_str;
       double x[6];
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
@@ -1084,26 +1221,28 @@ __global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds
       for (int j = 0; j < 6; ++j) row[j] = x[j];
     }
     __syncthreads();
-    // trailing update over the affected rows: (a, b) with b <= a; pose rows index 0..nr-1, tail rows nr..nr+ntail-1
-    const int na = nr + ntail;
-    for (int idx = t; idx < na * na; idx += BAND_T) {
-      const int ia = idx / na, ib = idx % na;
-      if (ib > ia) continue;
-      const bool ta = ia >= nr, tb = ib >= nr;
-      if (tb && ib - nr == ntail - 1) continue;  // the rhs row has no column
-      const double* pa = ta ? &tref(ia - nr, j0) : &bref(j0 + 6 + ia, j0);
-      const double* pb = tb ? &tref(ib - nr, j0) : &bref(j0 + 6 + ib, j0);
-      double sacc = 0.0;
+    // trailing update, one (a, b) pair per thread
 #pragma unroll
-      for (int m = 0; m < 6; ++m) sacc += pa[m] * pb[m];
-      const int cb = tb ? npr + (ib - nr) : j0 + 6 + ib;  // global column of b
-      if (ta) tref(ia - nr, cb) -= sacc;
-      else bref(j0 + 6 + ia, cb) -= sacc;
+    for (int sl = 0; sl < UPT; ++sl) {
+      if (has_pair[sl] && (u_ia[sl] < 0 || j0 + 6 + u_ia[sl] < npr) && (u_ib[sl] < 0 || j0 + 6 + u_ib[sl] < npr)) {
+        const double* pa = L + uA[sl] + kb * sA[sl];
+        const double* pb = L + uB[sl] + kb * sB[sl];
+        double sacc = 0.0;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) sacc += pa[m] * pb[m];
+        L[uD[sl] + kb * sD[sl]] -= sacc;
+      }
+    }
+    // look-ahead: the 21 entries of the next diagonal block are pairs 0..20, all in wave 0
+    if (t < 64) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (t == 0 && kb + 1 < n_free) factor_diag(kb + 1);
     }
     __syncthreads();
   }
+  SOLVE_STAMP(2);
   // ---- tail columns (intrinsics unknowns), unblocked
-  const int F = ntail - 1;
   for (int f = 0; f < F; ++f) {
     const int cf = npr + f;
     if (t == 0) {
@@ -1117,50 +1256,72 @@ __global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds
     }
     __syncthreads();
   }
-  // ---- back substitution L^T x = y; y = rhs row (tail row F), solved in place
+  // ---- back substitution L^T x = y; y = rhs row (tail row F), solved in place by wave 0
   double* y = &tref(F, 0);
-  if (t == 0) {
-    for (int f = F - 1; f >= 0; --f) {
-      double sacc = y[npr + f];
-      for (int q = f + 1; q < F; ++q) sacc -= tref(q, npr + f) * y[npr + q];
-      y[npr + f] = sacc / tref(f, npr + f);
-    }
-  }
-  __syncthreads();
-  for (int kb = n_free - 1; kb >= 0; --kb) {
-    const int j0 = 6 * kb;
-    const int re = min(npr, 6 * (kb + bandblk + 1));
-    const int nr = max(re - (j0 + 6), 0);
-    // s_j = y[j0+j] - sum over rows below (band + intrinsics rows) L[r][j0+j] x[r]: one wave per column j
-    const int wv = t >> 6, ln = t & 63;
-    if (wv < 6) {
-      float dummy = 0.f;
-      (void)dummy;
-      double part = 0.0;
-      for (int q = ln; q < nr + F; q += 64) {
-        const double lv = q < nr ? bref(j0 + 6 + q, j0 + wv) : tref(q - nr, j0 + wv);
-        const double xv = q < nr ? y[j0 + 6 + q] : y[npr + (q - nr)];
-        part += lv * xv;
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, WAVE);
-      if (ln == 0) xs[wv] = y[j0 + wv] - part;
-    }
-    __syncthreads();
+  SOLVE_STAMP(3);
+  if (t < 64) {
+    // column-oriented: once x of block kb is known (6x6 triangular solve, replicated in every lane from broadcast
+    // LDS reads, reciprocal pivots), lane c subtracts its contribution from y of band row 6 kb - PB + c right away,
+    // so no reduction and no cross-lane traffic sits on the dependent chain
     if (t == 0) {
+      for (int f = F - 1; f >= 0; --f) {
+        double sacc = y[npr + f];
+        for (int q = f + 1; q < F; ++q) sacc -= tref(q, npr + f) * y[npr + q];
+        y[npr + f] = sacc / tref(f, npr + f);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (F > 0) {
+      for (int r = t; r < npr; r += 64) {
+        double sacc = y[r];
+        for (int f = 0; f < F; ++f) sacc -= tref(f, r) * y[npr + f];
+        y[r] = sacc;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    for (int kb = n_free - 1; kb >= 0; --kb) {
+      const int j0 = 6 * kb;
+      const double* Dk = L + bofs(j0, j0);
+      // operands that do not depend on the running y: block factor, reciprocal pivots, this lane's column of the
+      // six block rows (entries L[j0 + j][6 kb - PB + t])
+      double Lk[6][6], rp[6], lc[6];
+      const int rt = j0 - PB + t;
+      const bool upd = t < PB && rt >= 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        rp[i] = rdall[j0 + i];
+        lc[i] = upd ? L[(j0 + i) * WBP + t] : 0.0;
+#pragma unroll
+        for (int j = 0; j < i; ++j) Lk[i][j] = Dk[i * WBP + j];
+      }
       double x[6];
 #pragma unroll
       for (int j = 5; j >= 0; --j) {
-        double sacc = xs[j];
+        double sacc = y[j0 + j];
 #pragma unroll
-        for (int m = 5; m > j; --m) sacc -= bref(j0 + m, j0 + j) * x[m];
-        x[j] = sacc / bref(j0 + j, j0 + j);
+        for (int m = 5; m > j; --m) sacc -= Lk[m][j] * x[m];
+        x[j] = sacc * rp[j];
       }
+      if (t < 6) {
+        double xo = x[0];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) y[j0 + j] = x[j];
+        for (int j = 1; j < 6; ++j) xo = t == j ? x[j] : xo;
+        y[j0 + t] = xo;
+      }
+      if (upd) {
+        double sacc = lc[0] * x[0];
+#pragma unroll
+        for (int j = 1; j < 6; ++j) sacc += lc[j] * x[j];
+        y[rt] -= sacc;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
   }
+  __syncthreads();
+  SOLVE_STAMP(4);
   const bool bad = *failp != 0;
   if (t == 0) {
     if (bad) w.info[2] += 1;
@@ -1173,6 +1334,7 @@ __global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds
   }
   __syncthreads();
   apply_retraction(a, t, BAND_T, n_free);
+  SOLVE_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------ solve
@@ -1523,6 +1685,13 @@ int run_iters(const BAArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef VIPE_BA_STAMPS
+VIPE_EXPORT int vipe_diag_set_ba_stamps(void* d_buf) {
+  unsigned long long* p = (unsigned long long*)d_buf;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ba_stamps), &p, sizeof(p));
+}
+#endif
 
 VIPE_EXPORT int64_t vipe_dense_ba_workspace_bytes(const vipe_ba_params* p) {
   if (!p || p->n_poses <= 0 || p->n_views <= 0 || p->ht <= 0 || p->wd <= 0 || p->M < 0) return VIPE_EINVAL;
