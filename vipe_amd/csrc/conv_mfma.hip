@@ -1091,6 +1091,123 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   CONV_STAMP(4);
 }
 
+// ---- 3x3 with at most 16 output channels (flow / confidence heads: 4, eta: 1).  One 16x16x32 A fragment covers all
+// couts, so a K step of one tap is only 2 MFMAs per wave and the per-tap barrier of the general kernel dominates
+// (measured 221 us for 15.6 GFLOP).  Here a step is a whole 32-channel chunk: the 9 taps' weights (9 x 1 KiB) and
+// the halo chunk are double buffered, one barrier per chunk, 18 MFMAs per wave between barriers.
+constexpr int NRW_WBYTES = 9 * 1024;
+constexpr size_t NRW_LDS = 2 * NRW_WBYTES + 2 * H32_XBYTES + 1024;
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_halo32_narrow_kernel(ConvArgs a) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 3, pxh = (wave >> 2) * 32;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles_per_img = a.H / HALO_TH;
+  const int e = tile / tiles_per_img, y0 = (tile % tiles_per_img) * HALO_TH;
+  const int64_t pix0 = (int64_t)tile * (HALO_TH * HALO_TW);
+  const int cs32 = a.Cin_pad / H32_BK, cs64 = a.Cin_pad / 64;
+  const int r16 = lane >> 2, sl = lane & 3, l16 = lane & 15, lk = lane >> 4;
+  const unsigned ldsW_a = lds_address(lds), ldsX_a = ldsW_a + 2 * NRW_WBYTES, sink_a = ldsX_a + 2 * H32_XBYTES;
+  const unsigned char* ldsW = lds;
+  const unsigned char* ldsX = lds + 2 * NRW_WBYTES;
+  const half_t* zp = reinterpret_cast<const half_t*>(g_zero_page);
+
+  int xpix[H32_XP];
+  const int xk = (sl ^ swzf<true>(r16)) * 8;
+#pragma unroll
+  for (int i = 0; i < H32_XP; ++i) {
+    const int pce = wave + 8 * i;
+    const int r = pce * 16 + r16;
+    const int hy = r / HALO_PITCH, hx = r % HALO_PITCH;
+    const int y = y0 + hy - 1, x = hx - 1;
+    const bool ok = pce < H32_PIECES && r < HALO_ROWS && y >= 0 && y < a.H && x >= 0 && x < a.W;
+    xpix[i] = ok ? (e * a.H + y) * a.W + x : -1;
+  }
+  auto issue = [&](int c, int buf) {
+    const int c0 = c * H32_BK;
+    const bool s0 = c0 < a.split;
+    const int ctot = s0 ? a.x0_ctot : a.x1_ctot;
+    const int cb = (s0 ? a.x0_coff : a.x1_coff - a.split) + c0;
+#pragma unroll
+    for (int i = 0; i < H32_XP; ++i) {
+      if (wave + 8 * i < H32_PIECES) {
+        const bool ok = xpix[i] >= 0 && (c0 + xk < a.Cin);
+        const unsigned off = ((unsigned)xpix[i] * (unsigned)ctot + (unsigned)(cb + xk)) * 2u;
+        const char* src = reinterpret_cast<const char*>(s0 ? a.x0 : a.x1) + off;
+        glds16(ok ? (const void*)src : (const void*)zp, ldsX_a + buf * H32_XBYTES + (wave + 8 * i) * 1024);
+      }
+    }
+    // weights: tap `wave` (and tap 8 on wave 0): rows 0..15 of packed block tap * cs64 + c / 2, 64-byte half c & 1
+    const unsigned woff = (unsigned)(r16 * 64 + ((sl ^ swzf<true>(r16)) << 3)) * 2u;
+    const half_t* wb = a.w + ((int64_t)(wave * cs64 + (c >> 1)) * a.Cout_pad) * BK + (c & 1) * H32_BK;
+    glds16_off(wb, woff, ldsW_a + buf * NRW_WBYTES + wave * 1024);
+    if (wave == 0) {
+      const half_t* w8 = a.w + ((int64_t)(8 * cs64 + (c >> 1)) * a.Cout_pad) * BK + (c & 1) * H32_BK;
+      glds16_off(w8, woff, ldsW_a + buf * NRW_WBYTES + 8 * 1024);
+    }
+  };
+
+  float4v acc[2] = {float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}};
+  const int wa0 = swz32<true>(l16, lk);
+  const int Rl0 = wn * HALO_PITCH + pxh + l16;
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int c = 0; c < cs32; ++c) {
+    if (c + 1 < cs32) issue(c + 1, (c + 1) & 1);
+    const unsigned char* bw = ldsW + (c & 1) * NRW_WBYTES;
+    const unsigned char* bx = ldsX + (c & 1) * H32_XBYTES;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int rb = Rl0 + (tap / 3) * HALO_PITCH + (tap % 3);
+      const int xa0 = swz32<true>(rb, lk);
+      const half8 wf = *reinterpret_cast<const half8*>(bw + (wa0 + tap * 1024));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const half8 xf = *reinterpret_cast<const half8*>(bx + (xa0 + j * 1024));
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf, acc[j], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // ---- epilogue: fp32 tile [256 px][16 couts] through LDS, one pixel per thread
+  constexpr int PITCH = 20;
+  float* stage = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    *reinterpret_cast<float4*>(stage + (wn * 64 + pxh + j * 16 + l16) * PITCH + 4 * lk) =
+        make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+  __syncthreads();
+  if (tid < HALO_TH * HALO_TW) {
+    const int64_t m = pix0 + tid;
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 t4 = *reinterpret_cast<const float4*>(stage + tid * PITCH + 4 * q);
+      v[4 * q] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      v[q] += a.bias[q];
+      if (a.extra && q < a.Cout) v[q] += a.extra[(int64_t)e * a.extra_stride + a.extra_off + q];
+    }
+    if (a.epi == EPI_HEADS) {
+      // cout 0,1: delta; cout 2,3: sigmoid -> weight (droid_net.py:486-490); written as float [M,4]
+      *reinterpret_cast<float4*>(a.fout + m * 4) =
+          make_float4((float)(half_t)v[0], (float)(half_t)v[1], (float)(half_t)act_apply(v[2], VIPE_ACT_SIGMOID),
+                      (float)(half_t)act_apply(v[3], VIPE_ACT_SIGMOID));
+    } else if (a.epi == EPI_ETA) {
+      const float sp = v[0] > 20.0f ? v[0] : log1pf(__expf(v[0]));  // 0.01 * softplus (droid_net.py:410,429)
+      a.fout[m] = 0.01f * (float)(half_t)sp;
+    } else {
+      half_t* dst = a.y + m * a.y_ctot + a.y_coff;
+      for (int q = 0; q < a.Cout; ++q) dst[q] = (half_t)act_apply(v[q], a.act);
+    }
+  }
+}
+
 // ---- 7x7, 4 input channels (the flow encoder's first conv, droid_net.py:447): K = 49 taps x 4 = 196 -> 224.
 // The whole packed weight tensor (4 blocks of [128 cout][64 k], 64 KiB) is brought to LDS once by LDS-DMA; the
 // (4 + 6) x (64 + 6) pixel halo of the tile (8 B per pixel, 5.5 KiB) is staged through registers.  A 16x16x32
@@ -1280,6 +1397,16 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
   const bool halo = glds && a.W == HALO_TW && a.H % HALO_TH == 0 && a.KH == a.KW && (a.KH == 1 || a.KH == 3) &&
                     (int64_t)a.B * a.H * a.W * (a.x0_ctot > a.x1_ctot ? a.x0_ctot : a.x1_ctot) * 2 < (1ll << 32) &&
                     getenv("VIPE_AMD_CONV_NOHALO") == nullptr;
+  if (halo && a.KH == 3 && a.Cout <= 16 && cp == 32 && (a.split >= a.Cin || a.split % H32_BK == 0) &&
+      (a.epi == EPI_HEADS || a.epi == EPI_ETA || a.epi == EPI_PLAIN) && getenv("VIPE_AMD_CONV_NONARROW") == nullptr) {
+    static bool nattr = false;
+    if (!nattr) {
+      (void)hipFuncSetAttribute((const void*)conv_halo32_narrow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRW_LDS);
+      nattr = true;
+    }
+    conv_halo32_narrow_kernel<<<dim3((int)(M / (HALO_TH * HALO_TW))), 512, NRW_LDS, s>>>(a);
+    return vipe_launch_status();
+  }
   if (halo && (a.split >= a.Cin || a.split % H32_BK == 0) && getenv("VIPE_AMD_CONV_HALO64") == nullptr) {
     static bool h32attr = false;
     const int bmc = cp >= 128 ? 128 : cp;

@@ -231,6 +231,103 @@ __global__ __launch_bounds__(256) void corr_pyramid_lookup_rows_kernel(LevelPtrs
     for (int qq = L * RD * RD; qq < nhwc_stride; ++qq) out[((int64_t)n * P + p) * nhwc_stride + qq] = (half_t)0;
 }
 
+// ---- channels-last, 4 levels in one workgroup: the 8 loads of a lane (2 per level) are issued back to back (4x the
+// memory-level parallelism of the per-level launch) and the pixel's 196 + 4 channels are staged in LDS so that the
+// output leaves as full 16-byte stores, 400 contiguous bytes per pixel (the per-level kernel writes 2-byte pieces:
+// 437 MB of HBM writes for 339 MB of output at E = 276).  Same taps, weights and addition chains as above.
+constexpr int LK4_PITCH = 208;  // halves per staged pixel (16-byte aligned rows)
+
+__global__ __launch_bounds__(256) void corr_pyramid_lookup_rows4_kernel(LevelPtrs lv, const float* __restrict__ coords,
+                                                                        half_t* __restrict__ out, int h1, int w1, int h2,
+                                                                        int w2, int nhwc_stride) {
+  constexpr int R = 3, RD = 7, L = 4;
+  using A = Acc<half_t>;
+  __shared__ __align__(16) half_t stage[32 * LK4_PITCH];
+  const int P = h1 * w1;
+  const int j = threadIdx.x & 7;       // tap row
+  const int pl = threadIdx.x >> 3;     // pixel of the workgroup
+  const int p = blockIdx.x * 32 + pl;
+  const int n = blockIdx.y;
+  const bool pok = p < P;
+  const int pc = pok ? p : P - 1;
+  const float2 c = reinterpret_cast<const float2*>(coords)[(int64_t)n * P + pc];
+  uint4v lo[L], hi[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const float sc = 1.0f / (float)(1 << l);
+    const int h2l = h2 >> l, w2l = w2 >> l;
+    const int bx = (int)floorf(c.x * sc) - R, by = (int)floorf(c.y * sc) - R;
+    const int y1 = by + j, c0 = bx >> 3, nchunks = w2l >> 3;
+    const bool rowok = (y1 >= 0) & (y1 < h2l);
+    const half_t* slab = reinterpret_cast<const half_t*>(lv.p[l]) + ((int64_t)n * P + pc) * ((int64_t)h2l * w2l);
+    const uint4v* rowp = reinterpret_cast<const uint4v*>(slab + (int64_t)(rowok ? y1 : 0) * w2l);
+    lo[l] = uint4v{0, 0, 0, 0};
+    hi[l] = uint4v{0, 0, 0, 0};
+    if (rowok & (c0 >= 0) & (c0 < nchunks)) lo[l] = rowp[c0];
+    if (rowok & (c0 + 1 >= 0) & (c0 + 1 < nchunks)) hi[l] = rowp[c0 + 1];
+  }
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const float sc = 1.0f / (float)(1 << l);
+    const float x0 = c.x * sc, y0 = c.y * sc;
+    const float fx = floorf(x0), fy = floorf(y0);
+    const float dx = x0 - fx, dy = y0 - fy;
+    const int sh = ((int)fx - R) & 7;
+    const float w11 = A::weight(dx * dy), w10 = A::weight(dx * (1.0f - dy));
+    const float w01 = A::weight((1.0f - dx) * dy), w00 = A::weight((1.0f - dx) * (1.0f - dy));
+    unsigned d[8] = {lo[l][0], lo[l][1], lo[l][2], lo[l][3], hi[l][0], hi[l][1], hi[l][2], hi[l][3]};
+    const int q = sh >> 1;
+    unsigned a1[7], f[5];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) a1[k] = (q & 1) ? d[k + 1] : d[k];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) f[k] = (q & 2) ? a1[k + 2] : a1[k];
+    unsigned e[4], ne[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = (sh & 1) ? __builtin_amdgcn_alignbyte(f[k + 1], f[k], 2) : f[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ne[k] = __shfl_down(e[k], 1, 8);
+    float t[8], nb[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      half_t h0, h1v;
+      unsigned short u0 = (unsigned short)(e[k] & 0xffffu), u1 = (unsigned short)(e[k] >> 16);
+      __builtin_memcpy(&h0, &u0, 2);
+      __builtin_memcpy(&h1v, &u1, 2);
+      t[2 * k] = (float)h0;
+      t[2 * k + 1] = (float)h1v;
+      u0 = (unsigned short)(ne[k] & 0xffffu);
+      u1 = (unsigned short)(ne[k] >> 16);
+      __builtin_memcpy(&h0, &u0, 2);
+      __builtin_memcpy(&h1v, &u1, 2);
+      nb[2 * k] = (float)h0;
+      nb[2 * k + 1] = (float)h1v;
+    }
+    if (j < RD) {
+#pragma unroll
+      for (int a = 0; a < RD; ++a) {
+        float acc = 0.0f;
+        acc = A::madd(acc, t[a], w00);       // tap (i=a,   j)
+        acc = A::madd(acc, nb[a], w01);      // tap (i=a,   j+1)
+        acc = A::madd(acc, t[a + 1], w10);   // tap (i=a+1, j)
+        acc = A::madd(acc, nb[a + 1], w11);  // tap (i=a+1, j+1)
+        stage[pl * LK4_PITCH + l * (RD * RD) + a * RD + j] = A::store(acc);
+      }
+    }
+  }
+  if (j < 4) stage[pl * LK4_PITCH + L * RD * RD + j] = (half_t)0;
+  __syncthreads();
+  // 16-byte pieces of the staged pixels: nhwc_stride / 8 per pixel
+  const int cpp = nhwc_stride >> 3;
+  for (int i = threadIdx.x; i < 32 * cpp; i += 256) {
+    const int pq = i / cpp, ck = i % cpp;
+    const int pg = blockIdx.x * 32 + pq;
+    if (pg < P)
+      *reinterpret_cast<uint4v*>(out + ((int64_t)n * P + pg) * nhwc_stride + ck * 8) =
+          *reinterpret_cast<const uint4v*>(stage + pq * LK4_PITCH + ck * 8);
+  }
+}
+
 // adjoint: each lane owns its pixel's slab, so plain stores into a zero-filled gradient are race free.
 template <typename T, int R>
 __global__ __launch_bounds__(256) void corr_index_backward_kernel(const float* __restrict__ coords,
@@ -360,6 +457,11 @@ static int pyramid_lookup_impl(const void* const* h_levels, const float* d_coord
   }
   hipStream_t s = as_stream(stream);
   if (dtype == VIPE_F16 && radius == 3 && ((w2 >> (num_levels - 1)) & 7) == 0 && getenv("VIPE_AMD_LOOKUP_SIMPLE") == nullptr) {
+    if (num_levels == 4 && nhwc_stride == 200 && getenv("VIPE_AMD_LOOKUP_PERLEVEL") == nullptr) {
+      corr_pyramid_lookup_rows4_kernel<<<dim3((h1 * w1 + 31) / 32, B), 256, 0, s>>>(lv, d_coords, (half_t*)d_out, h1, w1,
+                                                                                   h2, w2, nhwc_stride);
+      return vipe_launch_status();
+    }
     dim3 grid((h1 * w1 + 31) / 32, B, num_levels);
     corr_pyramid_lookup_rows_kernel<<<grid, 256, 0, s>>>(lv, d_coords, (half_t*)d_out, h1, w1, h2, w2, num_levels,
                                                           nhwc_stride);
