@@ -279,9 +279,71 @@ def gen_lie_wrapper(R):
     np.savez_compressed(os.path.join(HERE, "lie_wrapper_reference.npz"), **out)
 
 
+def gen_edge_selection(R):
+    """Golden vector #8 of SURVEY 8(c): the exact (ii, jj) lists `FactorGraph.add_proximity_factors`
+    (factor_graph.py:411-488) hands to add_factors, from the reference file itself driven by a fake buffer whose
+    frame distances come from a fixed matrix.  Pure integer / ordering logic -> pins "bit-exact edge indexing"."""
+    for name in ["rerun"]:
+        sys.modules.setdefault(name, types.ModuleType(name))
+    comp = types.ModuleType("vipe.slam.components")
+    comp.__path__ = []
+    sys.modules["vipe.slam.components"] = comp
+    sys.modules["vipe.slam"].components = comp
+    bufmod = types.ModuleType("vipe.slam.components.buffer")
+    bufmod.GraphBuffer = type("GraphBuffer", (), {})
+    sys.modules["vipe.slam.components.buffer"] = bufmod
+    comp.buffer = bufmod
+    fg = _load("vipe.slam.components.factor_graph", "vipe/slam/components/factor_graph.py")
+    out = {}
+    cases = {
+        # name: (n_frames, existing edge radius, n inactive, t0, t1, rad, nms, beta, thresh, max_factors, seed)
+        "frontend": (12, 2, 3, 7, 2, 2, 2, 0.25, 16.0, 48, 1),
+        "backend": (16, 0, 0, 0, 0, 2, 2, 0.25, 20.0, 16 * 16, 2),
+        "backend_dense": (14, 1, 4, 0, 0, 3, 1, 0.25, 30.0, 60, 3),
+    }
+    for cname, (t, er, ninac, t0, t1, rad, nms, beta, thresh, maxf, seed) in cases.items():
+        rng = np.random.default_rng(seed)
+        D = rng.uniform(0.0, 40.0, size=(t, t)).astype(np.float32)
+        ii0, jj0 = np.meshgrid(np.arange(t), np.arange(t), indexing="ij")
+        keep = (np.abs(ii0 - jj0) > 0) & (np.abs(ii0 - jj0) <= er)
+        ii_act, jj_act = ii0[keep].astype(np.int64), jj0[keep].astype(np.int64)
+        inac = rng.integers(0, t, size=(ninac, 2)).astype(np.int64)
+
+        class FakeBuffer:
+            n_frames = t
+            n_views = 1
+
+            def frame_distance_dense_disp(self, ii, jj, beta):
+                return torch.from_numpy(D)[ii, jj][:, None]
+
+        g = object.__new__(fg.FactorGraph)
+        g.buffer, g.device, g.cross_view, g.max_factors = FakeBuffer(), torch.device("cpu"), False, maxf
+        g.ii, g.jj = torch.from_numpy(ii_act), torch.from_numpy(jj_act)
+        g.ii_inac, g.jj_inac = torch.from_numpy(inac[:, 0].copy()), torch.from_numpy(inac[:, 1].copy())
+        got = {}
+
+        def record(ii, jj, remove=False, got=got):
+            got["ii"], got["jj"], got["remove"] = ii.numpy().copy(), jj.numpy().copy(), remove
+
+        g.add_factors = record
+        g.add_proximity_factors(t0, t1, rad, nms, beta, thresh, True)
+        out[cname + "_D"] = D
+        out[cname + "_params"] = np.array([t, t0, t1, rad, nms, maxf], dtype=np.int64)
+        out[cname + "_beta_thresh"] = np.array([beta, thresh], dtype=np.float64)
+        out[cname + "_act"] = np.stack([ii_act, jj_act], 1)
+        out[cname + "_inac"] = inac
+        out[cname + "_es"] = np.stack([got["ii"], got["jj"]], 1).astype(np.int64)
+    np.savez_compressed(os.path.join(HERE, "edge_selection_reference.npz"), **out)
+    print("edge selection:", {k: v.shape for k, v in out.items() if k.endswith("_es")})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     R = load_reference()
+    if os.environ.get("GOLDEN_ONLY") == "edges":
+        gen_edge_selection(R)
+        sys.exit(0)
+    gen_edge_selection(R)
     gen_lie_wrapper(R)
     gen_reproject(R)
     gen_ba(R)

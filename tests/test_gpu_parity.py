@@ -657,3 +657,36 @@ def test_corr_pyramid_build_fused_kernel(shape):
         assert float((vol.view(lv[i].shape).float() - lv[i].float()).abs().max()) <= 2e-2
         if i < 3:
             vol = torch.nn.functional.avg_pool2d(vol, 2, stride=2)
+
+
+def test_add_proximity_factors_on_device_buffer():
+    """Edge proposal end to end on the device buffer (frame_distance kernel -> host NMS, factor_graph.py:411-488):
+    the edge list equals the one the same selection logic produces from the ORACLE's frame distances (the selection
+    logic itself is pinned against the reference's own code in test_oracle_golden)."""
+    import types
+
+    from oracle import frame_ops as ofo
+    from vipe_amd.slam.factor_graph import FactorGraph
+
+    g, buf, graph, um = _tiny_graph(n=7, seed=44)
+    n = 7
+    graph.rm_factors(torch.ones(len(graph.ii), dtype=torch.bool))  # start from an empty graph
+    graph.max_factors = 64
+    graph.add_proximity_factors(t0=0, t1=0, rad=1, nms=1, beta=0.25, thresh=1e3, remove=False)
+    got = np.stack([graph.ii.cpu().numpy(), graph.jj.cpu().numpy()], 1)
+    # oracle distances into the same host logic
+    ii, jj = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    ii, jj = ii.reshape(-1), jj.reshape(-1)
+    z = np.zeros_like(ii)
+    intr8 = (g.intrinsics / 8.0).astype(np.float32)
+    dij = ofo.frame_distance(g.poses, g.disps, intr8, ii, jj, z, z, ii, 0.25)
+    dji = ofo.frame_distance(g.poses, g.disps, intr8, jj, ii, z, z, jj, 0.25)
+    D = torch.from_numpy((0.5 * (dij + dji)).reshape(n, n))  # buffer.py:585-590 bidirectional mean
+    ref = object.__new__(FactorGraph)
+    ref.buffer = types.SimpleNamespace(n_frames=n, n_views=1, frame_distance_dense_disp=lambda a, b, beta: D[a, b][:, None])
+    ref.device, ref.cross_view, ref.max_factors = torch.device("cpu"), False, 64
+    ref.ii = ref.jj = ref.ii_inac = ref.jj_inac = torch.zeros(0, dtype=torch.long)
+    out = {}
+    ref.add_factors = lambda a, b, remove=False: out.update(e=torch.stack([a, b], 1).numpy())
+    ref.add_proximity_factors(t0=0, t1=0, rad=1, nms=1, beta=0.25, thresh=1e3, remove=False)
+    assert len(got) > 2 * (n - 1) and np.array_equal(got, out["e"])

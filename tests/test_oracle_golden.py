@@ -210,3 +210,32 @@ def test_update_module_matches_reference():
     assert np.allclose(weight.numpy(), G["out_weight"], atol=2e-5)
     assert np.allclose(eta.numpy(), G["out_eta"], atol=2e-6)
     assert np.allclose(upmask[:, :, ::16].numpy(), G["out_upmask_sub"], atol=2e-5)
+
+
+@pytest.mark.parametrize("case", ["frontend", "backend", "backend_dense"])
+def test_add_proximity_factors_edge_lists_match_reference(case):
+    """Golden vector #8: the (ii, jj) lists handed to add_factors by the reference's own
+    `add_proximity_factors` (factor_graph.py:411-488, run from the reference file with a fake buffer) - integer-exact,
+    including order.  The distances are injected, so this pins the host-side selection / NMS / ordering logic; the
+    distances themselves are the `frame_distance` kernel's business (test_gpu_parity)."""
+    import types
+
+    from vipe_amd.slam.factor_graph import FactorGraph
+
+    g = np.load(os.path.join(GOLD, "edge_selection_reference.npz"))
+    t, t0, t1, rad, nms, maxf = [int(x) for x in g[case + "_params"]]
+    beta, thresh = [float(x) for x in g[case + "_beta_thresh"]]
+    D = torch.from_numpy(g[case + "_D"])
+    fgr = object.__new__(FactorGraph)
+    fgr.buffer = types.SimpleNamespace(n_frames=t, n_views=1,
+                                       frame_distance_dense_disp=lambda ii, jj, beta: D[ii, jj][:, None])
+    fgr.device, fgr.cross_view, fgr.max_factors = torch.device("cpu"), False, maxf
+    fgr.ii, fgr.jj = torch.from_numpy(g[case + "_act"][:, 0].copy()), torch.from_numpy(g[case + "_act"][:, 1].copy())
+    fgr.ii_inac = torch.from_numpy(g[case + "_inac"][:, 0].copy())
+    fgr.jj_inac = torch.from_numpy(g[case + "_inac"][:, 1].copy())
+    got = {}
+    fgr.add_factors = lambda ii, jj, remove=False: got.update(ii=ii.numpy(), jj=jj.numpy(), remove=remove)
+    fgr.add_proximity_factors(t0, t1, rad, nms, beta, thresh, True)
+    es = g[case + "_es"]
+    assert got["remove"] is True
+    assert np.array_equal(np.stack([got["ii"], got["jj"]], 1), es)

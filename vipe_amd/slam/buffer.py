@@ -105,6 +105,18 @@ class GraphBuffer:
             intr[:, 0:2] = intr[:, 0:2] / (1 + self.intrinsics[:, 4:5])
         return intr.contiguous()
 
+    def remove_second_newest(self, ix):
+        """buffer.py:218-231: keyframe ix is overwritten by its successor (the newest frame)."""
+        assert ix == self.n_frames - 2
+        for name in ("tstamp", "images", "poses", "disps", "disps_sens", "nets", "inps", "fmaps", "masks",
+                     "cross_view_idx"):
+            arr = getattr(self, name, None)
+            if arr is not None:
+                arr[ix] = arr[ix + 1]
+        if getattr(self, "dirty", None) is not None:
+            self.dirty[ix] = True
+        self.n_frames -= 1
+
     def frame_distance_dense_disp(self, ii, jj, beta=0.3, bidirectional=True, view_offset=0):
         """buffer.py:550-593 -> [M, n_views]."""
         from ..ext.lietorch import SE3

@@ -6,6 +6,7 @@ correlation lookup -> flow-update operator -> dense BA.  Per iteration it issues
 scatter_mean's index.max(), every _tmult_mat_elements and the CPU spsolve).
 """
 
+import numpy as np
 import torch
 
 from ..ext import slam_ext
@@ -13,12 +14,13 @@ from .networks import AltCorrBlock, CorrBlock
 
 
 class FactorGraph:
-    def __init__(self, update_module, buffer, device, max_factors=48, incremental=True):
+    def __init__(self, update_module, buffer, device, max_factors=48, incremental=True, cross_view=False):
         self.update_op = update_module
         self.buffer = buffer
         self.device = device
         self.max_factors = max_factors
         self.incremental = incremental
+        self.cross_view = cross_view and buffer.n_views > 1  # factor_graph.py:62
         ht, wd = buffer.height // 8, buffer.width // 8
         self.ht, self.wd = ht, wd
         self.ii = torch.as_tensor([], dtype=torch.long, device=device)
@@ -100,6 +102,90 @@ class FactorGraph:
         ii, jj = ii.reshape(-1), jj.reshape(-1)
         keep = ((ii - jj).abs() > 0) & ((ii - jj).abs() <= r)
         self.add_factors(ii[keep], jj[keep])
+
+    @torch.no_grad()
+    def add_proximity_factors(self, t0=0, t1=0, rad=2, nms=2, beta=0.25, thresh=16.0, remove=False):
+        """Edge proposal (factor_graph.py:411-488): neighbourhood edges i-rad-1..i-1 <-> i for i in [t0, t), then
+        proximity edges (i, j), i in [t0, t), j in [t1, t), j <= i - rad, in order of increasing frame distance with
+        non-maximum suppression around every edge already present or just added; all made bidirectional.
+
+        Integer-exact mirror of the reference: the frame distances come from ONE launch of the HIP `frame_distance`
+        kernel and ONE device-to-host copy; the suppression / ordering logic (a few hundred candidates) then runs on
+        the host exactly as the reference's Python does (which instead pays one `.item()` sync per candidate)."""
+        assert t0 >= t1, "t0 should be a subset of t1"
+        t = self.buffer.n_frames
+        ix = torch.arange(t0, t, device=self.device)
+        jx = torch.arange(t1, t, device=self.device)
+        ii, jj = torch.meshgrid(ix, jx, indexing="ij")
+        ii, jj = ii.reshape(-1), jj.reshape(-1)
+        if ii.numel() == 0:
+            return
+        d = self.buffer.frame_distance_dense_disp(ii, jj, beta=beta).mean(-1).cpu().numpy().astype(np.float32)
+        iin, jjn = ii.cpu().numpy(), jj.cpu().numpy()
+        nj = t - t1
+
+        def suppress(i, j):
+            if (t0 <= i < t) and (t1 <= j < t):
+                d[(i - t0) * nj + (j - t1)] = np.inf
+
+        def suppress_nms(i, j):
+            lim = max(min(abs(i - j) - 2, nms), 0)
+            for di in range(-nms, nms + 1):
+                for dj in range(-nms, nms + 1):
+                    if abs(di) + abs(dj) <= lim:
+                        suppress(i + di, j + dj)
+
+        for i, j in zip(self.ii.tolist(), self.jj.tolist()):
+            suppress_nms(i, j)
+        for i, j in zip(self.ii_inac.tolist(), self.jj_inac.tolist()):
+            suppress_nms(i, j)
+        d[(iin - rad < jjn) | (d > thresh)] = np.inf
+        es = []
+        for i in range(t0, t):
+            if self.cross_view:
+                es.append((i, i))
+                suppress(i, i)
+            for j in range(max(i - rad - 1, 0), i):
+                es.append((i, j))
+                es.append((j, i))
+                suppress(i, j)
+        for k in np.argsort(d, kind="stable"):
+            if d[k] > thresh:
+                continue
+            if len(es) > self.max_factors:
+                break
+            i, j = int(iin[k]), int(jjn[k])
+            es.append((i, j))
+            es.append((j, i))
+            suppress_nms(i, j)
+        if len(es) == 0:
+            return
+        e = torch.as_tensor(es, device=self.device)
+        self.add_factors(e[:, 0], e[:, 1], remove)
+
+    @torch.no_grad()
+    def rm_second_newest_keyframe(self, ix):
+        """factor_graph.py:204-228: drop keyframe ix (= n_frames - 2) from the buffer and the graph."""
+        self.buffer.remove_second_newest(ix)
+        m = (self.ii_inac == ix) | (self.jj_inac == ix)
+        self.ii_inac[self.ii_inac >= ix] -= 1
+        self.jj_inac[self.jj_inac >= ix] -= 1
+        if bool(m.any()):
+            self.ii_inac, self.jj_inac = self.ii_inac[~m], self.jj_inac[~m]
+            m_exp = m.view(-1, 1).repeat(1, self.buffer.n_views).view(-1)
+            self.target_inac = self.target_inac[:, ~m_exp]
+            self.weight_inac = self.weight_inac[:, ~m_exp]
+        m = (self.ii == ix) | (self.jj == ix)
+        self.ii[self.ii >= ix] -= 1
+        self.jj[self.jj >= ix] -= 1
+        self.rm_factors(m, store=False)
+
+    def get_edges_np(self):
+        """factor_graph.py:110-117."""
+        ii, jj = self.ii.cpu().numpy(), self.jj.cpu().numpy()
+        w = torch.mean(self.weight, dim=[0, 2, 3, 4]).cpu().numpy()
+        ix = np.argsort(ii)
+        return np.stack([ii[ix], jj[ix]], axis=1), w[ix]
 
     @property
     def f_net(self):
