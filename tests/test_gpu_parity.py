@@ -353,9 +353,12 @@ def test_conv_halo_tile_kernel_against_torch_fp32():
     from vipe_amd._lib import check, lib, ptr, stream_ptr
     from vipe_amd.slam.update_engine import _Packed
     torch.manual_seed(5)
-    for (B, H, cin, cout, k, act) in [(2, 8, 128, 128, 3, "relu"), (1, 4, 448, 256, 3, "none"), (3, 12, 200, 128, 1, "relu"),
-                                      (2, 8, 128, 384, 3, "tanh")]:
-        W = 64
+    for (B, H, W, cin, cout, k, act) in [(2, 8, 64, 128, 128, 3, "relu"), (1, 4, 64, 448, 256, 3, "none"),
+                                         (3, 12, 64, 200, 128, 1, "relu"), (2, 8, 64, 128, 384, 3, "tanh"),
+                                         # config 5 (1024x512 -> 64x128 grid): two 64-column segments per row
+                                         (1, 8, 128, 128, 128, 3, "relu"), (2, 4, 128, 200, 128, 1, "none"),
+                                         (1, 8, 128, 4, 128, 7, "relu"), (2, 8, 128, 256, 4, 3, "none"),
+                                         (1, 4, 192, 128, 64, 3, "sigmoid")]:
         x = (torch.randn(B, H, W, cin) * 0.5).half().to(dev())
         w = (torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5).half()
         b = torch.randn(cout) * 0.1
@@ -690,3 +693,43 @@ def test_add_proximity_factors_on_device_buffer():
     ref.add_factors = lambda a, b, remove=False: out.update(e=torch.stack([a, b], 1).numpy())
     ref.add_proximity_factors(t0=0, t1=0, rad=1, nms=1, beta=0.25, thresh=1e3, remove=False)
     assert len(got) > 2 * (n - 1) and np.array_equal(got, out["e"])
+
+
+def test_config5_grid_dense_ba_and_update_operator():
+    """BASELINE config 5 shape (1024x512 image -> 64x128 grid, P = 8192, pinhole model - the reference has no panorama
+    projection): a small graph through the dense BA against the fp64 oracle (1e-4), and the flow-update operator on
+    the halo-tile convolution path for width 128 against the torch-fp32 restatement of the reference operator."""
+    from oracle import update_module as oum
+    from vipe_amd.slam.networks import UpdateModule
+
+    g = make_graph(n=3, height=512, width=1024, radius=2, seed=55)
+    assert (g.ht, g.wd) == (64, 128)
+    bk = dict(t0=1, t1=3, n_iters=2, pose_damping=1e-3, pose_ep=0.1, motion_only=False, limited_disp=False,
+              optimize_intrinsics=False)
+    p, d, k, info = run_hip_ba(g, g.intrinsics, "pinhole", bk)
+    E = len(g.ii)
+    op, od, _, _ = oba.bundle_adjustment(g.poses, g.disps[:, None], g.disps_sens[:, None], g.intrinsics,
+                                         ose3.se3_identity(1), g.target.reshape(E, -1, 2), g.weight.reshape(E, -1, 2),
+                                         g.eta[:, None], g.ii, g.jj, **bk)
+    assert np.abs(p - op).max() <= 1e-4 * max(1.0, np.abs(op).max())
+    assert np.abs(d - od[:, 0]).max() <= 1e-4 * np.abs(od).max()
+    # flow-update operator at 64 x 128
+    torch.manual_seed(0)
+    um = UpdateModule().eval()
+    gen = torch.Generator().manual_seed(8)
+    n = 2
+    net = torch.randn(1, n, 128, 64, 128, generator=gen).tanh().half()
+    inp = torch.randn(1, n, 128, 64, 128, generator=gen).relu().half()
+    corr = (torch.randn(1, n, 196, 64, 128, generator=gen) * 0.5).half()
+    flow = (torch.randn(1, n, 4, 64, 128, generator=gen) * 2).half()
+    ix = torch.tensor([0, 1])
+    eng = um.engine(dev())
+    net_d, delta_d, weight_d, eta_d, _ = eng.forward(net.to(dev()), inp.to(dev()), corr.to(dev()), flow.to(dev()), ix.to(dev()),
+                                                     skip_upmask=True)
+    sd = {kk: w.float() for kk, w in um.state_dict().items()}
+    with torch.no_grad():
+        net_r, delta_r, weight_r, eta_r, _ = oum.update_forward(sd, net.float(), inp.float(), corr.float(), flow.float(), ix)
+    assert (net_d.float().cpu() - net_r).abs().max().item() < 0.03
+    assert (delta_d.float().cpu() - delta_r).abs().max().item() < 0.05
+    assert (weight_d.float().cpu() - weight_r).abs().max().item() < 0.02
+    assert (eta_d.float().cpu() - eta_r).abs().max().item() < 2e-3

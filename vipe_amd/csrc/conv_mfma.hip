@@ -396,299 +396,6 @@ __device__ __forceinline__ void glds16_off(const void* base, unsigned voff_bytes
 #endif
 }
 
-template <int BMC, int KS>
-__global__ __launch_bounds__(512) void conv_halo_kernel(ConvArgs a, int gy) {
-  // BMC = 128: waves = 2 cout halves x 4 image rows, wave tile 64 couts x 64 px; BMC = 64: 32 couts x 64 px;
-  // BMC = 32: waves = 4 rows x 2 half rows, wave tile 32 couts x 32 px (flow / confidence heads, eta)
-  constexpr int TM = BMC >= 128 ? 2 : 1, TN = BMC == 32 ? 1 : 2, BP = HALO_TH * HALO_TW;
-  extern __shared__ __align__(16) unsigned char lds[];
-  unsigned char* ldsW = lds;                          // [3][BMC rows * 128 B] weight ring
-  unsigned char* ldsX = lds + 3 * BMC * 128;          // [2][400 rows * 128 B] halo double buffer, then 2 KiB sink
-
-  CONV_STAMP(0);
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = BMC == 32 ? 0 : (wave >> 2), wn = wave & 3;  // cout half, image row of the tile
-  const int pxh = BMC == 32 ? (wave >> 2) * 32 : 0;           // BMC = 32: which half of the row
-  const int L = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile = L / gy, cout0 = (L % gy) * BMC;
-  const int tiles_per_img = a.H / HALO_TH;
-  const int e = tile / tiles_per_img, y0 = (tile % tiles_per_img) * HALO_TH;
-  const int64_t pix0 = (int64_t)tile * BP;
-  const int64_t M = (int64_t)a.B * a.H * a.W;
-  const int HW = a.H * a.W;
-  const int ph = a.KH / 2, pw = a.KW / 2, ntaps = a.KH * a.KW;
-  const int csteps = a.Cin_pad / BK;
-  const int r8 = lane >> 3, sl = lane & 7;
-
-  // ---- descriptors
-  // every wave issues exactly two weight DMAs per step (real pieces first, then dummies) so the hand-counted
-  // vmcnt below is the same for every tile shape: BMC/8 pieces of 1 KiB over 8 waves
-  constexpr int WPW = BMC / 64;  // real pieces per wave: 2, 1, or (BMC = 32) one for waves 0..3
-  const int nwreal = BMC == 32 ? (wave < 4 ? 1 : 0) : WPW;
-  unsigned woff[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int row = ((BMC == 128 ? wave * 2 + q : wave) * 8 + r8) % BMC;
-    woff[q] = (unsigned)(row * BK + ((sl ^ ((row >> 1) & 7)) << 3)) * 2u;
-  }
-  unsigned xo0[HALO_XP], xo1[HALO_XP];
-  int xk8[HALO_XP];
-  const unsigned BAD = 0xffffffffu;
-#pragma unroll
-  for (int i = 0; i < HALO_XP; ++i) {
-    const int pce = wave + 8 * i;
-    const int r = pce * 8 + r8;
-    const int hy = r / HALO_PITCH, hx = r % HALO_PITCH;
-    const int y = y0 + hy - 1, x = hx - 1;
-    const bool ok = pce < HALO_PIECES && r < HALO_ROWS && y >= 0 && y < a.H && x >= 0 && x < a.W;
-    const int k8 = sl ^ ((r >> 1) & 7);
-    xk8[i] = k8 * 8;
-    const int64_t pix = ok ? ((int64_t)(e * a.H + y) * a.W + x) : 0;
-    xo0[i] = ok ? (unsigned)((pix * a.x0_ctot + a.x0_coff + k8 * 8) * 2) : BAD;
-    xo1[i] = ok ? (unsigned)((pix * a.x1_ctot + a.x1_coff + k8 * 8 - a.split) * 2) : BAD;
-  }
-  const half_t* zp = reinterpret_cast<const half_t*>(g_zero_page);
-  // LDS byte addresses as integers (one generic->LDS cast in the whole kernel)
-  const unsigned ldsW_a = lds_address(lds), ldsX_a = ldsW_a + 3 * BMC * 128;
-  const unsigned dummy_a = ldsX_a + 2 * HALO_LDS_ROWS * 128;  // 2 KiB sink for the count-keeping dummy DMAs
-
-  auto issueX = [&](int c, int i, int buf) {
-    const int c0 = c * BK;
-    const bool s0 = c0 < a.split;
-    const unsigned off = s0 ? xo0[i] : xo1[i];
-    const bool ok = off != BAD && (c0 + xk8[i] < a.Cin);
-    const unsigned lx = (ldsX_a + buf * HALO_LDS_ROWS * 128) + (wave + 8 * i) * 1024;
-    // invalid lanes read the 16-byte zero page
-    const char* src = reinterpret_cast<const char*>(s0 ? a.x0 : a.x1) + (off + (unsigned)c0 * 2u);
-    glds16(ok ? (const void*)src : (const void*)zp, lx);
-  };
-
-  float16v acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  // ---- pipeline.  3x3 (KS = 3): the 9 taps are FULLY UNROLLED, so the ring positions ((9c + tap) % 3 = tap % 3),
-  // the tap offsets and the descriptor registers of the halo piece issued at each tap are compile-time constants
-  // (the K-step is instruction-issue bound: runtime divisions / compare chains per step cost more than the MFMAs).
-  // Weights run 2 steps ahead through the 3-deep ring; every step issues exactly 3 LDS-DMAs per wave (2 weight
-  // slots, then 1 halo piece of the next chunk or a dummy), so "s_waitcnt vmcnt(4)" at the end of step s retires
-  // W(s+1) while W(s+2) and the two newest halo pieces stay in flight; a halo piece issued at step s has landed by
-  // the end of step s+2, i.e. pieces issued at taps 0..6 are complete when the chunk ends.
-  // 1x1 (KS = 1, one tap per chunk): prefetch distance 1 with a full drain per step.
-  const int lrow = lane & 31, lhalf = lane >> 5;
-  const int64_t tapstride = (int64_t)csteps * a.Cout_pad * BK;  // weight elements between consecutive taps
-  auto mma_step = [&](const unsigned char* bw, const unsigned char* bx, int dy, int dx) {
-    const int rx0 = (wn + dy + 1) * HALO_PITCH + (pxh + lrow + dx + 1);
-#pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      half8 wf[TM], xf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        wf[i] = *reinterpret_cast<const half8*>(bw + swz((wm * TM + i) * 32 + lrow, kk * 2 + lhalf));
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        xf[j] = *reinterpret_cast<const half8*>(bx + swz(rx0 + j * 32, kk * 2 + lhalf));
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-    }
-  };
-  auto issueW_at = [&](const half_t* wb, int buf) {  // two weight slots (real pieces, then dummies)
-    const unsigned lw = (ldsW_a + buf * BMC * 128) + (BMC == 128 ? wave * 2048 : (wave * 1024) % (BMC * 128));
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (q < nwreal) glds16_off(wb, woff[q], lw + q * 1024);
-      else glds16(zp, dummy_a + q * 1024);
-    }
-  };
-  auto issueW_dummy = [&]() {
-    glds16(zp, dummy_a);
-    glds16(zp, dummy_a + 1024);
-  };
-  const half_t* wtile0 = a.w + (int64_t)cout0 * BK;  // + (tap * csteps + c) * Cout_pad * BK
-
-#pragma unroll
-  for (int i = 0; i < HALO_XP; ++i)
-    if (wave + 8 * i < HALO_PIECES) issueX(0, i, 0);
-  issueW_at(wtile0, 0);
-  if constexpr (KS == 3) issueW_at(wtile0 + tapstride, 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  CONV_STAMP(1);
-
-  if constexpr (KS == 3) {
-    for (int c = 0; c < csteps; ++c) {
-      const unsigned char* bx = ldsX + (c & 1) * HALO_LDS_ROWS * 128;
-      const half_t* wc = wtile0 + (int64_t)c * a.Cout_pad * BK;
-      const bool more = c + 1 < csteps;
-      auto tap_step = [&](auto TAPC) {
-        constexpr int TAP = decltype(TAPC)::value;
-        constexpr int T2 = TAP + 2;
-        // 1. LDS-DMAs of step + 2 (hidden from hipcc's waitcnt bookkeeping, counted by hand below)
-        if constexpr (T2 < 9) {
-          issueW_at(wc + T2 * tapstride, T2 % 3);
-        } else {
-          if (more) issueW_at(wc + (int64_t)a.Cout_pad * BK + (T2 - 9) * tapstride, T2 % 3);
-          else issueW_dummy();
-        }
-        if constexpr (TAP < HALO_XP) {
-          if (more && wave + 8 * TAP < HALO_PIECES) issueX(c + 1, TAP, (c + 1) & 1);
-          else glds16(zp, dummy_a);
-        } else {
-          glds16(zp, dummy_a);
-        }
-        // 2. fragments + matrix cores
-        mma_step(ldsW + (TAP % 3) * BMC * 128, bx, TAP / 3 - 1, TAP % 3 - 1);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        __syncthreads();
-      };
-      tap_step(std::integral_constant<int, 0>{});
-      tap_step(std::integral_constant<int, 1>{});
-      tap_step(std::integral_constant<int, 2>{});
-      tap_step(std::integral_constant<int, 3>{});
-      tap_step(std::integral_constant<int, 4>{});
-      tap_step(std::integral_constant<int, 5>{});
-      tap_step(std::integral_constant<int, 6>{});
-      tap_step(std::integral_constant<int, 7>{});
-      tap_step(std::integral_constant<int, 8>{});
-    }
-  } else {
-    for (int c = 0; c < csteps; ++c) {
-      const unsigned char* bx = ldsX + (c & 1) * HALO_LDS_ROWS * 128;
-      if (c + 1 < csteps) {
-        issueW_at(wtile0 + (int64_t)(c + 1) * a.Cout_pad * BK, (c + 1) & 1);
-#pragma unroll
-        for (int i = 0; i < HALO_XP; ++i)
-          if (wave + 8 * i < HALO_PIECES) issueX(c + 1, i, (c + 1) & 1);
-      }
-      mma_step(ldsW + (c & 1) * BMC * 128, bx, 0, 0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-  }
-  // ---- epilogue through LDS: the accumulator layout (lane = pixel, registers = 4-cout groups) would store 8-byte
-  // pieces at a 256-byte stride (64 segments per wave instruction).  Stage the fp32 tile [256 px][128 co] in LDS
-  // (row pitch 132 floats: the 16-lane write groups hit 64 distinct banks), then every lane handles 8 consecutive
-  // channels of one pixel: 16-byte loads of net / z, 16-byte stores, 256 contiguous bytes per pixel.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  CONV_STAMP(2);
-  {
-    constexpr int PITCH = BMC + 4, CPP = BMC / 8;  // floats per staged pixel row, 8-channel chunks per pixel
-    constexpr int NIT = BP * CPP / 512, PSTEP = 512 / CPP;
-    float* stage = reinterpret_cast<float*>(lds);
-    const int ch = (tid % CPP) * 8, co = cout0 + ch, pl0 = tid / CPP;
-    // the epilogue's global operands (hidden state, update gate) do not depend on the staged tile: issue every
-    // load now so that their latency overlaps the staging writes and the barrier instead of serialising the loop
-    const bool want_net = a.epi == EPI_GLO || a.epi == EPI_Q || (a.epi == EPI_ZR && co >= 128);
-    const bool want_z = a.epi == EPI_Q;
-    half8 nvv[NIT], zvv[NIT];
-    {
-      const int cn = a.epi == EPI_ZR ? co - 128 : co;
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int64_t m = pix0 + pl0 + PSTEP * it;
-        if (want_net) nvv[it] = *reinterpret_cast<const half8*>(a.net + m * a.net_ctot + a.net_coff + cn);
-        if (want_z) zvv[it] = *reinterpret_cast<const half8*>(a.zbuf + m * 128 + co);
-      }
-    }
-    float bv[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      bv[q] = (co + q < a.Cout) ? a.bias[co + q] : 0.0f;
-      if (a.extra && co + q < a.Cout) bv[q] += a.extra[(int64_t)e * a.extra_stride + a.extra_off + co + q];
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int pl = wn * 64 + pxh + j * 32 + lrow, cs = wm * (TM * 32) + i * 32 + 8 * g + 4 * lhalf;
-          *reinterpret_cast<float4*>(stage + pl * PITCH + cs) =
-              make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-        }
-    __syncthreads();
-    CONV_STAMP(3);
-    float gsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int pl = pl0 + PSTEP * it;
-      const int64_t m = pix0 + pl;
-      const float4 v0 = *reinterpret_cast<const float4*>(stage + pl * PITCH + ch);
-      const float4 v1 = *reinterpret_cast<const float4*>(stage + pl * PITCH + ch + 4);
-      float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
-      half8 o;
-      half_t* dst = nullptr;
-      if (a.epi == EPI_PLAIN) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] = (half_t)act_apply(v[q], a.act);
-        dst = a.y + m * a.y_ctot + a.y_coff + co;
-      } else if (a.epi == EPI_GLO) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) gsum[q] += (float)(half_t)act_apply(v[q], VIPE_ACT_SIGMOID) * (float)nvv[it][q];
-      } else if (a.epi == EPI_ZR) {
-        if (co < 128) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) o[q] = (half_t)act_apply(v[q], VIPE_ACT_SIGMOID);
-          dst = a.y + m * a.y_ctot + a.y_coff + co;
-        } else {
-#pragma unroll
-          for (int q = 0; q < 8; ++q)
-            o[q] = (half_t)((float)(half_t)act_apply(v[q], VIPE_ACT_SIGMOID) * (float)nvv[it][q]);
-          dst = a.y2 + m * a.y2_ctot + a.y2_coff + co - 128;
-        }
-      } else if (a.epi == EPI_Q) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const float qq = (float)(half_t)tanhf(v[q]);
-          const float z = (float)zvv[it][q];
-          o[q] = (half_t)((1.0f - z) * (float)nvv[it][q] + z * qq);  // droid_net.py:399
-        }
-        dst = a.y + m * a.y_ctot + a.y_coff + co;
-      } else if (a.epi == EPI_HEADS) {
-        // cout 0,1: delta; cout 2,3: sigmoid -> weight (droid_net.py:486-490); written as float [M,4]
-        if (ch == 0)
-          *reinterpret_cast<float4*>(a.fout + m * 4) =
-              make_float4((float)(half_t)v[0], (float)(half_t)v[1], (float)(half_t)act_apply(v[2], VIPE_ACT_SIGMOID),
-                          (float)(half_t)act_apply(v[3], VIPE_ACT_SIGMOID));
-      } else if (a.epi == EPI_ETA) {
-        if (ch == 0) {  // 0.01 * softplus (droid_net.py:410,429)
-          const float sp = v[0] > 20.0f ? v[0] : log1pf(__expf(v[0]));
-          a.fout[m] = 0.01f * (float)(half_t)sp;
-        }
-      }
-      if (dst) {
-        if (co + 8 <= a.Cout) {
-          *reinterpret_cast<half8*>(dst) = o;
-        } else {
-          for (int q = 0; q < 8 && co + q < a.Cout; ++q) dst[q] = o[q];
-        }
-      }
-    }
-    if (a.epi == EPI_GLO) {
-      // threads with equal tid % CPP hold the same 8 channels (different pixels): fold them through LDS (the staged
-      // tile is dead after the barrier), then ONE atomic per channel and workgroup
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < 8; ++q) stage[(tid / CPP) * (BMC + 1) + ch + q] = gsum[q];
-      __syncthreads();
-      if (tid < BMC) {
-        float t = 0.0f;
-        for (int r = 0; r < 512 / CPP; ++r) t += stage[r * (BMC + 1) + tid];
-        if (cout0 + tid < a.Cout) atomicAdd(a.fout + (int64_t)e * a.Cout + cout0 + tid, t);
-      }
-    }
-  }
-  CONV_STAMP(4);
-}
-
 // ---- Halo-tile kernel, K step 32: TWO workgroups per CU.
 // Same tile (8 waves: 4 image rows x 64 px x BMC couts) and the same halo idea as above, but the channel chunk is 32
 // (64-byte LDS rows): halo double buffer 2 x 25 KiB + weight ring 3 x 8 KiB = 75 KiB, so two workgroups share a CU
@@ -729,9 +436,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int pxh = BMC == 32 ? (wave >> 2) * 32 : 0;           // BMC = 32: which half of the row
   const int L = xcd_remap(blockIdx.x, gridDim.x);
   const int tile = L / gy, cout0 = (L % gy) * BMC;
-  const int tiles_per_img = a.H / HALO_TH;
-  const int e = tile / tiles_per_img, y0 = (tile % tiles_per_img) * HALO_TH;
-  const int64_t pix0 = (int64_t)tile * BP;
+  const int xsegs = a.W / HALO_TW, tiles_per_img = (a.H / HALO_TH) * xsegs;
+  const int e = tile / tiles_per_img, trem = tile % tiles_per_img;
+  const int y0 = (trem / xsegs) * HALO_TH, x0 = (trem % xsegs) * HALO_TW;
+  // pixel index of tile pixel pl (row pl / 64, column pl % 64)
+  auto pix_of = [&](int pl) { return ((int64_t)(e * a.H + y0 + (pl >> 6))) * a.W + x0 + (pl & 63); };
   const int cs32 = a.Cin_pad / H32_BK, cs64 = a.Cin_pad / 64;
   const int r16 = lane >> 2, sl = lane & 3;
   const int lrow = lane & 31, lhalf = lane >> 5;
@@ -757,7 +466,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int pce = wave + 8 * i;
     const int r = pce * 16 + r16;
     const int hy = r / HALO_PITCH, hx = r % HALO_PITCH;
-    const int y = y0 + hy - 1, x = hx - 1;
+    const int y = y0 + hy - 1, x = x0 + hx - 1;
     const bool ok = pce < H32_PIECES && r < HALO_ROWS && y >= 0 && y < a.H && x >= 0 && x < a.W;
     xpix[i] = ok ? (e * a.H + y) * a.W + x : -1;
   }
@@ -971,7 +680,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const int cn = a.epi == EPI_ZR ? co - 128 : co;
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        const int64_t m = pix0 + pl0 + PSTEP * it;
+        const int64_t m = pix_of(pl0 + PSTEP * it);
         if (want_net) nvv[it] = *reinterpret_cast<const half8*>(a.net + m * a.net_ctot + a.net_coff + cn);
         if (want_z) zvv[it] = *reinterpret_cast<const half8*>(a.zbuf + m * 128 + co);
       }
@@ -982,7 +691,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int pl = pl0 + PSTEP * it;
-      const int64_t m = pix0 + pl;
+      const int64_t m = pix_of(pl);
       const half8 sv = *reinterpret_cast<const half8*>(stage + pl * PITCH + ch);
       half8 o = sv;
       half_t* dst = nullptr;
@@ -1059,7 +768,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int pl = pl0 + PSTEP * it;
-      const int64_t m = pix0 + pl;
+      const int64_t m = pix_of(pl);
       const float4 v0 = *reinterpret_cast<const float4*>(stage + pl * PITCH + ch);
       const float4 v1 = *reinterpret_cast<const float4*>(stage + pl * PITCH + ch + 4);
       const float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3],
@@ -1103,9 +812,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 3, pxh = (wave >> 2) * 32;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int tiles_per_img = a.H / HALO_TH;
-  const int e = tile / tiles_per_img, y0 = (tile % tiles_per_img) * HALO_TH;
-  const int64_t pix0 = (int64_t)tile * (HALO_TH * HALO_TW);
+  const int xsegs = a.W / HALO_TW, tiles_per_img = (a.H / HALO_TH) * xsegs;
+  const int e = tile / tiles_per_img, trem = tile % tiles_per_img;
+  const int y0 = (trem / xsegs) * HALO_TH, x0 = (trem % xsegs) * HALO_TW;
+  auto pix_of = [&](int pl) { return ((int64_t)(e * a.H + y0 + (pl >> 6))) * a.W + x0 + (pl & 63); };
   const int cs32 = a.Cin_pad / H32_BK, cs64 = a.Cin_pad / 64;
   const int r16 = lane >> 2, sl = lane & 3, l16 = lane & 15, lk = lane >> 4;
   const unsigned ldsW_a = lds_address(lds), ldsX_a = ldsW_a + 2 * NRW_WBYTES, sink_a = ldsX_a + 2 * H32_XBYTES;
@@ -1120,7 +830,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int pce = wave + 8 * i;
     const int r = pce * 16 + r16;
     const int hy = r / HALO_PITCH, hx = r % HALO_PITCH;
-    const int y = y0 + hy - 1, x = hx - 1;
+    const int y = y0 + hy - 1, x = x0 + hx - 1;
     const bool ok = pce < H32_PIECES && r < HALO_ROWS && y >= 0 && y < a.H && x >= 0 && x < a.W;
     xpix[i] = ok ? (e * a.H + y) * a.W + x : -1;
   }
@@ -1181,7 +891,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
   __syncthreads();
   if (tid < HALO_TH * HALO_TW) {
-    const int64_t m = pix0 + tid;
+    const int64_t m = pix_of(tid);
     float v[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1223,9 +933,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int wm = wave >> 2, wn = wave & 3;
   const int L = xcd_remap(blockIdx.x, gridDim.x);
   const int tile = L / gy, cout0 = (L % gy) * 128;
-  const int tiles_per_img = a.H / HALO_TH;
-  const int e = tile / tiles_per_img, y0 = (tile % tiles_per_img) * HALO_TH;
-  const int64_t pix0 = (int64_t)tile * (HALO_TH * HALO_TW);
+  const int xsegs = a.W / HALO_TW, tiles_per_img = (a.H / HALO_TH) * xsegs;
+  const int e = tile / tiles_per_img, trem = tile % tiles_per_img;
+  const int y0 = (trem / xsegs) * HALO_TH, x0 = (trem % xsegs) * HALO_TW;
+  auto pix_of = [&](int pl) { return ((int64_t)(e * a.H + y0 + (pl >> 6))) * a.W + x0 + (pl & 63); };
   const int l16 = lane & 15, lk = lane >> 4;
   const unsigned ldsW_a = lds_address(lds);
   unsigned char* ldsX = lds + C7_WBYTES;
@@ -1244,7 +955,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // halo pixels (zero outside the image)
   for (int i = tid; i < C7_PW * C7_ROWS; i += 512) {
     const int hy = i / C7_PW, hx = i % C7_PW;
-    const int y = y0 + hy - 3, x = hx - 3;
+    const int y = y0 + hy - 3, x = x0 + hx - 3;
     uint2 v = make_uint2(0u, 0u);
     if (y >= 0 && y < a.H && x >= 0 && x < a.W)
       v = *reinterpret_cast<const uint2*>(a.x0 + ((int64_t)(e * a.H + y) * a.W + x) * a.x0_ctot + a.x0_coff);
@@ -1301,7 +1012,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   for (int it = 0; it < 8; ++it) {
     const int pl = (tid >> 4) + 32 * it;
     const half8 o = *reinterpret_cast<const half8*>(stage + pl * PITCH + ch);
-    half_t* dst = a.y + (pix0 + pl) * a.y_ctot + a.y_coff + co;
+    half_t* dst = a.y + pix_of(pl) * a.y_ctot + a.y_coff + co;
     if (co + 8 <= a.Cout) {
       *reinterpret_cast<half8*>(dst) = o;
     } else {
@@ -1394,7 +1105,7 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
     attr = true;
   }
   const bool glds = !small && a.KH * a.KW <= 32 && getenv("VIPE_AMD_CONV_REGSTAGE") == nullptr;
-  const bool halo = glds && a.W == HALO_TW && a.H % HALO_TH == 0 && a.KH == a.KW && (a.KH == 1 || a.KH == 3) &&
+  const bool halo = glds && a.W % HALO_TW == 0 && a.H % HALO_TH == 0 && a.KH == a.KW && (a.KH == 1 || a.KH == 3) &&
                     (int64_t)a.B * a.H * a.W * (a.x0_ctot > a.x1_ctot ? a.x0_ctot : a.x1_ctot) * 2 < (1ll << 32) &&
                     getenv("VIPE_AMD_CONV_NOHALO") == nullptr;
   if (halo && a.KH == 3 && a.Cout <= 16 && cp == 32 && (a.split >= a.Cin || a.split % H32_BK == 0) &&
@@ -1407,7 +1118,7 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
     conv_halo32_narrow_kernel<<<dim3((int)(M / (HALO_TH * HALO_TW))), 512, NRW_LDS, s>>>(a);
     return vipe_launch_status();
   }
-  if (halo && (a.split >= a.Cin || a.split % H32_BK == 0) && getenv("VIPE_AMD_CONV_HALO64") == nullptr) {
+  if (halo && (a.split >= a.Cin || a.split % H32_BK == 0)) {
     static bool h32attr = false;
     const int bmc = cp >= 128 ? 128 : cp;
     if (!h32attr) {
@@ -1445,35 +1156,7 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
     }
     return vipe_launch_status();
   }
-  if (halo) {
-    static bool hattr = false;
-    const int bmc = cp >= 128 ? 128 : cp;
-    const size_t lds = 3 * (size_t)bmc * 128 + 2 * HALO_LDS_ROWS * 128 + 2048;
-    if (!hattr) {
-      const int x = 2 * HALO_LDS_ROWS * 128 + 2048;
-      (void)hipFuncSetAttribute((const void*)conv_halo_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 128 + x);
-      (void)hipFuncSetAttribute((const void*)conv_halo_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 128 + x);
-      (void)hipFuncSetAttribute((const void*)conv_halo_kernel<32, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32 * 128 + x);
-      (void)hipFuncSetAttribute((const void*)conv_halo_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 128 + x);
-      (void)hipFuncSetAttribute((const void*)conv_halo_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 128 + x);
-      (void)hipFuncSetAttribute((const void*)conv_halo_kernel<32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32 * 128 + x);
-      hattr = true;
-    }
-    const int gy = cp >= 128 ? cp / 128 : 1;
-    const int tiles = (int)(M / (HALO_TH * HALO_TW));
-    const dim3 grid(tiles * gy);
-    if (a.KH == 3) {
-      if (bmc == 128) conv_halo_kernel<128, 3><<<grid, 512, lds, s>>>(a, gy);
-      else if (bmc == 64) conv_halo_kernel<64, 3><<<grid, 512, lds, s>>>(a, 1);
-      else conv_halo_kernel<32, 3><<<grid, 512, lds, s>>>(a, 1);
-    } else {
-      if (bmc == 128) conv_halo_kernel<128, 1><<<grid, 512, lds, s>>>(a, gy);
-      else if (bmc == 64) conv_halo_kernel<64, 1><<<grid, 512, lds, s>>>(a, 1);
-      else conv_halo_kernel<32, 1><<<grid, 512, lds, s>>>(a, 1);
-    }
-    return vipe_launch_status();
-  }
-  if (small && a.KH == 7 && a.KW == 7 && a.W == HALO_TW && a.H % HALO_TH == 0 && cp % 128 == 0 && kp == 256 &&
+  if (small && a.KH == 7 && a.KW == 7 && a.W % HALO_TW == 0 && a.H % HALO_TH == 0 && cp % 128 == 0 && kp == 256 &&
       a.epi == EPI_PLAIN && a.extra == nullptr && getenv("VIPE_AMD_CONV_NO7X7") == nullptr) {
     static bool a7 = false;
     if (!a7) {
