@@ -1,8 +1,8 @@
 // lietorch_ext: batched Lie-group ops, one group element per lane, grid-stride (device) or a plain
 // loop (host) over the SAME closed forms (lie_math.h).  Replaces csrc/lietorch_ext/lietorch_gpu.cu:24-299
 // and lietorch_cpu.cpp of the reference for SO3 (group_id 1) and SE3 (group_id 3), float32/float64.
-// RxSO3 / Sim3 (ids 2, 4) are not on the SLAM path and return VIPE_EUNSUPPORTED, as do the backward
-// passes (the SLAM system runs under torch.no_grad, system.py:207).
+// Forward AND backward passes, projector, Jinv.  RxSO3 / Sim3 (ids 2, 4) are not on the SLAM path and return
+// VIPE_EUNSUPPORTED.
 #include "common.cuh"
 #include "lie_math.h"
 
@@ -227,14 +227,231 @@ VIPE_EXPORT int vipe_lie_act4_bcast(int g, const void* X, const void* p, void* q
   return dispatch<OpAct4>(g, X, p, q, n_elem * rpe, rpe, dt, 1, st);
 }
 
-// Not on the inference path (torch.no_grad): declared for ABI completeness.
-VIPE_EXPORT int vipe_lie_projector(int, const void*, void*, int64_t, int, int, void*) { return VIPE_EUNSUPPORTED; }
-VIPE_EXPORT int vipe_lie_jinv(int, const void*, const void*, void*, int64_t, int, int, void*) { return VIPE_EUNSUPPORTED; }
-VIPE_EXPORT int vipe_lie_expm_backward(int, const void*, const void*, void*, int64_t, int, int, void*) { return VIPE_EUNSUPPORTED; }
-VIPE_EXPORT int vipe_lie_logm_backward(int, const void*, const void*, void*, int64_t, int, int, void*) { return VIPE_EUNSUPPORTED; }
-VIPE_EXPORT int vipe_lie_inv_backward(int, const void*, const void*, void*, int64_t, int, int, void*) { return VIPE_EUNSUPPORTED; }
-VIPE_EXPORT int vipe_lie_mul_backward(int, const void*, const void*, const void*, void*, void*, int64_t, int, int, void*) { return VIPE_EUNSUPPORTED; }
-VIPE_EXPORT int vipe_lie_adj_backward(int, const void*, const void*, const void*, void*, void*, int64_t, int, int, void*) { return VIPE_EUNSUPPORTED; }
-VIPE_EXPORT int vipe_lie_adjT_backward(int, const void*, const void*, const void*, void*, void*, int64_t, int, int, void*) { return VIPE_EUNSUPPORTED; }
-VIPE_EXPORT int vipe_lie_act_backward(int, const void*, const void*, const void*, void*, void*, int64_t, int, int, void*) { return VIPE_EUNSUPPORTED; }
-VIPE_EXPORT int vipe_lie_act4_backward(int, const void*, const void*, const void*, void*, void*, int64_t, int, int, void*) { return VIPE_EUNSUPPORTED; }
+// ---- backward passes (training / optimisation utilities; the SLAM system itself runs under torch.no_grad)
+
+namespace {
+
+// ---- backward passes, projector, Jinv (lietorch_gpu.cu:36-275): per-element functors with up to three inputs
+// (grad, in0, in1) and two outputs.  Gradients of group elements live in the first K of N columns (the rest stays 0).
+template <typename G, typename S, int K>
+LIE_HD void rowvec_mat(const S* v, const S (&M)[K][K], S* o, S sign = S(1)) {
+  for (int j = 0; j < K; ++j) {
+    S acc = 0;
+    for (int i = 0; i < K; ++i) acc += v[i] * M[i][j];
+    o[j] = sign * acc;
+  }
+}
+
+template <typename G, typename S>
+struct BwExp {  // da = dX Jl(a)
+  static constexpr int GW = G::N, A = G::K, B = 0, C0 = G::K, C1 = 0;
+  static LIE_HD void run(const S* g, const S* a, const S*, S* o0, S*) {
+    S J[G::K][G::K];
+    Jac<G, S>::left_jacobian(a, J);
+    rowvec_mat<G, S, G::K>(g, J, o0);
+  }
+};
+template <typename G, typename S>
+struct BwLog {  // dX = da Jl^-1(log X)
+  static constexpr int GW = G::K, A = G::N, B = 0, C0 = G::N, C1 = 0;
+  static LIE_HD void run(const S* g, const S* x, const S*, S* o0, S*) {
+    S a[G::K], J[G::K][G::K];
+    Jac<G, S>::log(G(x), a);
+    Jac<G, S>::left_jacobian_inverse(a, J);
+    for (int k = G::K; k < G::N; ++k) o0[k] = 0;
+    rowvec_mat<G, S, G::K>(g, J, o0);
+  }
+};
+template <typename G, typename S>
+struct BwInv {  // dX = -dY Adj(X^-1)
+  static constexpr int GW = G::N, A = G::N, B = 0, C0 = G::N, C1 = 0;
+  static LIE_HD void run(const S* g, const S* x, const S*, S* o0, S*) {
+    S Ad[G::K][G::K];
+    Jac<G, S>::Adj(G(x).inv(), Ad);
+    for (int k = G::K; k < G::N; ++k) o0[k] = 0;
+    rowvec_mat<G, S, G::K>(g, Ad, o0, S(-1));
+  }
+};
+template <typename G, typename S>
+struct BwMul {  // dX = dZ, dY = dZ Adj(X)
+  static constexpr int GW = G::N, A = G::N, B = G::N, C0 = G::N, C1 = G::N;
+  static LIE_HD void run(const S* g, const S* x, const S*, S* o0, S* o1) {
+    S Ad[G::K][G::K];
+    Jac<G, S>::Adj(G(x), Ad);
+    for (int k = 0; k < G::N; ++k) { o0[k] = k < G::K ? g[k] : S(0); o1[k] = 0; }
+    rowvec_mat<G, S, G::K>(g, Ad, o1);
+  }
+};
+template <typename G, typename S>
+struct BwAdj {  // b = Adj(X) a: da = db Adj(X), dX = -db adj(b)
+  static constexpr int GW = G::K, A = G::N, B = G::K, C0 = G::N, C1 = G::K;
+  static LIE_HD void run(const S* g, const S* x, const S* a, S* o0, S* o1) {
+    S Ad[G::K][G::K], ad[G::K][G::K], b[G::K];
+    Jac<G, S>::Adj(G(x), Ad);
+    for (int i = 0; i < G::K; ++i) {
+      S acc = 0;
+      for (int j = 0; j < G::K; ++j) acc += Ad[i][j] * a[j];
+      b[i] = acc;
+    }
+    Jac<G, S>::adj(b, ad);
+    rowvec_mat<G, S, G::K>(g, Ad, o1);
+    for (int k = G::K; k < G::N; ++k) o0[k] = 0;
+    rowvec_mat<G, S, G::K>(g, ad, o0, S(-1));
+  }
+};
+template <typename G, typename S>
+struct BwAdjT {  // b = Adj(X)^T a: da = Adj(X) db, dX = -a^T adj(Adj(X) db)
+  static constexpr int GW = G::K, A = G::N, B = G::K, C0 = G::N, C1 = G::K;
+  static LIE_HD void run(const S* g, const S* x, const S* a, S* o0, S* o1) {
+    S Ad[G::K][G::K], ad[G::K][G::K];
+    Jac<G, S>::Adj(G(x), Ad);
+    for (int i = 0; i < G::K; ++i) {
+      S acc = 0;
+      for (int j = 0; j < G::K; ++j) acc += Ad[i][j] * g[j];
+      o1[i] = acc;
+    }
+    Jac<G, S>::adj(o1, ad);
+    for (int k = G::K; k < G::N; ++k) o0[k] = 0;
+    rowvec_mat<G, S, G::K>(a, ad, o0, S(-1));
+  }
+};
+template <typename G, typename S>
+struct BwAct {  // q = X p: dp = dq R, dX = dq act_jacobian(q)
+  static constexpr int GW = 3, A = G::N, B = 3, C0 = G::N, C1 = 3;
+  static LIE_HD void run(const S* g, const S* x, const S* p, S* o0, S* o1) {
+    G X(x);
+    S T[4][4], J[3][G::K];
+    Jac<G, S>::matrix4(X, T);
+    for (int j = 0; j < 3; ++j) o1[j] = g[0] * T[0][j] + g[1] * T[1][j] + g[2] * T[2][j];
+    Jac<G, S>::act_jacobian(X.act(Vec3<S>{p[0], p[1], p[2]}), J);
+    for (int k = 0; k < G::N; ++k) o0[k] = 0;
+    for (int j = 0; j < G::K; ++j) o0[j] = g[0] * J[0][j] + g[1] * J[1][j] + g[2] * J[2][j];
+  }
+};
+template <typename G, typename S>
+struct BwAct4 {  // q = X.act4(p): dp = dq T, dX = dq act4_jacobian(q)
+  static constexpr int GW = 4, A = G::N, B = 4, C0 = G::N, C1 = 4;
+  static LIE_HD void run(const S* g, const S* x, const S* p, S* o0, S* o1) {
+    G X(x);
+    S T[4][4], J[4][G::K], q[4];
+    Jac<G, S>::matrix4(X, T);
+    for (int j = 0; j < 4; ++j) o1[j] = g[0] * T[0][j] + g[1] * T[1][j] + g[2] * T[2][j] + g[3] * T[3][j];
+    OpAct4<G, S>::run(x, p, q);
+    Jac<G, S>::act4_jacobian(q, J);
+    for (int k = 0; k < G::N; ++k) o0[k] = 0;
+    for (int j = 0; j < G::K; ++j) o0[j] = g[0] * J[0][j] + g[1] * J[1][j] + g[2] * J[2][j] + g[3] * J[3][j];
+  }
+};
+template <typename G, typename S>
+struct OpProjector {
+  static constexpr int A = G::N, B = 0, C = G::N * G::N;
+  static LIE_HD void run(const S* x, const S*, S* o) {
+    S P[G::N][G::N];
+    Jac<G, S>::projector(G(x), P);
+    for (int i = 0; i < G::N; ++i)
+      for (int j = 0; j < G::N; ++j) o[i * G::N + j] = P[i][j];
+  }
+};
+template <typename G, typename S>
+struct OpJinv {  // b = Jl^-1(log X) a
+  static constexpr int A = G::N, B = G::K, C = G::K;
+  static LIE_HD void run(const S* x, const S* a, S* o) {
+    S l[G::K], J[G::K][G::K];
+    Jac<G, S>::log(G(x), l);
+    Jac<G, S>::left_jacobian_inverse(l, J);
+    for (int i = 0; i < G::K; ++i) {
+      S acc = 0;
+      for (int j = 0; j < G::K; ++j) acc += J[i][j] * a[j];
+      o[i] = acc;
+    }
+  }
+};
+
+template <typename Op, typename S>
+__global__ __launch_bounds__(256) void lie_bwd_kernel(const S* __restrict__ grad, const S* __restrict__ in0,
+                                                       const S* __restrict__ in1, S* __restrict__ out0,
+                                                       S* __restrict__ out1, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    S g[Op::GW], a[Op::A], b[Op::B > 0 ? Op::B : 1], o0[Op::C0], o1[Op::C1 > 0 ? Op::C1 : 1];
+#pragma unroll
+    for (int k = 0; k < Op::GW; ++k) g[k] = grad[i * Op::GW + k];
+#pragma unroll
+    for (int k = 0; k < Op::A; ++k) a[k] = in0[i * Op::A + k];
+#pragma unroll
+    for (int k = 0; k < Op::B; ++k) b[k] = in1[i * Op::B + k];
+    Op::run(g, a, b, o0, o1);
+#pragma unroll
+    for (int k = 0; k < Op::C0; ++k) out0[i * Op::C0 + k] = o0[k];
+#pragma unroll
+    for (int k = 0; k < Op::C1; ++k) out1[i * Op::C1 + k] = o1[k];
+  }
+}
+
+template <typename Op, typename S>
+int run_bwd(const void* grad, const void* in0, const void* in1, void* out0, void* out1, int64_t n, int on_device,
+            hipStream_t s) {
+  if (n == 0) return VIPE_OK;
+  if (!grad || !in0 || !out0 || (Op::B > 0 && !in1) || (Op::C1 > 0 && !out1)) return VIPE_EINVAL;
+  if (on_device) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    lie_bwd_kernel<Op, S><<<(int)blocks, 256, 0, s>>>((const S*)grad, (const S*)in0, (const S*)in1, (S*)out0, (S*)out1, n);
+    return vipe_launch_status();
+  }
+  const S *g = (const S*)grad, *a = (const S*)in0, *b = (const S*)in1;
+  S *o0 = (S*)out0, *o1 = (S*)out1, dummy[8];
+  for (int64_t i = 0; i < n; ++i)
+    Op::run(g + i * Op::GW, a + i * Op::A, Op::B > 0 ? b + i * Op::B : nullptr, o0 + i * Op::C0,
+            Op::C1 > 0 ? o1 + i * Op::C1 : dummy);
+  return VIPE_OK;
+}
+
+template <template <typename, typename> class Op>
+int dispatch_bwd(int gid, const void* grad, const void* in0, const void* in1, void* out0, void* out1, int64_t n,
+                 int dtype, int on_device, void* stream) {
+  hipStream_t s = as_stream(stream);
+  if (n < 0) return VIPE_EINVAL;
+  if (dtype == VIPE_F32) {
+    if (gid == 3) return run_bwd<Op<SE3<float>, float>, float>(grad, in0, in1, out0, out1, n, on_device, s);
+    if (gid == 1) return run_bwd<Op<SO3<float>, float>, float>(grad, in0, in1, out0, out1, n, on_device, s);
+  } else if (dtype == VIPE_F64) {
+    if (gid == 3) return run_bwd<Op<SE3<double>, double>, double>(grad, in0, in1, out0, out1, n, on_device, s);
+    if (gid == 1) return run_bwd<Op<SO3<double>, double>, double>(grad, in0, in1, out0, out1, n, on_device, s);
+  } else {
+    return VIPE_EINVAL;
+  }
+  return (gid == 2 || gid == 4) ? VIPE_EUNSUPPORTED : VIPE_EINVAL;
+}
+
+}  // namespace
+
+VIPE_EXPORT int vipe_lie_projector(int g, const void* X, void* P, int64_t n, int dt, int dev, void* st) {
+  return dispatch<OpProjector>(g, X, nullptr, P, n, 1, dt, dev, st);
+}
+VIPE_EXPORT int vipe_lie_jinv(int g, const void* X, const void* a, void* b, int64_t n, int dt, int dev, void* st) {
+  return dispatch<OpJinv>(g, X, a, b, n, 1, dt, dev, st);
+}
+VIPE_EXPORT int vipe_lie_expm_backward(int g, const void* grad, const void* a, void* da, int64_t n, int dt, int dev, void* st) {
+  return dispatch_bwd<BwExp>(g, grad, a, nullptr, da, nullptr, n, dt, dev, st);
+}
+VIPE_EXPORT int vipe_lie_logm_backward(int g, const void* grad, const void* X, void* dX, int64_t n, int dt, int dev, void* st) {
+  return dispatch_bwd<BwLog>(g, grad, X, nullptr, dX, nullptr, n, dt, dev, st);
+}
+VIPE_EXPORT int vipe_lie_inv_backward(int g, const void* grad, const void* X, void* dX, int64_t n, int dt, int dev, void* st) {
+  return dispatch_bwd<BwInv>(g, grad, X, nullptr, dX, nullptr, n, dt, dev, st);
+}
+VIPE_EXPORT int vipe_lie_mul_backward(int g, const void* grad, const void* X, const void* Y, void* dX, void* dY, int64_t n, int dt, int dev, void* st) {
+  return dispatch_bwd<BwMul>(g, grad, X, Y, dX, dY, n, dt, dev, st);
+}
+VIPE_EXPORT int vipe_lie_adj_backward(int g, const void* grad, const void* X, const void* a, void* dX, void* da, int64_t n, int dt, int dev, void* st) {
+  return dispatch_bwd<BwAdj>(g, grad, X, a, dX, da, n, dt, dev, st);
+}
+VIPE_EXPORT int vipe_lie_adjT_backward(int g, const void* grad, const void* X, const void* a, void* dX, void* da, int64_t n, int dt, int dev, void* st) {
+  return dispatch_bwd<BwAdjT>(g, grad, X, a, dX, da, n, dt, dev, st);
+}
+VIPE_EXPORT int vipe_lie_act_backward(int g, const void* grad, const void* X, const void* p, void* dX, void* dp, int64_t n, int dt, int dev, void* st) {
+  return dispatch_bwd<BwAct>(g, grad, X, p, dX, dp, n, dt, dev, st);
+}
+VIPE_EXPORT int vipe_lie_act4_backward(int g, const void* grad, const void* X, const void* p, void* dX, void* dp, int64_t n, int dt, int dev, void* st) {
+  return dispatch_bwd<BwAct4>(g, grad, X, p, dX, dp, n, dt, dev, st);
+}

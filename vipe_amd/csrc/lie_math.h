@@ -175,4 +175,171 @@ struct SE3 {
   }
 };
 
+
+// ---- Jacobian blocks for the backward passes (so3.h:153-202, se3.h:60-214).  Small dense matrices as S[R][C].
+template <typename S>
+LIE_HD void hat3(Vec3<S> v, S (&M)[3][3]) {
+  M[0][0] = 0; M[0][1] = -v.z; M[0][2] = v.y;
+  M[1][0] = v.z; M[1][1] = 0; M[1][2] = -v.x;
+  M[2][0] = -v.y; M[2][1] = v.x; M[2][2] = 0;
+}
+template <typename S>
+LIE_HD void mat3_mul(const S (&A)[3][3], const S (&B)[3][3], S (&C)[3][3]) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) C[i][j] = A[i][0] * B[0][j] + A[i][1] * B[1][j] + A[i][2] * B[2][j];
+}
+// I + c1 Phi + c2 Phi^2
+template <typename S>
+LIE_HD void poly3(S c1, S c2, Vec3<S> phi, S (&J)[3][3]) {
+  S P[3][3], P2[3][3];
+  hat3(phi, P);
+  mat3_mul(P, P, P2);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) J[i][j] = (i == j ? S(1) : S(0)) + c1 * P[i][j] + c2 * P2[i][j];
+}
+template <typename S>
+LIE_HD void so3_left_jacobian(Vec3<S> phi, S (&J)[3][3]) {  // so3.h:153-168
+  S t2 = dot(phi, phi), t = sqrt(t2);
+  S c1 = (t < S(LIE_EPS)) ? S(0.5) - S(1.0 / 24.0) * t2 : (S(1) - cos(t)) / t2;
+  S c2 = (t < S(LIE_EPS)) ? S(1.0 / 6.0) - S(1.0 / 120.0) * t2 : (t - sin(t)) / (t2 * t);
+  poly3(c1, c2, phi, J);
+}
+template <typename S>
+LIE_HD void so3_left_jacobian_inverse(Vec3<S> phi, S (&J)[3][3]) {  // so3.h:170-184
+  S t2 = dot(phi, phi), t = sqrt(t2), h = S(0.5) * t;
+  S c2 = (t < S(LIE_EPS)) ? S(1.0 / 12.0) : (S(1) - t * cos(h) / (S(2) * sin(h))) / (t * t);
+  poly3(S(-0.5), c2, phi, J);
+}
+template <typename S>
+LIE_HD void se3_calcQ(const S* a, S (&Q)[3][3]) {  // se3.h:138-163
+  Vec3<S> tau{a[0], a[1], a[2]}, phi{a[3], a[4], a[5]};
+  S T[3][3], P[3][3], PT[3][3], TP[3][3], PTP[3][3], PP[3][3], PPT[3][3], TPP[3][3], PTPP[3][3], PPTP[3][3];
+  hat3(tau, T);
+  hat3(phi, P);
+  mat3_mul(P, T, PT); mat3_mul(T, P, TP); mat3_mul(PT, P, PTP); mat3_mul(P, P, PP);
+  mat3_mul(PP, T, PPT); mat3_mul(T, PP, TPP); mat3_mul(PTP, P, PTPP); mat3_mul(PP, TP, PPTP);
+  S t = sqrt(dot(phi, phi)), t2 = t * t, t4 = t2 * t2;
+  S c1 = (t < S(LIE_EPS)) ? S(1.0 / 6.0) - S(1.0 / 120.0) * t2 : (t - sin(t)) / (t2 * t);
+  S c2 = (t < S(LIE_EPS)) ? S(1.0 / 24.0) - S(1.0 / 720.0) * t2 : (t2 + 2 * cos(t) - 2) / (2 * t4);
+  S c3 = (t < S(LIE_EPS)) ? S(1.0 / 120.0) - S(1.0 / 2520.0) * t2 : (2 * t - 3 * sin(t) + t * cos(t)) / (2 * t4 * t);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      Q[i][j] = S(0.5) * T[i][j] + c1 * (PT[i][j] + TP[i][j] + PTP[i][j]) +
+                c2 * (PPT[i][j] + TPP[i][j] - 3 * PTP[i][j]) + c3 * (PTPP[i][j] + PPTP[i][j]);
+}
+
+// Per-group Jacobian providers.  K x K matrices are S[K][K]; everything the reference's backward kernels use
+// (lietorch_gpu.cu:36-275): Adj(), adj(b), left_jacobian(a), left_jacobian_inverse(a), act / act4 Jacobians,
+// the 4x4 matrix and the orthogonal projector.
+template <typename G, typename S>
+struct Jac;
+
+template <typename S>
+struct Jac<SO3<S>, S> {
+  static constexpr int K = 3, N = 4;
+  static LIE_HD void Adj(const SO3<S>& X, S (&A)[3][3]) {
+    Mat3<S> R = X.matrix();
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) A[i][j] = R.m[i][j];
+  }
+  static LIE_HD void adj(const S* b, S (&A)[3][3]) { hat3(Vec3<S>{b[0], b[1], b[2]}, A); }
+  static LIE_HD void left_jacobian(const S* a, S (&J)[3][3]) { so3_left_jacobian(Vec3<S>{a[0], a[1], a[2]}, J); }
+  static LIE_HD void left_jacobian_inverse(const S* a, S (&J)[3][3]) {
+    so3_left_jacobian_inverse(Vec3<S>{a[0], a[1], a[2]}, J);
+  }
+  static LIE_HD void log(const SO3<S>& X, S* a) { Vec3<S> v = X.log(); a[0] = v.x; a[1] = v.y; a[2] = v.z; }
+  static LIE_HD void act_jacobian(Vec3<S> q, S (&J)[3][3]) { hat3(S(-1) * q, J); }
+  static LIE_HD void act4_jacobian(const S* q, S (&J)[4][3]) {
+    S H[3][3];
+    hat3(Vec3<S>{-q[0], -q[1], -q[2]}, H);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) J[i][j] = H[i][j];
+    J[3][0] = J[3][1] = J[3][2] = 0;
+  }
+  static LIE_HD void matrix4(const SO3<S>& X, S (&T)[4][4]) {
+    Mat3<S> R = X.matrix();
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) T[i][j] = (i < 3 && j < 3) ? R.m[i][j] : (i == j ? S(1) : S(0));
+  }
+  static LIE_HD void projector(const SO3<S>& X, S (&P)[4][4]) {  // so3.h:72-80
+    S H[3][3];
+    hat3(Vec3<S>{-X.q.x, -X.q.y, -X.q.z}, H);
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) P[i][j] = 0;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) P[i][j] = S(0.5) * ((i == j ? X.q.w : S(0)) + H[i][j]);
+    P[3][0] = S(-0.5) * X.q.x; P[3][1] = S(-0.5) * X.q.y; P[3][2] = S(-0.5) * X.q.z;
+  }
+};
+
+template <typename S>
+struct Jac<SE3<S>, S> {
+  static constexpr int K = 6, N = 7;
+  static LIE_HD void Adj(const SE3<S>& X, S (&A)[6][6]) {  // [[R, t^R],[0,R]]
+    Mat3<S> R = X.r.matrix();
+    S Rm[3][3], Tx[3][3], TR[3][3];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) Rm[i][j] = R.m[i][j];
+    hat3(X.t, Tx);
+    mat3_mul(Tx, Rm, TR);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        A[i][j] = Rm[i][j]; A[i][j + 3] = TR[i][j]; A[i + 3][j] = 0; A[i + 3][j + 3] = Rm[i][j];
+      }
+  }
+  static LIE_HD void adj(const S* b, S (&A)[6][6]) {  // [[Phi, Tau],[0,Phi]]
+    S T[3][3], P[3][3];
+    hat3(Vec3<S>{b[0], b[1], b[2]}, T);
+    hat3(Vec3<S>{b[3], b[4], b[5]}, P);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) { A[i][j] = P[i][j]; A[i][j + 3] = T[i][j]; A[i + 3][j] = 0; A[i + 3][j + 3] = P[i][j]; }
+  }
+  static LIE_HD void left_jacobian(const S* a, S (&J6)[6][6]) {  // [[J, Q],[0,J]]
+    S J[3][3], Q[3][3];
+    so3_left_jacobian(Vec3<S>{a[3], a[4], a[5]}, J);
+    se3_calcQ(a, Q);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) { J6[i][j] = J[i][j]; J6[i][j + 3] = Q[i][j]; J6[i + 3][j] = 0; J6[i + 3][j + 3] = J[i][j]; }
+  }
+  static LIE_HD void left_jacobian_inverse(const S* a, S (&J6)[6][6]) {  // [[Ji, -Ji Q Ji],[0,Ji]]
+    S Ji[3][3], Q[3][3], A1[3][3], A2[3][3];
+    so3_left_jacobian_inverse(Vec3<S>{a[3], a[4], a[5]}, Ji);
+    se3_calcQ(a, Q);
+    mat3_mul(Ji, Q, A1);
+    mat3_mul(A1, Ji, A2);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) { J6[i][j] = Ji[i][j]; J6[i][j + 3] = -A2[i][j]; J6[i + 3][j] = 0; J6[i + 3][j + 3] = Ji[i][j]; }
+  }
+  static LIE_HD void log(const SE3<S>& X, S* a) { X.log(a); }
+  static LIE_HD void act_jacobian(Vec3<S> q, S (&J)[3][6]) {  // [I | hat(-q)]
+    S H[3][3];
+    hat3(S(-1) * q, H);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) { J[i][j] = (i == j ? S(1) : S(0)); J[i][j + 3] = H[i][j]; }
+  }
+  static LIE_HD void act4_jacobian(const S* q, S (&J)[4][6]) {  // [[q3 I, hat(-q)],[0,0]]
+    S H[3][3];
+    hat3(Vec3<S>{-q[0], -q[1], -q[2]}, H);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) { J[i][j] = (i == j ? q[3] : S(0)); J[i][j + 3] = H[i][j]; }
+    for (int j = 0; j < 6; ++j) J[3][j] = 0;
+  }
+  static LIE_HD void matrix4(const SE3<S>& X, S (&T)[4][4]) {
+    Mat3<S> R = X.r.matrix();
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) T[i][j] = R.m[i][j]; }
+    T[0][3] = X.t.x; T[1][3] = X.t.y; T[2][3] = X.t.z;
+    T[3][0] = T[3][1] = T[3][2] = 0; T[3][3] = 1;
+  }
+  static LIE_HD void projector(const SE3<S>& X, S (&P)[7][7]) {  // se3.h:107-115
+    S H[3][3], P4[4][4];
+    hat3(S(-1) * X.t, H);
+    Jac<SO3<S>, S>::projector(X.r, P4);
+    for (int i = 0; i < 7; ++i)
+      for (int j = 0; j < 7; ++j) P[i][j] = 0;
+    for (int i = 0; i < 3; ++i) { P[i][i] = 1; for (int j = 0; j < 3; ++j) P[i][j + 3] = H[i][j]; }
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) P[i + 3][j + 3] = P4[i][j];
+  }
+};
+
 }  // namespace lie

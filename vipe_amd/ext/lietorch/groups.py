@@ -1,7 +1,7 @@
 """LieGroup Python API (reference: vipe/ext/lietorch/groups.py:54-328) over `lietorch_ext`.
 
-Inference-only (the SLAM system runs under torch.no_grad, system.py:207): ops call the backend directly,
-no autograd Functions.  Broadcasting follows broadcasting.py:14-41, except that a group element shared by
+Under torch.no_grad (the SLAM system, system.py:207) ops call the backend directly; when an input requires grad they
+go through the autograd Functions of `group_ops` (forward + backward entry points of the C ABI).  Broadcasting follows broadcasting.py:14-41, except that a group element shared by
 whole trailing blocks of rows is NOT replicated per row on the device (adjT / act4 use the *_bcast
 entry points of the C ABI).
 """
@@ -10,6 +10,14 @@ import numpy as np
 import torch
 
 from .. import lietorch_ext as B
+from . import group_ops as GO
+
+_AUTOGRAD = {B.expm: GO.Exp, B.logm: GO.Log, B.inv: GO.Inv, B.mul: GO.Mul, B.adj: GO.Adj, B.adjT: GO.AdjT,
+             B.act: GO.Act3, B.act4: GO.Act4, B.Jinv: GO.Jinv}
+
+
+def _needs_grad(*ts):
+    return torch.is_grad_enabled() and any(t.requires_grad for t in ts)
 
 
 def _broadcast(x, y):
@@ -82,16 +90,33 @@ class LieGroup:
 
     @classmethod
     def _un(cls, fn, x):
-        return fn(cls.group_id, x.reshape(-1, x.shape[-1]).contiguous()).view(x.shape[:-1] + (-1,))
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        if _needs_grad(x):
+            return _AUTOGRAD[fn].apply(cls.group_id, x2).view(x.shape[:-1] + (-1,))
+        return fn(cls.group_id, x2).view(x.shape[:-1] + (-1,))
 
     @classmethod
     def _bin(cls, fn, x, y, bcast_fn=None):
+        if _needs_grad(x, y):  # differentiable path: plain expansion (the reference's broadcasting.py), autograd ops
+            out_shape = tuple(max(n, m) for n, m in zip(x.shape[:-1], y.shape[:-1]))
+            xe = x.expand(out_shape + (x.shape[-1],)).reshape(-1, x.shape[-1]).contiguous()
+            ye = y.expand(out_shape + (y.shape[-1],)).reshape(-1, y.shape[-1]).contiguous()
+            return _AUTOGRAD[fn].apply(cls.group_id, xe, ye).view(out_shape + (-1,))
         x2, y2, out_shape, rows = _broadcast(x, y)
         if rows is not None:
             if bcast_fn is not None:
                 return bcast_fn(cls.group_id, x2, y2).view(out_shape + (-1,))
             x2 = x2.repeat_interleave(rows, dim=0)
         return fn(cls.group_id, x2, y2).view(out_shape + (-1,))
+
+    @classmethod
+    def InitFromVec(cls, data):
+        """groups.py:104-106: Euclidean embedding -> group (gradient through the projector's pseudo-inverse)."""
+        return cls(GO.FromVec.apply(cls.group_id, data) if _needs_grad(data) else data)
+
+    def vec(self):
+        """groups.py:201-202: group -> Euclidean embedding."""
+        return GO.ToVec.apply(self.group_id, self.data) if _needs_grad(self.data) else self.data
 
     @classmethod
     def exp(cls, x):
