@@ -733,3 +733,37 @@ def test_config5_grid_dense_ba_and_update_operator():
     assert (delta_d.float().cpu() - delta_r).abs().max().item() < 0.05
     assert (weight_d.float().cpu() - weight_r).abs().max().item() < 0.02
     assert (eta_d.float().cpu() - eta_r).abs().max().item() < 2e-3
+
+
+def test_fused_lookup_conv1x1_matches_lookup_then_conv():
+    """`vipe_corr_lookup_conv1x1` = lookup_nhwc (bit-exact, tested above) followed by the 1x1 convolution: the fused
+    kernel must agree with the two-kernel composition to fp16 rounding of the output (same fp16 inputs, fp32
+    accumulation in a different order), incl. a ragged last pixel group and out-of-range windows."""
+    from vipe_amd._lib import check, lib, ptr, stream_ptr
+    from vipe_amd.ext import droid_net_ext
+    from vipe_amd.slam.update_engine import _Packed
+
+    E, h, w = 2, 24, 64  # level 3 is 3 x 8
+    gen = torch.Generator().manual_seed(12)
+    f1 = torch.randn(E, 128, h, w, generator=gen).half().to(dev())
+    f2 = torch.randn(E, 128, h, w, generator=gen).half().to(dev())
+    lv = droid_net_ext.corr_pyramid_build(f1, f2, 4)
+    u, v = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+    base = torch.from_numpy(np.stack([u, v], -1))[None].repeat(E, 1, 1, 1)
+    coords = (base + 6.0 * torch.randn(E, h, w, 2, generator=gen)).to(dev()).contiguous()
+    coords[0, 0, :8] = -50.0  # windows completely outside
+    wt = torch.zeros(128, 200, 1, 1)
+    wt[:, :196] = torch.randn(128, 196, 1, 1, generator=gen) / 14.0
+    bias = torch.randn(128, generator=gen) * 0.1
+    pk = _Packed(wt.half(), bias, dev())
+    corr = droid_net_ext.corr_pyramid_lookup_nhwc(lv, coords, 3, 200)
+    ref = torch.empty(E, h, w, 128, dtype=torch.float16, device=dev())
+    check(lib().vipe_conv2d_nhwc_f16(ptr(corr), ptr(pk.packed), ptr(pk.bias), None, ptr(ref), E, h, w, 200, 200, 0, 128,
+                                     128, 0, 1, 1, 1, stream_ptr(corr)), "conv")
+    out = torch.full((E, h, w, 160), 3.0, dtype=torch.float16, device=dev())
+    droid_net_ext.corr_lookup_conv1x1(lv, coords, pk.packed, pk.bias, out, out_coff=16, act="relu")
+    assert float((out[..., 16:144].float() - ref.float()).abs().max()) <= 2e-2 * max(1.0, float(ref.float().abs().max()))
+    assert torch.all(out[..., :16] == 3.0) and torch.all(out[..., 144:] == 3.0)
+    # against the fp32 restatement: relu(W corr + b)
+    r32 = torch.relu(torch.einsum("ehwc,oc->ehwo", corr[..., :196].float().cpu(), wt[:, :196, 0, 0].half().float()) + bias)
+    assert float((out[..., 16:144].float().cpu() - r32).abs().max()) < 3e-2

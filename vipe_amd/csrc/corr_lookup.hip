@@ -328,6 +328,158 @@ __global__ __launch_bounds__(256) void corr_pyramid_lookup_rows4_kernel(LevelPtr
   }
 }
 
+// ---- lookup fused with the correlation encoder's 1x1 convolution (droid_net.py:436-437 first layer, 196 -> Cout,
+// + bias + activation): the 196 looked-up channels of 32 pixels are staged in LDS as above and consumed right there
+// as the B operand of v_mfma_f32_16x16x32_f16; the [E,h,w,200] intermediate (339 MB written and read back per update
+// at E = 276) never exists.  Persistent workgroups: each wave keeps its 32 output channels x 224 k of the packed
+// weights in registers (loaded once), so only the gather and the 256-byte output rows touch memory.
+constexpr int LKC_PITCH = 232;   // halves per staged pixel: 224 k + 8 (row stride 464 B spreads the 16-lane b128 reads)
+constexpr int LKC_OPITCH = 136;  // halves per staged output pixel (128 couts + 8)
+
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void corr_lookup_conv_kernel(
+    LevelPtrs lv, const float* __restrict__ coords, const half_t* __restrict__ wpk, const float* __restrict__ bias,
+    half_t* __restrict__ out, int out_ctot, int out_coff, int h1, int w1, int h2, int w2, int B, int cout_pad, int act) {
+  constexpr int R = 3, RD = 7, L = 4;
+  using A = Acc<half_t>;
+  __shared__ __align__(16) half_t stage[32 * LKC_PITCH];
+  __shared__ __align__(16) half_t ostage[32 * LKC_OPITCH];
+  const int P = h1 * w1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = tid & 7, pl = tid >> 3;
+  const int l16 = lane & 15, kg = lane >> 4;
+  const int gpp = (P + 31) / 32;
+  const int ngroups = B * gpp;
+  // this wave's weights: couts 32 wave + 16 i + l16, k = 32 s + 8 kg .. + 7  (packed [k / 64][cout_pad][64])
+  half8v af[2][7];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+      const int k = 32 * s + 8 * kg, r = 32 * wave + 16 * i + l16;
+      af[i][s] = *reinterpret_cast<const half8v*>(wpk + ((int64_t)(k >> 6) * cout_pad + r) * 64 + (k & 63));
+    }
+  float4 bv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) bv[i] = *reinterpret_cast<const float4*>(bias + 32 * wave + 16 * i + 4 * kg);
+  // zero the k padding of the staged rows once (columns 196..231 are never written by the lookup)
+  for (int i = tid; i < 32 * (LKC_PITCH - L * RD * RD); i += 256)
+    stage[(i / (LKC_PITCH - L * RD * RD)) * LKC_PITCH + L * RD * RD + i % (LKC_PITCH - L * RD * RD)] = (half_t)0;
+
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int n = grp / gpp, p = (grp % gpp) * 32 + pl;
+    const bool pok = p < P;
+    const int pc = pok ? p : P - 1;
+    const float2 c = reinterpret_cast<const float2*>(coords)[(int64_t)n * P + pc];
+    uint4v lo[L], hi[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const float sc = 1.0f / (float)(1 << l);
+      const int h2l = h2 >> l, w2l = w2 >> l;
+      const int bx = (int)floorf(c.x * sc) - R, by = (int)floorf(c.y * sc) - R;
+      const int y1 = by + j, c0 = bx >> 3, nchunks = w2l >> 3;
+      const bool rowok = (y1 >= 0) & (y1 < h2l);
+      const half_t* slab = reinterpret_cast<const half_t*>(lv.p[l]) + ((int64_t)n * P + pc) * ((int64_t)h2l * w2l);
+      const uint4v* rowp = reinterpret_cast<const uint4v*>(slab + (int64_t)(rowok ? y1 : 0) * w2l);
+      lo[l] = uint4v{0, 0, 0, 0};
+      hi[l] = uint4v{0, 0, 0, 0};
+      if (rowok & (c0 >= 0) & (c0 < nchunks)) lo[l] = rowp[c0];
+      if (rowok & (c0 + 1 >= 0) & (c0 + 1 < nchunks)) hi[l] = rowp[c0 + 1];
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const float sc = 1.0f / (float)(1 << l);
+      const float x0 = c.x * sc, y0 = c.y * sc;
+      const float fx = floorf(x0), fy = floorf(y0);
+      const float dx = x0 - fx, dy = y0 - fy;
+      const int sh = ((int)fx - R) & 7;
+      const float w11 = A::weight(dx * dy), w10 = A::weight(dx * (1.0f - dy));
+      const float w01 = A::weight((1.0f - dx) * dy), w00 = A::weight((1.0f - dx) * (1.0f - dy));
+      unsigned d[8] = {lo[l][0], lo[l][1], lo[l][2], lo[l][3], hi[l][0], hi[l][1], hi[l][2], hi[l][3]};
+      const int q = sh >> 1;
+      unsigned a1[7], f[5];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) a1[k] = (q & 1) ? d[k + 1] : d[k];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) f[k] = (q & 2) ? a1[k + 2] : a1[k];
+      unsigned e[4], ne[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e[k] = (sh & 1) ? __builtin_amdgcn_alignbyte(f[k + 1], f[k], 2) : f[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ne[k] = __shfl_down(e[k], 1, 8);
+      float t[8], nb[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        half_t h0, h1v;
+        unsigned short u0 = (unsigned short)(e[k] & 0xffffu), u1 = (unsigned short)(e[k] >> 16);
+        __builtin_memcpy(&h0, &u0, 2);
+        __builtin_memcpy(&h1v, &u1, 2);
+        t[2 * k] = (float)h0;
+        t[2 * k + 1] = (float)h1v;
+        u0 = (unsigned short)(ne[k] & 0xffffu);
+        u1 = (unsigned short)(ne[k] >> 16);
+        __builtin_memcpy(&h0, &u0, 2);
+        __builtin_memcpy(&h1v, &u1, 2);
+        nb[2 * k] = (float)h0;
+        nb[2 * k + 1] = (float)h1v;
+      }
+      if (j < RD) {
+#pragma unroll
+        for (int a = 0; a < RD; ++a) {
+          float acc = 0.0f;
+          acc = A::madd(acc, t[a], w00);
+          acc = A::madd(acc, nb[a], w01);
+          acc = A::madd(acc, t[a + 1], w10);
+          acc = A::madd(acc, nb[a + 1], w11);
+          stage[pl * LKC_PITCH + l * (RD * RD) + a * RD + j] = A::store(acc);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- 1x1 convolution of the 32 staged pixels: D[cout, pixel]
+    float4v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) acc[i][jj] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 7; ++s)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const half8v xf = *reinterpret_cast<const half8v*>(stage + (16 * jj + l16) * LKC_PITCH + 32 * s + 8 * kg);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][s], xf, acc[i][jj], 0, 0, 0);
+      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        half4v hv;
+        const float v0 = acc[i][jj][0] + bv[i].x, v1 = acc[i][jj][1] + bv[i].y;
+        const float v2 = acc[i][jj][2] + bv[i].z, v3 = acc[i][jj][3] + bv[i].w;
+        hv[0] = (half_t)(act == VIPE_ACT_RELU ? fmaxf(v0, 0.0f) : v0);
+        hv[1] = (half_t)(act == VIPE_ACT_RELU ? fmaxf(v1, 0.0f) : v1);
+        hv[2] = (half_t)(act == VIPE_ACT_RELU ? fmaxf(v2, 0.0f) : v2);
+        hv[3] = (half_t)(act == VIPE_ACT_RELU ? fmaxf(v3, 0.0f) : v3);
+        *reinterpret_cast<half4v*>(ostage + (16 * jj + l16) * LKC_OPITCH + 32 * wave + 16 * i + 4 * kg) = hv;
+      }
+    __syncthreads();
+    // 256 contiguous bytes per pixel: 2 x 16 B per thread
+    {
+      const int pq = tid >> 3, ck = tid & 7;
+      const int pg = (grp % gpp) * 32 + pq;
+      if (pg < P) {
+        half_t* dst = out + ((int64_t)n * P + pg) * out_ctot + out_coff;
+        *reinterpret_cast<uint4v*>(dst + ck * 8) = *reinterpret_cast<const uint4v*>(ostage + pq * LKC_OPITCH + ck * 8);
+        *reinterpret_cast<uint4v*>(dst + 64 + ck * 8) = *reinterpret_cast<const uint4v*>(ostage + pq * LKC_OPITCH + 64 + ck * 8);
+      }
+    }
+  }
+}
+
 // adjoint: each lane owns its pixel's slab, so plain stores into a zero-filled gradient are race free.
 template <typename T, int R>
 __global__ __launch_bounds__(256) void corr_index_backward_kernel(const float* __restrict__ coords,
@@ -487,4 +639,27 @@ VIPE_EXPORT int vipe_corr_pyramid_lookup_nhwc(const void* const* h_levels, const
   VIPE_CHECK_ARG(channel_stride >= num_levels * rd * rd);
   return pyramid_lookup_impl(h_levels, d_coords, d_out, B, h1, w1, h2, w2, num_levels, radius, dtype, channel_stride,
                              stream);
+}
+
+VIPE_EXPORT int vipe_corr_lookup_conv1x1(const void* const* h_levels, const float* d_coords, const void* d_w_packed,
+                                         const float* d_bias, void* d_out, int out_ctot, int out_coff, int B, int h1,
+                                         int w1, int h2, int w2, int Cout, int act, void* stream) {
+  VIPE_CHECK_ARG(B >= 0 && h1 > 0 && w1 > 0 && h2 > 0 && w2 > 0);
+  if (B == 0) return VIPE_OK;
+  VIPE_CHECK_ARG(h_levels && d_coords && d_w_packed && d_bias && d_out);
+  VIPE_CHECK_ARG(act == VIPE_ACT_NONE || act == VIPE_ACT_RELU);
+  VIPE_CHECK_ARG(out_ctot % 8 == 0 && out_coff % 8 == 0 && out_coff + Cout <= out_ctot);
+  // 4 levels, radius 3, fp16 volume whose coarsest level still has 8-element row chunks; 128 output channels
+  if (Cout != 128 || ((w2 >> 3) & 7) != 0 || (h2 >> 3) < 1) return VIPE_EUNSUPPORTED;
+  LevelPtrs lv;
+  for (int i = 0; i < 4; ++i) {
+    VIPE_CHECK_ARG(h_levels[i]);
+    lv.p[i] = h_levels[i];
+  }
+  const int64_t ngroups = (int64_t)B * ((h1 * w1 + 31) / 32);
+  const int blocks = (int)std::min<int64_t>(ngroups, 256 * 4);
+  corr_lookup_conv_kernel<<<blocks, 256, 0, as_stream(stream)>>>(lv, d_coords, (const half_t*)d_w_packed, d_bias,
+                                                                 (half_t*)d_out, out_ctot, out_coff, h1, w1, h2, w2, B,
+                                                                 128, act);
+  return vipe_launch_status();
 }

@@ -231,8 +231,9 @@ class FactorGraph:
         coords1, motn = slam_ext.reproject_motion_nhwc(buf.poses, buf.flattened_disps, buf.intrinsics, buf.rig,
                                                        P["pi"], P["qi"], P["pj"], P["qj"], P["di"],
                                                        self.target[0].contiguous(), camera=buf.camera_type)
-        corr = self.corr.lookup_nhwc(coords1)  # [E,h,w,200] channels-last, one launch for the 4 levels
         eng = self.update_op.engine(self.device)
+        # hip: the lookup is deferred into the correlation encoder's first convolution (one kernel, no [E,h,w,200])
+        corr = self.corr.lookup_deferred(coords1) if eng.backend == "hip" else self.corr.lookup_nhwc(coords1)
         if eng.backend == "hip":
             self.net_n, dw, eta, _ = eng.forward_nhwc(self.net_n, self.xbuf, corr, motn, ix=P["dix"], n_src=P["n_src"],
                                                       net_out=self._net_spare(), csr=P["csr"])

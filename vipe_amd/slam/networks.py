@@ -38,6 +38,15 @@ class CorrBlock:
         """coords [E,h,w,2] -> [E,h,w,channel_stride] fp16 channels-last (the GRU's input layout)."""
         return droid_net_ext.corr_pyramid_lookup_nhwc(self.corr_pyramid, coords, self.radius, channel_stride)
 
+    def lookup_deferred(self, coords):
+        """Handle for the fused lookup + correlation-encoder kernel (`UpdateEngine.forward_nhwc` consumes it), or the
+        materialised channels-last lookup when the fused kernel does not cover this pyramid."""
+        lv = self.corr_pyramid
+        if (self.num_levels == 4 and self.radius == 3 and lv[0].dtype == torch.float16 and lv[0].is_cuda
+                and (lv[0].shape[-1] >> 3) % 8 == 0 and (lv[0].shape[-2] >> 3) >= 1):
+            return ("lookup", lv, coords.contiguous())
+        return self.lookup_nhwc(coords)
+
     def cat(self, other):
         for i in range(self.num_levels):
             self.corr_pyramid[i] = torch.cat([self.corr_pyramid[i], other.corr_pyramid[i]], 0)

@@ -144,8 +144,13 @@ class UpdateEngine:
         glo = self._buf("glo", (E, 128), torch.float32)
         if net_out is None:
             net_out = torch.empty_like(net)
-        # encoders (droid_net.py:481-482)
-        self._conv(self.corr0, corr, 0, E, H, W, y=c1, act="relu", cin=CORR_CH)
+        # encoders (droid_net.py:481-482).  `corr` may be a deferred lookup ("lookup", levels, coords): lookup and the
+        # first 1x1 convolution then run as ONE kernel and the [E,h,w,200] tensor never exists
+        if isinstance(corr, tuple):
+            from ..ext import droid_net_ext
+            droid_net_ext.corr_lookup_conv1x1(corr[1], corr[2], self.corr0.packed, self.corr0.bias, c1, act="relu")
+        else:
+            self._conv(self.corr0, corr, 0, E, H, W, y=c1, act="relu", cin=CORR_CH)
         self._conv(self.corr2, c1, 0, E, H, W, y=xbuf, y_coff=128, act="relu")
         self._conv(self.flow0, motn, 0, E, H, W, y=f1, act="relu")
         self._conv(self.flow2, f1, 0, E, H, W, y=xbuf, y_coff=256, act="relu")
