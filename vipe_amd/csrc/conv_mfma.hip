@@ -918,6 +918,81 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
 }
 
+// ---- global-context gate (droid_net.py:392-393): glo[e, c] += sum_p sigmoid(W net[e, p] + b)[c] * net[e, p, c] with
+// a 128 -> 128 1x1 convolution.  The general 1x1 path streams `net` through LDS for the MFMA and reads it a second
+// time from HBM for the gate product; here the 256-pixel tile [256][128] stays resident in LDS for both uses (217 MB
+// of HBM reads per launch instead of 434 MB) and the weights live in registers.
+constexpr int GLO_PITCH = 136;  // halves per staged pixel
+constexpr size_t GLO_LDS = 256 * GLO_PITCH * 2 + 128 * 4;
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv1x1_glo_kernel(ConvArgs a) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  half_t* xt = reinterpret_cast<half_t*>(lds);                          // [256 px][136]
+  float* gacc = reinterpret_cast<float*>(lds + 256 * GLO_PITCH * 2);    // [128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, kg = lane >> 4;
+  const int wq = wave & 3, wp = wave >> 2;  // cout quarter (32 couts), pixel half (128 px)
+  const int HW = a.H * a.W;
+  const int64_t pix0 = (int64_t)blockIdx.x * 256;  // tiles never straddle images: HW % 256 == 0
+  const int e = (int)(pix0 / HW);
+  if (tid < 128) gacc[tid] = 0.0f;
+  // tile -> LDS (16 B per lane, 256 contiguous bytes per pixel)
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int i = tid + 512 * it, px = i >> 4, ck = i & 15;
+    *reinterpret_cast<half8*>(xt + px * GLO_PITCH + ck * 8) =
+        *reinterpret_cast<const half8*>(a.x0 + (pix0 + px) * a.x0_ctot + a.x0_coff + ck * 8);
+  }
+  // weights of this wave: couts 32 wq + 16 i + l16, k = 32 s + 8 kg (packed [k / 64][Cout_pad][64])
+  half8 af[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const int k = 32 * s2 + 8 * kg, r = 32 * wq + 16 * i + l16;
+      af[i][s2] = *reinterpret_cast<const half8*>(a.w + ((int64_t)(k >> 6) * a.Cout_pad + r) * 64 + (k & 63));
+    }
+  float4 bv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) bv[i] = *reinterpret_cast<const float4*>(a.bias + 32 * wq + 16 * i + 4 * kg);
+  __syncthreads();
+  float gs[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll 2
+  for (int j = 0; j < 8; ++j) {  // 16-pixel groups of this wave's 128 pixels
+    const int pxb = wp * 128 + j * 16 + l16;
+    float4v acc[2] = {float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const half8 xf = *reinterpret_cast<const half8*>(xt + pxb * GLO_PITCH + 32 * s2 + 8 * kg);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][s2], xf, acc[i], 0, 0, 0);
+    }
+    // D rows = couts 32 wq + 16 i + 4 kg + r, column = pixel pxb
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const half4 nv = *reinterpret_cast<const half4*>(xt + pxb * GLO_PITCH + 32 * wq + 16 * i + 4 * kg);
+      const float b4[4] = {bv[i].x, bv[i].y, bv[i].z, bv[i].w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        gs[i][r] += (float)(half_t)act_apply(acc[i][r] + b4[r], VIPE_ACT_SIGMOID) * (float)nv[r];
+    }
+  }
+  // sum over the 16 pixel lanes of each kg group (DPP row reductions), then over the workgroup in LDS
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = gs[i][r];
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+      if (l16 == 0) atomicAdd(&gacc[32 * wq + 16 * i + 4 * kg + r], v);
+    }
+  __syncthreads();
+  if (tid < a.Cout) atomicAdd(a.fout + (int64_t)e * a.Cout + tid, gacc[tid]);
+}
+
 // ---- 7x7, 4 input channels (the flow encoder's first conv, droid_net.py:447): K = 49 taps x 4 = 196 -> 224.
 // The whole packed weight tensor (4 blocks of [128 cout][64 k], 64 KiB) is brought to LDS once by LDS-DMA; the
 // (4 + 6) x (64 + 6) pixel halo of the tile (8 B per pixel, 5.5 KiB) is staged through registers.  A 16x16x32
@@ -1108,6 +1183,17 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
   const bool halo = glds && a.W % HALO_TW == 0 && a.H % HALO_TH == 0 && a.KH == a.KW && (a.KH == 1 || a.KH == 3) &&
                     (int64_t)a.B * a.H * a.W * (a.x0_ctot > a.x1_ctot ? a.x0_ctot : a.x1_ctot) * 2 < (1ll << 32) &&
                     getenv("VIPE_AMD_CONV_NOHALO") == nullptr;
+  if (a.epi == EPI_GLO && a.KH == 1 && a.KW == 1 && a.Cin == 128 && a.Cout == 128 && cp == 128 && a.split >= a.Cin &&
+      (a.H * a.W) % 256 == 0 && a.x0_ctot % 8 == 0 && a.x0_coff % 8 == 0 && a.net == a.x0 && a.net_ctot == a.x0_ctot &&
+      a.net_coff == a.x0_coff && a.extra == nullptr && getenv("VIPE_AMD_CONV_NOGLO") == nullptr) {
+    static bool gattr = false;
+    if (!gattr) {
+      (void)hipFuncSetAttribute((const void*)conv1x1_glo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GLO_LDS);
+      gattr = true;
+    }
+    conv1x1_glo_kernel<<<dim3((unsigned)(M / 256)), 512, GLO_LDS, s>>>(a);
+    return vipe_launch_status();
+  }
   if (halo && a.KH == 3 && a.Cout <= 16 && cp == 32 && (a.split >= a.Cin || a.split % H32_BK == 0) &&
       (a.epi == EPI_HEADS || a.epi == EPI_ETA || a.epi == EPI_PLAIN) && getenv("VIPE_AMD_CONV_NONARROW") == nullptr) {
     static bool nattr = false;
