@@ -522,11 +522,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if constexpr (M16) {
       const int xa0 = swz32<true>(rb, lk);
       half8 wf[MI];
+#ifdef VIPE_ABL_NOLDS  // ablation builds (scratch/build_abl.sh): constant fragments instead of LDS reads
+      (void)xa0;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) wf[i] = half8{(half_t)1, (half_t)2, (half_t)3, (half_t)4, (half_t)1, (half_t)2, (half_t)3, (half_t)4};
+#else
 #pragma unroll
       for (int i = 0; i < MI; ++i) wf[i] = *reinterpret_cast<const half8*>(bw + (wa0 + i * 1024));
+#endif
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
+#ifdef VIPE_ABL_NOLDS
+        const half8 xf = half8{(half_t)0.5f, (half_t)0.25f, (half_t)0.5f, (half_t)0.25f, (half_t)0.5f, (half_t)0.25f, (half_t)0.5f, (half_t)0.25f};
+#else
         const half8 xf = *reinterpret_cast<const half8*>(bx + (xa0 + j * 1024));
+#endif
 #pragma unroll
         for (int i = 0; i < MI; ++i)
           acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf, acc16[i][j], 0, 0, 0);
@@ -574,6 +584,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       auto tap_step = [&](auto TAPC) {
         constexpr int TAP = decltype(TAPC)::value;
         constexpr int T2 = TAP + 2;
+#ifndef VIPE_ABL_NODMA  // ablation: no LDS-DMA in the K loop (operands stay those of the prologue)
         if constexpr (T2 < 9) {
           issueW(wsrc(T2, c), T2 % 3);
         } else {
@@ -584,11 +595,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           if (more && piece_used(TAP)) issueX(c + 1, TAP, (c + 1) & 1);
           else glds16(zp, sink_a);
         }
+#endif
         mma_step(ldsW + (TAP % 3) * WSTAGE, bx, Rl, TAP / 3 - 1, TAP % 3 - 1);
+#ifndef VIPE_ABL_NODMA
         if constexpr (TAP == 0 || TAP == 4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else if constexpr (TAP < 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+#endif
+#ifndef VIPE_ABL_NOBAR  // ablation: no per-tap barrier
         __syncthreads();
+#endif
       };
       tap_step(std::integral_constant<int, 0>{});
       tap_step(std::integral_constant<int, 1>{});
