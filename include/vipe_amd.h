@@ -292,11 +292,16 @@ int vipe_conv_packed_dims(int Cout, int Cin, int KH, int KW, int* cout_pad, int*
  *   4 HEADS   Cout = 4: fout[pixel] = (delta_x, delta_y, sigmoid(w_x), sigmoid(w_y)) as float (:486-490)
  *   5 ETA     Cout = 1: fout[pixel] = 0.01 * softplus(conv + bias)                            (:410,429)
  */
+/* d_accinit (optional, fp16 [B*H*W, ai_ctot], channels [ai_coff, ai_coff + Cout)): initial value of the accumulators,
+ * i.e. a precomputed partial sum over OTHER input channels (convolution is linear in its input channels).  Used to
+ * hoist the context-feature part of the GRU gates, constant per edge, out of the update iteration.  Supported for
+ * image widths that are multiples of 64 and Cout >= 64; VIPE_EUNSUPPORTED otherwise. */
 int vipe_conv2d_fused(const void* d_x0, int x0_ctot, int x0_coff, const void* d_x1, int x1_ctot, int x1_coff,
                       int split, const void* d_w_packed, const float* d_bias, const float* d_extra, int extra_stride,
                       int extra_off, void* d_y, int y_ctot, int y_coff, void* d_y2, int y2_ctot, int y2_coff,
-                      const void* d_net, int net_ctot, int net_coff, const void* d_z, float* d_fout, int B, int H,
-                      int W, int Cin, int Cout, int KH, int KW, int act, int mode, void* stream);
+                      const void* d_net, int net_ctot, int net_coff, const void* d_z, float* d_fout,
+                      const void* d_accinit, int ai_ctot, int ai_coff, int B, int H, int W, int Cin, int Cout, int KH,
+                      int KW, int act, int mode, void* stream);
 
 #ifdef __cplusplus
 }

@@ -380,7 +380,8 @@ def test_conv_halo_tile_kernel_against_torch_fp32():
     pk = _Packed(w, torch.zeros(128), dev())
     y = torch.empty((B, H, W, 128), dtype=torch.float16, device=dev())
     check(lib().vipe_conv2d_fused(ptr(xa), 128, 0, ptr(xb), 320, 0, 128, ptr(pk.packed), ptr(pk.bias), None, 0, 0, ptr(y),
-                                  128, 0, None, 0, 0, None, 0, 0, None, None, B, H, W, 448, 128, 3, 3, 0, 0, stream_ptr(xa)),
+                                  128, 0, None, 0, 0, None, 0, 0, None, None, None, 0, 0, B, H, W, 448, 128, 3, 3, 0, 0,
+                                  stream_ptr(xa)),
           "conv_fused")
     ref = F.conv2d(torch.cat([xa, xb], -1).float().cpu().permute(0, 3, 1, 2), w.float(), None, padding=1)
     assert (y.float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < 4e-3

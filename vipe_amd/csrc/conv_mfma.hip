@@ -48,6 +48,7 @@ struct ConvArgs {
   const half_t* zbuf;                          // [M,128] (Q)
   half_t* y2; int y2_ctot, y2_coff;            // second output (ZR: r*net)
   float* fout;                                 // GLO: glo_sum [B,Cout]; HEADS: [M,4]; ETA: [M]
+  const half_t* accinit; int ai_ctot, ai_coff;  // optional initial accumulator [M, ai_ctot] (a partial conv sum)
 };
 
 constexpr int BNP = 128;  // pixels per tile
@@ -501,6 +502,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) acc16[i][j] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+    if constexpr (BMC >= 64) {
+      // the accumulators may start from a precomputed partial sum (convolution is linear in its input channels:
+      // the part of a GRU gate that only depends on the per-edge context features is computed once per edge)
+      if (a.accinit) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int64_t m = pix_of(wn * 64 + j * 16 + (lane & 15));
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            const int cg = cout0 + wm * (MI * 16) + i * 16 + 4 * (lane >> 4);
+            const half4 v = *reinterpret_cast<const half4*>(a.accinit + m * a.ai_ctot + a.ai_coff + cg);
+            acc16[i][j] = float4v{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+          }
+        }
+      }
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1199,6 +1216,11 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
   const bool halo = glds && a.W % HALO_TW == 0 && a.H % HALO_TH == 0 && a.KH == a.KW && (a.KH == 1 || a.KH == 3) &&
                     (int64_t)a.B * a.H * a.W * (a.x0_ctot > a.x1_ctot ? a.x0_ctot : a.x1_ctot) * 2 < (1ll << 32) &&
                     getenv("VIPE_AMD_CONV_NOHALO") == nullptr;
+  if (a.accinit) {
+    // initial accumulators are implemented by the 32-channel halo kernel with >= 64 output channels only
+    const bool ok = halo && cp >= 64 && (a.split >= a.Cin || a.split % H32_BK == 0) && !(a.KH == 3 && a.Cout <= 16);
+    if (!ok) return VIPE_EUNSUPPORTED;
+  }
   if (a.epi == EPI_GLO && a.KH == 1 && a.KW == 1 && a.Cin == 128 && a.Cout == 128 && cp == 128 && a.split >= a.Cin &&
       (a.H * a.W) % 256 == 0 && a.x0_ctot % 8 == 0 && a.x0_coff % 8 == 0 && a.net == a.x0 && a.net_ctot == a.x0_ctot &&
       a.net_coff == a.x0_coff && a.extra == nullptr && getenv("VIPE_AMD_CONV_NOGLO") == nullptr) {
@@ -1318,9 +1340,11 @@ VIPE_EXPORT int vipe_conv2d_fused(const void* d_x0, int x0_ctot, int x0_coff, co
                                   int x1_coff, int split, const void* d_w_packed, const float* d_bias,
                                   const float* d_extra, int extra_stride, int extra_off, void* d_y, int y_ctot,
                                   int y_coff, void* d_y2, int y2_ctot, int y2_coff, const void* d_net, int net_ctot,
-                                  int net_coff, const void* d_z, float* d_fout, int B, int H, int W, int Cin,
-                                  int Cout, int KH, int KW, int act, int mode, void* stream) {
+                                  int net_coff, const void* d_z, float* d_fout, const void* d_accinit, int ai_ctot,
+                                  int ai_coff, int B, int H, int W, int Cin, int Cout, int KH, int KW, int act, int mode,
+                                  void* stream) {
   VIPE_CHECK_ARG(d_x0 && d_w_packed && d_bias);
+  VIPE_CHECK_ARG(!d_accinit || (ai_ctot % 4 == 0 && ai_coff % 4 == 0 && ai_coff + Cout <= ai_ctot));
   VIPE_CHECK_ARG(B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (KH & 1) && (KW & 1));
   if (Cin == 4) {
     VIPE_CHECK_ARG(split >= Cin && x0_ctot % 4 == 0 && x0_coff % 4 == 0);
@@ -1344,6 +1368,7 @@ VIPE_EXPORT int vipe_conv2d_fused(const void* d_x0, int x0_ctot, int x0_coff, co
   a.y2 = (half_t*)d_y2; a.y2_ctot = y2_ctot; a.y2_coff = y2_coff;
   a.net = (const half_t*)d_net; a.net_ctot = net_ctot; a.net_coff = net_coff;
   a.zbuf = (const half_t*)d_z; a.fout = d_fout;
+  a.accinit = (const half_t*)d_accinit; a.ai_ctot = ai_ctot; a.ai_coff = ai_coff;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW;
   a.act = act; a.epi = mode;
   return launch_conv(a, as_stream(stream));

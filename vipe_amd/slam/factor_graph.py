@@ -31,6 +31,7 @@ class FactorGraph:
         self.weight = torch.zeros([1, 0, ht, wd, 2], device=device, dtype=torch.float)
         # channels-last state of the flow-update operator: hidden state [E,h,w,128] and [inp | corr | flow] features
         self.corr, self.net_n, self.xbuf = None, None, None
+        self.pgate = None  # [E,h,w,384]: context-feature part of the GRU gates, computed once per edge
         self.ii_inac = torch.as_tensor([], dtype=torch.long, device=device)
         self.jj_inac = torch.as_tensor([], dtype=torch.long, device=device)
         self.target_inac = torch.zeros([1, 0, ht, wd, 2], device=device, dtype=torch.float)
@@ -64,6 +65,10 @@ class FactorGraph:
                              device=self.device)
             xb[..., 0:128] = self.buffer.inps[pi, qi].permute(0, 2, 3, 1)
             self.xbuf = xb if self.xbuf is None else torch.cat([self.xbuf, xb], 0)
+            eng = self.update_op.engine(self.device)
+            if eng.backend == "hip" and eng.supports_gate_split(self.ht, self.wd):
+                pg = eng.gate_context(xb)
+                self.pgate = pg if self.pgate is None else torch.cat([self.pgate, pg], 0)
         target, _ = self.buffer.reproject_dense_disp(ii, jj)
         target = target[None]
         self.ii = torch.cat([self.ii, ii], 0)
@@ -92,6 +97,8 @@ class FactorGraph:
             self.net_n = self.net_n[~exp_mask]
         if self.xbuf is not None:
             self.xbuf = self.xbuf[~exp_mask]
+        if self.pgate is not None:
+            self.pgate = self.pgate[~exp_mask]
         self.target = self.target[:, ~exp_mask]
         self.weight = self.weight[:, ~exp_mask]
         self._plan = None
@@ -236,7 +243,7 @@ class FactorGraph:
         corr = self.corr.lookup_deferred(coords1) if eng.backend == "hip" else self.corr.lookup_nhwc(coords1)
         if eng.backend == "hip":
             self.net_n, dw, eta, _ = eng.forward_nhwc(self.net_n, self.xbuf, corr, motn, ix=P["dix"], n_src=P["n_src"],
-                                                      net_out=self._net_spare(), csr=P["csr"])
+                                                      net_out=self._net_spare(), csr=P["csr"], pgate=self.pgate)
             delta, weight = dw[None, ..., 0:2], dw[None, ..., 2:4].clone()
         else:  # A/B baseline: reference-shaped NCHW call
             f_net, delta, weight, eta, _ = eng.forward(
