@@ -768,3 +768,32 @@ def test_fused_lookup_conv1x1_matches_lookup_then_conv():
     # against the fp32 restatement: relu(W corr + b)
     r32 = torch.relu(torch.einsum("ehwc,oc->ehwo", corr[..., :196].float().cpu(), wt[:, :196, 0, 0].half().float()) + bias)
     assert float((out[..., 16:144].float().cpu() - r32).abs().max()) < 3e-2
+
+
+def test_gate_context_hoisting_equals_full_gate_convolutions():
+    """`UpdateEngine.gate_context` + accumulator initialisation (linearity of the gate convolutions in their input
+    channels) against the full 448-channel gate convolutions on the same inputs: identical up to the fp16 rounding of
+    the hoisted partial sum (the reference rounds once, after the full fp32 accumulation)."""
+    from vipe_amd.slam.networks import UpdateModule
+
+    torch.manual_seed(0)
+    um = UpdateModule().eval()
+    eng = um.engine(dev())
+    gen = torch.Generator().manual_seed(21)
+    E, H, W = 3, 8, 64
+    net = torch.randn(E, H, W, 128, generator=gen).tanh().half().to(dev())
+    xbuf = torch.zeros(E, H, W, 320, dtype=torch.float16, device=dev())
+    xbuf[..., :128] = torch.randn(E, H, W, 128, generator=gen).relu().half().to(dev())
+    corr = torch.zeros(E, H, W, 200, dtype=torch.float16, device=dev())
+    corr[..., :196] = (torch.randn(E, H, W, 196, generator=gen) * 0.5).half().to(dev())
+    motn = (torch.randn(E, H, W, 4, generator=gen) * 2).half().to(dev())
+    ix = torch.tensor([0, 0, 1], device=dev())
+    outs = []
+    for hoist in (False, True):
+        xb = xbuf.clone()
+        pg = eng.gate_context(xb) if hoist else None
+        n2, dw, eta, _ = eng.forward_nhwc(net.clone(), xb, corr, motn, ix=ix, n_src=2, pgate=pg)
+        outs.append((n2.float().cpu(), dw.clone().cpu(), eta.clone().cpu()))
+    assert (outs[0][0] - outs[1][0]).abs().max().item() < 4e-3
+    assert (outs[0][1] - outs[1][1]).abs().max().item() < 2e-2
+    assert (outs[0][2] - outs[1][2]).abs().max().item() < 1e-3
