@@ -797,3 +797,47 @@ def test_gate_context_hoisting_equals_full_gate_convolutions():
     assert (outs[0][0] - outs[1][0]).abs().max().item() < 4e-3
     assert (outs[0][1] - outs[1][1]).abs().max().item() < 2e-2
     assert (outs[0][2] - outs[1][2]).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("case", ["full", "motion_only", "prior_stereo_t0"])
+def test_slam_ext_ba_droid_signature_against_restatement(case):
+    """Row a13: `slam_ext.ba` (DROID signature, geom_kernels.cu:1273-1404; dormant in the reference).  PARITY UNPINNED:
+    the reference's CUDA/Eigen implementation cannot run here and has no fixture; the check is the HIP path against
+    the CPU restatement of the source text (oracle/droid_ba.py, incl. its quirks), 1e-4 relative."""
+    from oracle import droid_ba as odb
+    from vipe_amd.ext import slam_ext
+
+    g = make_graph(n=6, height=96, width=128, radius=2, seed=61, depth_prior=(case == "prior_stereo_t0"))
+    n, ht, wd = 6, g.ht, g.wd
+    ii, jj = g.ii.copy(), g.jj.copy()
+    tgt = g.target.reshape(len(ii), ht, wd, 2)
+    wgt = g.weight.reshape(len(ii), ht, wd, 2)
+    t0, t1 = (2, 6) if case == "prior_stereo_t0" else (1, 6)
+    if case == "prior_stereo_t0":  # a stereo term (ii == jj): only its disparity part may act
+        ii, jj = np.append(ii, 3), np.append(jj, 3)
+        u, v = ogeom.pixel_grid(ht, wd, np.float32)
+        st = np.stack([u - 0.1 * g.intrinsics[0, 0] / 8 * g.disps[3], v], -1)[None]
+        tgt = np.concatenate([tgt, st + 0.3], 0)
+        wgt = np.concatenate([wgt, np.full_like(st, 0.5)], 0)
+    targets = np.ascontiguousarray(tgt.transpose(0, 3, 1, 2)).astype(np.float32)
+    weights = np.ascontiguousarray(wgt.transpose(0, 3, 1, 2)).astype(np.float32)
+    kx = np.unique(np.concatenate([np.arange(t0, t1), ii]))
+    rng = np.random.default_rng(4)
+    eta = (1e-3 + 0.05 * rng.random((len(kx), ht, wd))).astype(np.float32)
+    intr8 = (g.intrinsics[0, :4] / 8.0).astype(np.float32)
+    sens = g.disps_sens.copy()
+    if case == "prior_stereo_t0":
+        sens[:, ::2] = 0.0  # per-pixel mask: half of the rows have no sensor depth
+    mo = case == "motion_only"
+    poses, disps = T(g.poses).clone(), T(g.disps).clone()
+    dx, dz = slam_ext.ba(poses, disps, T(intr8), T(sens), T(targets), T(weights), T(eta), T(ii), T(jj), t0, t1, 2,
+                         1e-4, 0.1, mo)
+    op, od, odx, odz = odb.droid_ba(g.poses, g.disps, intr8, sens, targets, weights, eta, ii, jj, t0, t1, 2, 1e-4, 0.1, mo)
+    assert np.abs(poses.cpu().numpy() - op).max() <= 1e-4 * max(1.0, np.abs(op).max())
+    assert np.abs(disps.cpu().numpy() - od).max() <= 1e-4 * np.abs(od).max()
+    assert np.abs(dx.cpu().numpy() - odx).max() <= 1e-4 * max(np.abs(odx).max(), 1e-2)
+    if not mo:
+        assert np.abs(dz.cpu().numpy() - odz).max() <= 1e-4 * max(np.abs(odz).max(), 1e-2)
+        assert np.abs(odz).max() > 1e-4
+    else:
+        assert np.all(disps.cpu().numpy() == g.disps)

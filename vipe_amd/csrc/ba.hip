@@ -46,6 +46,7 @@ struct BAWs {
   double* S;        // [(nmax+1),(nmax+1)] lower triangle + rhs row
   double* Hd;       // [nmax] undamped diagonal of H (for lambda * diag)
   float* dx;        // [nmax]
+  int* krow;        // [nF] DROID mode: row of frame k in the sorted unique set arange(t0,t1) U ii (eta / dz row)
   int ld;           // nmax + 1
 };
 
@@ -57,6 +58,11 @@ struct BAArgs {
   BAWs w;
   int P, nF, D;
   int force_simple;  // VIPE_BA_ACCUM_SIMPLE: shuffle-reduction accumulate kernel for every graph (A/B, debugging)
+  // DROID semantics of slam_ext.ba (geom_kernels.cu:178-432, 1273-1404; see oracle/droid_ba.py for the list):
+  // target / weight [M,2,P], eta [K,P] by krow, per-pixel depth prior, reduced-diagonal damping, poses free iff in
+  // [t0,t1), stereo terms, MIN_DEPTH 0.25, pose t0 left out of the disparity back-substitution, dz written to dz_out
+  int droid;
+  float* dz_out;
 };
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -87,6 +93,7 @@ size_t carve(const vipe_ba_params& p, char* base, BAWs* out) {
   w.S = (double*)take(8 * (nmax + 1) * (nmax + 1));
   w.Hd = (double*)take(8 * (nmax + 16));  // + 16 debug stamp slots
   w.dx = (float*)take(4 * nmax);
+  w.krow = (int*)take(4 * (nF + 1));
   w.ld = (int)(nmax + 1);
   if (out) *out = w;
   return off;
@@ -157,10 +164,21 @@ __global__ __launch_bounds__(1024) void ba_plan_kernel(BAArgs a) {
   for (int k = t; k < nF; k += 1024) {
     const int pose = k / V;
     int f = cnt[k] > 0 ? 1 : 0;
-    bool dfree = f && !p.motion_only && !(p.limited_disp && (pose < p.t0 || pose >= p.t1));  // buffer.py:490-493
-    if (dfree) { f |= 2; ++nfd_local; }
-    if (dfree && a.w.sens_sum[k] > 0.0f) f |= 4;
+    if (a.droid) {
+      // disparity frames = unique(arange(t0,t1) U ii) (geom_kernels.cu:1297-1303); bit 3: in the set without terms
+      const bool inkx = f || (k >= p.t0 && k < p.t1);
+      a.w.krow[k] = inkx ? 1 : 0;
+      if (inkx && !p.motion_only) { f |= 2; ++nfd_local; if (!(f & 1)) f |= 8; }
+    } else {
+      bool dfree = f && !p.motion_only && !(p.limited_disp && (pose < p.t0 || pose >= p.t1));  // buffer.py:490-493
+      if (dfree) { f |= 2; ++nfd_local; }
+      if (dfree && a.w.sens_sum[k] > 0.0f) f |= 4;
+    }
     a.w.fflags[k] = f;
+  }
+  if (a.droid) {
+    __syncthreads();
+    block_scan_excl(a.w.krow, nF, lds);
   }
   // rowptr = exclusive scan of counts
   for (int i = t; i < nF; i += 1024) a.w.rowptr[i] = cnt[i];
@@ -170,7 +188,8 @@ __global__ __launch_bounds__(1024) void ba_plan_kernel(BAArgs a) {
   // pose slots (buffer.py:462-465: fixed iff it is a source pose outside [t0,t1); t0 == t1 fixes all)
   for (int i = t; i < nP; i += 1024) {
     const bool fixed = all_fixed || (is_src[i] && (i < p.t0 || i >= p.t1));
-    a.w.pose_slot[i] = (used[i] && !fixed) ? 1 : 0;
+    // DROID: the system has one block per pose of [t0, t1), used or not (SparseBlock(t1 - t0, 6))
+    a.w.pose_slot[i] = a.droid ? ((i >= p.t0 && i < p.t1) ? 1 : 0) : ((used[i] && !fixed) ? 1 : 0);
   }
   __syncthreads();
   for (int i = t; i < nP; i += 1024) is_src[i] = a.w.pose_slot[i];  // keep the 0/1 flags
@@ -231,6 +250,58 @@ __global__ __launch_bounds__(1024) void ba_plan_kernel(BAArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ accumulate
+
+// target / weight of term e at pixel p: live layout [M,P,2], DROID layout [M,2,P] (geom_kernels.cu:304-309)
+__device__ __forceinline__ void load_tw(const BAArgs& a, int e, int p, int P, float2& tgt, float2& wg) {
+  if (a.droid) {
+    const int64_t o = (int64_t)e * 2 * P + p;
+    tgt = make_float2(a.target[o], a.target[o + P]);
+    wg = make_float2(a.weight[o], a.weight[o + P]);
+  } else {
+    const int64_t o2 = ((int64_t)e * P + p) * 2;
+    tgt = *reinterpret_cast<const float2*>(a.target + o2);
+    wg = *reinterpret_cast<const float2*>(a.weight + o2);
+  }
+}
+// validity weight: live z0... target-side z > 0.1 (geom.py:263); DROID !(z < 0.25) (geom_kernels.cu:33,304)
+__device__ __forceinline__ float valid_weight(const BAArgs& a, float Z, bool inb) {
+  const bool ok = a.droid ? !(Z < 0.25f) : (Z > cam::MIN_DEPTH);
+  return (inb && ok) ? a.p.weight_scale : 0.0f;
+}
+// per-term transforms incl. the DROID stereo term (ii == jj: fixed baseline, no pose blocks; geom_kernels.cu:222-233)
+__device__ __forceinline__ void term_setup(const BAArgs& a, int e, TermGeom& g) {
+  const int pi = (int)a.pi[e], pj = (int)a.pj[e], qj = (int)a.qj[e];
+  term_transforms(a.poses, a.rig, pi, (int)a.qi[e], pj, qj, g.T, g.G, g.Rr);
+  g.Ij = cam::load_scaled(a.intr + qj * (4 + a.D), a.D, 1.0f / a.p.intr_factor);
+  g.e = e;
+  g.merge = (pi == pj);
+  if (a.droid && pi == pj) {
+    g.merge = 2;  // stereo
+    for (int i = 0; i < 9; ++i) g.T.R[i] = g.G.R[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+    g.T.t[0] = g.G.t[0] = -0.1f;
+    g.T.t[1] = g.T.t[2] = g.G.t[1] = g.G.t[2] = 0.0f;
+  }
+  g.rig_adj = !(g.Rr.t[0] == 0.f && g.Rr.t[1] == 0.f && g.Rr.t[2] == 0.f && g.Rr.R[0] == 1.f &&
+                g.Rr.R[4] == 1.f && g.Rr.R[8] == 1.f);
+  g.sj = g.merge ? -1 : a.w.pose_slot[pj];
+}
+// sensor-depth prior and damping of one pixel's disparity block.  Live: frame-level flag, C += alpha, then the
+// damping 1e-7 + (0.2 eta + 1e-7) (terms.py:258-268, buffer.py:482-489).  DROID: per-pixel mask m = sens > 0,
+// C += m ? alpha : eta, w -= m alpha (d - sens) (geom_kernels.cu:1359-1369).
+__device__ __forceinline__ void finish_disp(const BAArgs& a, int k, int p, int P, int flags, float d, float& C, float& wz) {
+  const int64_t kp = (int64_t)k * P + p;
+  if (a.droid) {
+    const float sv = a.sens[kp];
+    if (sv > 0.0f) { C += a.p.alpha; wz -= a.p.alpha * (d - sv); }
+    else C += a.eta[(int64_t)a.w.krow[k] * P + p];
+  } else {
+    if (flags & 4) {
+      C += a.p.alpha;
+      wz -= a.p.alpha * (d - a.sens[kp]);
+    }
+    C += 1e-7f + (0.2f * a.eta[kp] + 1e-7f);
+  }
+}
 
 // lower-triangle index table for symmetric 6x6 (21 entries): (r,c), r >= c
 __device__ __constant__ int8_t SYM_R[21] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5};
@@ -300,16 +371,8 @@ __global__ __launch_bounds__(TILE) void ba_accum_kernel(BAArgs a) {
     const int nt = min(TCHUNK, end - c0);
     __syncthreads();
     if (tid < nt) {
-      const int e = w.order[c0 + tid];
-      const int pi = (int)a.pi[e], pj = (int)a.pj[e], qj = (int)a.qj[e];
       TermGeom g;
-      term_transforms(a.poses, a.rig, pi, (int)a.qi[e], pj, qj, g.T, g.G, g.Rr);
-      g.Ij = cam::load_scaled(a.intr + qj * (4 + a.D), a.D, 1.0f / prm.intr_factor);
-      g.e = e;
-      g.merge = (pi == pj);
-      g.rig_adj = !(g.Rr.t[0] == 0.f && g.Rr.t[1] == 0.f && g.Rr.t[2] == 0.f && g.Rr.R[0] == 1.f &&
-                    g.Rr.R[4] == 1.f && g.Rr.R[8] == 1.f);
-      g.sj = g.merge ? -1 : w.pose_slot[pj];
+      term_setup(a, w.order[c0 + tid], g);
       tg[tid] = g;
     }
     __syncthreads();
@@ -322,11 +385,11 @@ __global__ __launch_bounds__(TILE) void ba_accum_kernel(BAArgs a) {
       const float Z = G.T.R[6] * X0 + G.T.R[7] * Y0 + G.T.R[8] + G.T.t[2] * d;
       float x, y, Jp[2][3], Jfj[2][FF];
       cam::proj<CAM, true, F>(G.Ij, X, Y, Z, x, y, Jp, Jfj);
-      const int64_t o2 = ((int64_t)e * P + p) * 2;
-      const float2 tgt = *reinterpret_cast<const float2*>(a.target + o2);
-      const float2 wg = *reinterpret_cast<const float2*>(a.weight + o2);
-      const float val = (inb && Z > cam::MIN_DEPTH) ? prm.weight_scale : 0.0f;  // geom.py:263, buffer.py:413
-      const float wc[2] = {val * wg.x, val * wg.y};
+      float2 tgt, wg;
+      load_tw(a, e, p, P, tgt, wg);
+      const float val = valid_weight(a, Z, inb);  // geom.py:263, buffer.py:413
+      const float wd2[2] = {val * wg.x, val * wg.y};                     // weights of the disparity system
+      const float wc[2] = {G.merge == 2 ? 0.0f : wd2[0], G.merge == 2 ? 0.0f : wd2[1]};  // ... of the pose blocks
       const float rc[2] = {x - tgt.x, y - tgt.y};
       // ---- Jacobians (geom.py:114-145, 271-281)
       float Ja[3][6] = {{d, 0, 0, 0, Z, -Y}, {0, d, 0, -Z, 0, X}, {0, 0, d, Y, -X, 0}};
@@ -360,7 +423,7 @@ __global__ __launch_bounds__(TILE) void ba_accum_kernel(BAArgs a) {
           }
         }
       }
-      if (G.merge) {
+      if (G.merge == 1) {
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -370,8 +433,8 @@ __global__ __launch_bounds__(TILE) void ba_accum_kernel(BAArgs a) {
       // ---- per-pixel disparity quantities (kept in registers across the walk)
       const float wJz[2] = {wc[0] * Jz[0], wc[1] * Jz[1]};
       if (dfree) {
-        C += wJz[0] * Jz[0] + wJz[1] * Jz[1];
-        wz -= wJz[0] * rc[0] + wJz[1] * rc[1];
+        C += wd2[0] * Jz[0] * Jz[0] + wd2[1] * Jz[1] * Jz[1];
+        wz -= wd2[0] * Jz[0] * rc[0] + wd2[1] * Jz[1] * rc[1];
 #pragma unroll
         for (int q = 0; q < 6; ++q) Ei[q] += Ji[0][q] * wJz[0] + Ji[1][q] * wJz[1];
         if constexpr (F > 0) {
@@ -495,11 +558,7 @@ __global__ __launch_bounds__(TILE) void ba_accum_kernel(BAArgs a) {
   if (!dfree) return;
   // ---- finish the disparity block of this pixel: sensor prior, damping (terms.py:258-268, buffer.py:482-489)
   const int64_t kp = (int64_t)k * P + p;
-  if (flags & 4) {
-    C += prm.alpha;
-    wz -= prm.alpha * (d - a.sens[kp]);
-  }
-  C += 1e-7f + (0.2f * a.eta[kp] + 1e-7f);
+  finish_disp(a, k, p, P, flags, d, C, wz);
   const float Q = inb ? 1.0f / C : 0.0f;
   if (inb) {
     w.C[kp] = C;
@@ -668,24 +727,16 @@ __global__ __launch_bounds__(TILE) void ba_accum_mfma_kernel(BAArgs a) {
 
   for (int i = tid; i < AM_ROWS * AM_SP + AM_DMAX * 256 + 64; i += TILE) accS[i] = 0.0f;
   if (tid < deg) {
-    const int e = w.order[beg + tid];
-    const int pi = (int)a.pi[e], pj = (int)a.pj[e], qj = (int)a.qj[e];
     TermGeomM m;
     TermGeom& g = m.g;
-    term_transforms(a.poses, a.rig, pi, (int)a.qi[e], pj, qj, g.T, g.G, g.Rr);
-    g.Ij = cam::load_scaled(a.intr + qj * (4 + a.D), a.D, 1.0f / prm.intr_factor);
-    g.e = e;
-    g.merge = (pi == pj);
-    g.rig_adj = !(g.Rr.t[0] == 0.f && g.Rr.t[1] == 0.f && g.Rr.t[2] == 0.f && g.Rr.R[0] == 1.f &&
-                  g.Rr.R[4] == 1.f && g.Rr.R[8] == 1.f);
-    g.sj = g.merge ? -1 : w.pose_slot[pj];
+    term_setup(a, w.order[beg + tid], g);
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       float ec[6] = {0, 0, 0, 0, 0, 0}, col[6];
       ec[c] = 1.0f;
       adjT_apply(g.G, ec, col);
 #pragma unroll
-      for (int r = 0; r < 6; ++r) m.Mi[r * 6 + c] = (g.merge && r == c ? 1.0f : 0.0f) - col[r];
+      for (int r = 0; r < 6; ++r) m.Mi[r * 6 + c] = (g.merge == 1 && r == c ? 1.0f : 0.0f) - col[r];
     }
     tg[tid] = m;
   }
@@ -707,9 +758,7 @@ __global__ __launch_bounds__(TILE) void ba_accum_mfma_kernel(BAArgs a) {
 #pragma unroll
     for (int uu = 0; uu < TPT; ++uu) {
       const int t = min(t0 + uu, deg - 1);
-      const int64_t o2 = ((int64_t)tg[t].g.e * P + p) * 2;
-      nx_t[uu] = *reinterpret_cast<const float2*>(a.target + o2);
-      nx_w[uu] = *reinterpret_cast<const float2*>(a.weight + o2);
+      load_tw(a, tg[t].g.e, p, P, nx_t[uu], nx_w[uu]);
     }
   };
   prefetch(0);
@@ -730,8 +779,9 @@ __global__ __launch_bounds__(TILE) void ba_accum_mfma_kernel(BAArgs a) {
       float x, y, Jp[2][3], Jfj[2][FF];
       cam::proj<CAM, true, F>(G.Ij, X, Y, Z, x, y, Jp, Jfj);
       const float2 tgt = cur_t[uu], wg = cur_w[uu];
-      const float val = (inb && Z > cam::MIN_DEPTH) ? prm.weight_scale : 0.0f;  // geom.py:263, buffer.py:413
-      const float wc[2] = {val * wg.x, val * wg.y};
+      const float val = valid_weight(a, Z, inb);  // geom.py:263, buffer.py:413
+      const float wd2[2] = {val * wg.x, val * wg.y};                     // weights of the disparity system
+      const float wc[2] = {G.merge == 2 ? 0.0f : wd2[0], G.merge == 2 ? 0.0f : wd2[1]};  // ... of the pose blocks
       const float rc[2] = {x - tgt.x, y - tgt.y};
       float Ja[3][6] = {{d, 0, 0, 0, Z, -Y}, {0, d, 0, -Z, 0, X}, {0, 0, d, Y, -X, 0}};
       if (G.rig_adj) {
@@ -773,13 +823,13 @@ __global__ __launch_bounds__(TILE) void ba_accum_mfma_kernel(BAArgs a) {
         // per-pixel disparity quantities
         if (dfree) {
           const float wJz = wc[c] * Jz;
-          C += wJz * Jz;
-          wz -= wJz * rc[c];
+          C += wd2[c] * Jz * Jz;
+          wz -= wd2[c] * Jz * rc[c];
           float tmp[6];
           adjT_apply(G.G, Jj, tmp);
 #pragma unroll
           for (int q = 0; q < 6; ++q) {
-            Ji[q] = (G.merge ? Jj[q] : 0.0f) - tmp[q];
+            Ji[q] = (G.merge == 1 ? Jj[q] : 0.0f) - tmp[q];
             Ei[q] += Ji[q] * wJz;
           }
           if constexpr (F > 0) {
@@ -821,11 +871,7 @@ __global__ __launch_bounds__(TILE) void ba_accum_mfma_kernel(BAArgs a) {
   const int NR = 6 * (deg + 1) + F + 1;  // R2 rows: pose i, targets, intrinsics, w
   if (dfree) {
     const int64_t kp = (int64_t)k * P + p;
-    if (flags & 4) {
-      C += prm.alpha;
-      wz -= prm.alpha * (d - a.sens[kp]);
-    }
-    C += 1e-7f + (0.2f * a.eta[kp] + 1e-7f);
+    finish_disp(a, k, p, P, flags, d, C, wz);
     if (inb) {
       w.C[kp] = C;
       w.wv[kp] = wz;
@@ -1104,7 +1150,7 @@ __global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds
       double v = 0.0;
       if (ln < WB && c >= 0 && c <= r) {
         v = S[(int64_t)r * ld + c];
-        if (c == r) v += (double)prm.pose_ep + (double)prm.pose_damping * w.Hd[r];
+        if (c == r) v += (double)prm.pose_ep + (double)prm.pose_damping * (a.droid ? v : w.Hd[r]);  // DROID: geom_kernels.cu:1176
       }
       if (ln < WBP) L[r * WBP + ln] = v;
     }
@@ -1380,7 +1426,7 @@ __global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_c
   for (int dd = t; dd < n; dd += SOLVE_T) {
     const bool pose = dd < 6 * n_free;
     const double ep = pose ? (double)prm.pose_ep : 1e-6, lam = pose ? (double)prm.pose_damping : 1e-6;
-    S[(int64_t)dd * ld + dd] += ep + lam * w.Hd[dd];
+    S[(int64_t)dd * ld + dd] += ep + lam * (a.droid ? S[(int64_t)dd * ld + dd] : w.Hd[dd]);
   }
   __syncthreads();
   const bool use_lds_panel = (n + 1) <= panel_cap;
@@ -1622,12 +1668,23 @@ __global__ __launch_bounds__(TILE) void ba_retract_kernel(BAArgs a) {
   const int P = a.P, V = a.p.n_views;
   const int p = blockIdx.x * TILE + threadIdx.x;
   if (p >= P) return;
-  const int beg = w.rowptr[k], end = w.rowptr[k + 1];
   const int64_t kp = (int64_t)k * P + p;
+  if (flags & 8) {
+    // DROID: frame of [t0, t1) without terms - only the depth prior acts on it (geom_kernels.cu:1359-1369)
+    float C = 0.f, wz = 0.f;
+    finish_disp(a, k, p, P, flags, a.disps[kp], C, wz);
+    const float dz = wz / C;
+    a.disps[kp] += dz;
+    if (a.dz_out) a.dz_out[(int64_t)w.krow[k] * P + p] = dz;
+    return;
+  }
+  const int beg = w.rowptr[k], end = w.rowptr[k + 1];
   float rhs = w.wv[kp];
   const int si = w.pose_slot[k / V];
   const int n_free = w.info[0];
-  if (si >= 0) {
+  // DROID leaves pose slot 0 out of the back-substitution (EvT6x1_kernel: idx <= 0 returns, geom_kernels.cu:1085)
+  const int smin = a.droid ? 1 : 0;
+  if (si >= smin) {
 #pragma unroll
     for (int q = 0; q < 6; ++q) rhs -= w.Ekk[((int64_t)k * 6 + q) * P + p] * w.dx[6 * si + q];
   }
@@ -1635,7 +1692,7 @@ __global__ __launch_bounds__(TILE) void ba_retract_kernel(BAArgs a) {
     const int e = w.order[c];
     const int pj = (int)a.pj[e];
     const int sj = ((int)a.pi[e] == pj) ? -1 : w.pose_slot[pj];
-    if (sj < 0) continue;
+    if (sj < smin) continue;
 #pragma unroll
     for (int q = 0; q < 6; ++q) rhs -= w.Ej[((int64_t)e * 6 + q) * P + p] * w.dx[6 * sj + q];
   }
@@ -1644,8 +1701,9 @@ __global__ __launch_bounds__(TILE) void ba_retract_kernel(BAArgs a) {
     for (int f = 0; f < F; ++f) rhs -= w.Ef[((int64_t)k * 2 + f) * P + p] * w.dx[6 * n_free + f];
   }
   float dz = rhs / w.C[kp];
-  if (dz > 10.0f) dz = 0.0f;  // retractor.py:41
+  if (!a.droid && dz > 10.0f) dz = 0.0f;  // retractor.py:41
   a.disps[kp] += dz;
+  if (a.dz_out) a.dz_out[(int64_t)w.krow[k] * P + p] = dz;
 }
 
 __global__ void clamp_min_kernel(float* __restrict__ x, int64_t n, float lo) {
@@ -1721,6 +1779,8 @@ VIPE_EXPORT int vipe_dense_ba(const vipe_ba_params* p, float* d_poses, float* d_
   a.nF = p->n_poses * p->n_views;
   a.D = p->camera == VIPE_CAM_MEI ? 1 : 0;
   a.force_simple = getenv("VIPE_BA_ACCUM_SIMPLE") != nullptr;
+  a.droid = 0;
+  a.dz_out = nullptr;
   hipStream_t s = as_stream(stream);
   int rc = VIPE_OK;
   if (p->M > 0 && p->n_iters > 0) {
@@ -1739,4 +1799,64 @@ VIPE_EXPORT int vipe_dense_ba(const vipe_ba_params* p, float* d_poses, float* d_
   const int64_t nd = (int64_t)a.nF * a.P;
   clamp_min_kernel<<<(int)std::min<int64_t>((nd + 255) / 256, 2048), 256, 0, s>>>(d_disps, nd, 1e-3f);
   return vipe_launch_status();
+}
+
+// ---- slam_ext.ba with the DROID signature (dormant in the reference; geom_kernels.cu:1273-1404).  Same kernels as the
+// live dense BA with the DROID semantics switched on (BAArgs::droid; oracle/droid_ba.py lists the differences).
+namespace {
+size_t droid_extra_bytes(int E) { return align_up(8 * (size_t)(E + 1)) + align_up(7 * 4); }
+vipe_ba_params droid_params(int n_poses, int ht, int wd, int E, int t0, int t1, int iterations, float lm, float ep,
+                            int motion_only) {
+  vipe_ba_params p = {};
+  p.n_poses = n_poses; p.n_views = 1; p.ht = ht; p.wd = wd; p.M = E; p.t0 = t0; p.t1 = t1; p.n_iters = iterations;
+  p.pose_damping = lm; p.pose_ep = ep; p.motion_only = motion_only; p.limited_disp = 0; p.optimize_intrinsics = 0;
+  p.optimize_rig_rotation = 0; p.camera = VIPE_CAM_PINHOLE; p.alpha = 0.05f; p.weight_scale = 0.001f; p.intr_factor = 1.0f;
+  return p;
+}
+}  // namespace
+
+VIPE_EXPORT int64_t vipe_ba_workspace_bytes(int n_poses, int ht, int wd, int E) {
+  if (n_poses <= 0 || ht <= 0 || wd <= 0 || E < 0) return VIPE_EINVAL;
+  const vipe_ba_params p = droid_params(n_poses, ht, wd, E, 0, 0, 0, 0.f, 0.f, 0);
+  return (int64_t)(carve(p, nullptr, nullptr) + droid_extra_bytes(E));
+}
+
+VIPE_EXPORT int vipe_ba(float* d_poses, float* d_disps, const float* d_intrinsics, const float* d_disps_sens,
+                        const float* d_targets, const float* d_weights, const float* d_eta, const int64_t* d_ii,
+                        const int64_t* d_jj, int n_poses, int ht, int wd, int E, int n_eta, int t0, int t1,
+                        int iterations, float lm, float ep, int motion_only, float* d_dx, float* d_dz,
+                        void* d_workspace, int64_t workspace_bytes, void* stream) {
+  VIPE_CHECK_ARG(d_poses && d_disps && d_intrinsics && d_disps_sens && d_eta && d_workspace && d_dx && d_dz);
+  VIPE_CHECK_ARG(n_poses > 0 && ht > 0 && wd > 0 && E >= 0 && iterations >= 0 && n_eta >= 0);
+  VIPE_CHECK_ARG(0 <= t0 && t0 <= t1 && t1 <= n_poses);
+  VIPE_CHECK_ARG(E == 0 || (d_targets && d_weights && d_ii && d_jj));
+  if (n_poses > 65535) return VIPE_EINVAL;
+  BAArgs a;
+  a.p = droid_params(n_poses, ht, wd, E, t0, t1, iterations, lm, ep, motion_only);
+  const size_t base = carve(a.p, (char*)d_workspace, &a.w);
+  if ((int64_t)(base + droid_extra_bytes(E)) > workspace_bytes) return VIPE_ENOSPACE;
+  int64_t* zeros = (int64_t*)((char*)d_workspace + base);
+  float* rig = (float*)((char*)d_workspace + base + align_up(8 * (size_t)(E + 1)));
+  hipStream_t s = as_stream(stream);
+  const float rig_id[7] = {0, 0, 0, 0, 0, 0, 1};
+  hipError_t e0 = hipMemsetAsync(zeros, 0, 8 * (size_t)(E + 1), s);
+  hipError_t e1 = hipMemcpyAsync(rig, rig_id, sizeof(rig_id), hipMemcpyHostToDevice, s);
+  const int64_t P = (int64_t)ht * wd;
+  hipError_t e2 = hipMemsetAsync(d_dx, 0, sizeof(float) * 6 * (size_t)(t1 - t0), s);
+  hipError_t e3 = hipMemsetAsync(d_dz, 0, sizeof(float) * (size_t)n_eta * P, s);
+  if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return VIPE_EINVAL;
+  a.poses = d_poses; a.disps = d_disps; a.intr = (float*)d_intrinsics; a.rig = rig;
+  a.sens = d_disps_sens; a.target = d_targets; a.weight = d_weights; a.eta = d_eta;
+  a.pi = d_ii; a.qi = zeros; a.pj = d_jj; a.qj = zeros; a.di = d_ii;
+  a.P = ht * wd; a.nF = n_poses; a.D = 0;
+  a.force_simple = getenv("VIPE_BA_ACCUM_SIMPLE") != nullptr;
+  a.droid = 1;
+  a.dz_out = d_dz;
+  if (iterations == 0 || t1 == t0) return VIPE_OK;
+  ba_sens_kernel<<<a.nF, 256, 0, s>>>(d_disps_sens, a.w.sens_sum, a.P);
+  ba_plan_kernel<<<1, 1024, 0, s>>>(a);
+  const int rc = run_iters<VIPE_CAM_PINHOLE, 0>(a, s);
+  if (rc != VIPE_OK) return rc;
+  hipError_t e4 = hipMemcpyAsync(d_dx, a.w.dx, sizeof(float) * 6 * (size_t)(t1 - t0), hipMemcpyDeviceToDevice, s);
+  return e4 == hipSuccess ? vipe_launch_status() : (int)e4;
 }
