@@ -841,3 +841,25 @@ def test_slam_ext_ba_droid_signature_against_restatement(case):
         assert np.abs(odz).max() > 1e-4
     else:
         assert np.all(disps.cpu().numpy() == g.disps)
+
+
+def test_altcorr_backward_is_adjoint_of_forward():
+    """`altcorr_backward` (altcorr_kernel.cu:140-264, 292-320; float32): the forward is bilinear in (fmap1, fmap2), so
+    <corr_grad, altcorr(f1 + e d1, f2 + e d2)>' at e = 0 must equal <g1, d1> + <g2, d2> (exactly, up to fp32 rounding)."""
+    from vipe_amd.ext import droid_net_ext
+
+    gen = torch.Generator().manual_seed(17)
+    B, H, W, C, N = 2, 8, 10, 64, 3
+    f1 = torch.randn(B, H, W, C, generator=gen).to(dev())
+    f2 = torch.randn(B, H, W, C, generator=gen).to(dev())
+    u, v = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
+    coords = (torch.from_numpy(np.stack([u, v], -1))[None, None] + 3 * torch.randn(B, N, H, W, 2, generator=gen)).to(dev()).contiguous()
+    cg = torch.randn(B, N, 49, H, W, generator=gen).to(dev())
+    g1, g2, gc = droid_net_ext.altcorr_backward(f1, f2, coords, cg, 3)
+    d1 = torch.randn(B, H, W, C, generator=gen).to(dev())
+    d2 = torch.randn(B, H, W, C, generator=gen).to(dev())
+    fwd = lambda a, b: droid_net_ext.altcorr_forward(a, b, coords, 3)[0]
+    lhs = (cg * (fwd(d1, f2) + fwd(f1, d2))).double().sum()  # directional derivative of a bilinear map
+    rhs = (g1 * d1).double().sum() + (g2 * d2).double().sum()
+    assert abs(float(lhs - rhs)) <= 1e-4 * max(1.0, abs(float(lhs)))
+    assert float(gc.abs().max()) == 0.0

@@ -56,6 +56,52 @@ __global__ __launch_bounds__(128) void altcorr_forward_kernel(const T* __restric
   for (int q = 0; q < RD * RD; ++q) o[(int64_t)q * P] = (T)acc[q];
 }
 
+// adjoint of altcorr_forward with respect to both feature maps (altcorr_kernel.cu:140-264): one wave per (b, n, pixel),
+// lanes over channels.  For each of the (2r+2)^2 tap positions the gradients of the up-to-four outputs that the tap
+// contributes to are folded with their bilinear weights into one scalar g; then grad_f1[p] += g f2[tap] (kept in
+// registers over the taps, one atomic per channel at the end because several n share fmap1[p]) and
+// grad_f2[tap] += g f1[p] (atomic).  coords receive no gradient, as in the reference.
+template <int R>
+__global__ __launch_bounds__(256) void altcorr_backward_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                               const float* __restrict__ coords,
+                                                               const float* __restrict__ cgrad, float* __restrict__ g1,
+                                                               float* __restrict__ g2, int H1, int W1, int H2, int W2,
+                                                               int N, int C, int64_t total) {
+  constexpr int RD = 2 * R + 1;
+  const int P = H1 * W1;
+  const int lane = threadIdx.x & 63;
+  for (int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); item < total; item += (int64_t)gridDim.x * 4) {
+    const int p = (int)(item % P);
+    const int n = (int)((item / P) % N);
+    const int b = (int)(item / ((int64_t)P * N));
+    const float2 c = reinterpret_cast<const float2*>(coords)[((int64_t)b * N + n) * P + p];
+    const float fx = floorf(c.x), fy = floorf(c.y);
+    const float dx = c.x - fx, dy = c.y - fy;
+    const int bx = (int)fx - R, by = (int)fy - R;
+    const float* cg = cgrad + (((int64_t)b * N + n) * RD * RD) * P + p;
+    const float* a = f1 + ((int64_t)b * P + p) * C;
+    float* ga = g1 + ((int64_t)b * P + p) * C;
+    for (int c0 = lane; c0 < C; c0 += 64) {
+      const float av = a[c0];
+      float acc1 = 0.0f;
+      for (int iy = 0; iy <= RD; ++iy)
+        for (int ix = 0; ix <= RD; ++ix) {
+          const int h2 = by + iy, w2 = bx + ix;
+          if (h2 < 0 || h2 >= H2 || w2 < 0 || w2 >= W2) continue;
+          float g = 0.0f;
+          if (iy > 0 && ix > 0) g += cg[(int64_t)((iy - 1) + RD * (ix - 1)) * P] * (dy * dx);
+          if (iy > 0 && ix < RD) g += cg[(int64_t)((iy - 1) + RD * ix) * P] * (dy * (1 - dx));
+          if (iy < RD && ix > 0) g += cg[(int64_t)(iy + RD * (ix - 1)) * P] * ((1 - dy) * dx);
+          if (iy < RD && ix < RD) g += cg[(int64_t)(iy + RD * ix) * P] * ((1 - dy) * (1 - dx));
+          const int64_t o2 = (((int64_t)b * H2 + h2) * W2 + w2) * C + c0;
+          acc1 += g * f2[o2];
+          atomicAdd(g2 + o2, g * av);
+        }
+      atomicAdd(ga + c0, acc1);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ scatter
 template <typename T>
 __device__ __forceinline__ void atomic_combine(T* addr, T v, int reduce);
@@ -247,9 +293,18 @@ VIPE_EXPORT int vipe_altcorr_forward(const void* d_fmap1, const void* d_fmap2, c
   return vipe_launch_status();
 }
 
-VIPE_EXPORT int vipe_altcorr_backward(const float*, const float*, const float*, const float*, float*, float*, int, int,
-                                      int, int, int, int, int, int, void*) {
-  return VIPE_EUNSUPPORTED;  // training only; the SLAM system runs under torch.no_grad (system.py:207)
+VIPE_EXPORT int vipe_altcorr_backward(const float* d_fmap1, const float* d_fmap2, const float* d_coords,
+                                      const float* d_corr_grad, float* d_fmap1_grad, float* d_fmap2_grad, int B, int H1,
+                                      int W1, int H2, int W2, int N, int C, int radius, void* stream) {
+  VIPE_CHECK_ARG(B >= 0 && N >= 0 && H1 > 0 && W1 > 0 && H2 > 0 && W2 > 0 && C > 0);
+  if (B == 0 || N == 0) return VIPE_OK;
+  VIPE_CHECK_ARG(d_fmap1 && d_fmap2 && d_coords && d_corr_grad && d_fmap1_grad && d_fmap2_grad);
+  if (radius != 3) return VIPE_EUNSUPPORTED;
+  const int64_t total = (int64_t)B * N * H1 * W1;
+  const int blocks = (int)std::min<int64_t>((total + 3) / 4, 256 * 16);
+  altcorr_backward_kernel<3><<<blocks, 256, 0, as_stream(stream)>>>(d_fmap1, d_fmap2, d_coords, d_corr_grad, d_fmap1_grad,
+                                                                    d_fmap2_grad, H1, W1, H2, W2, N, C, total);
+  return vipe_launch_status();
 }
 
 VIPE_EXPORT int vipe_scatter(const void* d_src, const int64_t* d_index, void* d_out, int64_t* d_arg_out, int64_t outer,
