@@ -66,7 +66,7 @@ def cpu_baseline(seconds_budget=20.0):
     from oracle import se3 as ose3
     from vipe_amd.synth import make_graph
 
-    n_sub = 16
+    n_sub = 32
     g = make_graph(n=n_sub, height=384, width=512, radius=3, seed=1234)
     E = len(g.ii)
     rng = np.random.default_rng(0)
