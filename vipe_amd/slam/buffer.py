@@ -79,10 +79,12 @@ class GraphBuffer:
         return tuple(x.reshape(-1).contiguous() for x in (pi, qi, di, pj, qj, dj))
 
     def bundle_adjustment(self, target, weight, disp_damping, ii, jj, t0, t1, n_iters, pose_damping, pose_ep,
-                          motion_only, limited_disp, optimize_intrinsics, optimize_rig_rotation, verbose=False):
-        """buffer.py:373-525, in place on self.poses / self.disps (/ self.intrinsics)."""
+                          motion_only, limited_disp, optimize_intrinsics, optimize_rig_rotation, verbose=False,
+                          plan=None):
+        """buffer.py:373-525, in place on self.poses / self.disps (/ self.intrinsics).  `plan` = (pi, qi, di, pj, qj)
+        of `expand_edge_multiview(ii, jj)` when the caller already holds it (the reference re-expands every call)."""
         assert t0 <= t1
-        pi, qi, di, pj, qj, _ = self.expand_edge_multiview(ii, jj)
+        pi, qi, di, pj, qj = plan if plan is not None else self.expand_edge_multiview(ii, jj)[:5]
         n_poses = max(self.n_frames, int(t1))
         return slam_ext.dense_ba(
             self.poses, self.flattened_disps, self.flattened_disps_sens, self.intrinsics, self.rig,

@@ -244,7 +244,7 @@ class FactorGraph:
         if eng.backend == "hip":
             self.net_n, dw, eta, _ = eng.forward_nhwc(self.net_n, self.xbuf, corr, motn, ix=P["dix"], n_src=P["n_src"],
                                                       net_out=self._net_spare(), csr=P["csr"], pgate=self.pgate)
-            delta, weight = dw[None, ..., 0:2], dw[None, ..., 2:4].clone()
+            delta, weight = dw[None, ..., 0:2], dw[None, ..., 2:4]
         else:  # A/B baseline: reference-shaped NCHW call
             f_net, delta, weight, eta, _ = eng.forward(
                 self.net_n.permute(0, 3, 1, 2)[None], self.xbuf[..., 0:128].permute(0, 3, 1, 2)[None],
@@ -252,9 +252,9 @@ class FactorGraph:
                 skip_upmask=True, n_src=P["n_src"])
             self.net_n = f_net[0].permute(0, 2, 3, 1).contiguous()
             delta, weight, eta = delta.float(), weight.float(), eta[0]
-        weight[:, buf.masks[P["pi"], P["qi"]]] = 0.0  # factor_graph.py:272
+        # factor_graph.py:272 (`weight[:, masks[pi, qi]] = 0`) without the host sync of a boolean-mask assignment
+        self.weight = weight.masked_fill(buf.masks[P["pi"], P["qi"]][None, ..., None], 0.0)
         self.target = coords1[None] + delta
-        self.weight = weight
         self.damping[P["du"]] = eta
         if use_inactive:
             m = (self.ii_inac >= t0 - 3) & (self.jj_inac >= t0 - 3)
@@ -263,11 +263,14 @@ class FactorGraph:
             exp_m = m.view(-1, 1).repeat(1, buf.n_views).view(-1)
             target = torch.cat([self.target_inac[:, exp_m], self.target], 1)
             weight = torch.cat([self.weight_inac[:, exp_m], self.weight], 1)
+            plan = None
         else:
             ii, jj, target, weight = self.ii, self.jj, self.target, self.weight
+            plan = (P["pi"], P["qi"], P["di"], P["pj"], P["qj"])  # cached expand_edge_multiview of the edge set
         E = target.shape[1]
         buf.bundle_adjustment(target.view(E, -1, 2), weight.view(E, -1, 2), self.damping, ii, jj, t0,
-                              t1 if not fixed_motion else t0, itrs, 1e-3, 0.1, motion_only, limited_disp, False, False)
+                              t1 if not fixed_motion else t0, itrs, 1e-3, 0.1, motion_only, limited_disp, False, False,
+                              plan=plan)
         self.age += 1
 
     @torch.no_grad()
