@@ -863,3 +863,23 @@ def test_altcorr_backward_is_adjoint_of_forward():
     rhs = (g1 * d1).double().sum() + (g2 * d2).double().sum()
     assert abs(float(lhs - rhs)) <= 1e-4 * max(1.0, abs(float(lhs)))
     assert float(gc.abs().max()) == 0.0
+
+
+def test_dense_ba_medium_degree_uses_large_mfma_accumulate():
+    """Source frames with 7..14 terms (radius-5 graph: degree 10) take the large-LDS instantiation of the matrix-core
+    accumulate kernel; the reduced system is wider than the LDS band solver's limit, so the global-memory Cholesky
+    solves it.  Against the fp64 oracle, 1e-4 (incl. focal optimisation)."""
+    g = make_graph(n=14, height=96, width=128, radius=5, seed=88)
+    deg = np.bincount(g.ii).max()
+    assert 7 <= deg <= 14
+    bk = dict(t0=1, t1=14, n_iters=2, pose_damping=1e-3, pose_ep=0.1, motion_only=False, limited_disp=False,
+              optimize_intrinsics=True)
+    p, d, k, info = run_hip_ba(g, g.intrinsics, "pinhole", bk)
+    E = len(g.ii)
+    op, od, ok_, _ = oba.bundle_adjustment(g.poses, g.disps[:, None], g.disps_sens[:, None], g.intrinsics,
+                                           ose3.se3_identity(1), g.target.reshape(E, -1, 2), g.weight.reshape(E, -1, 2),
+                                           g.eta[:, None], g.ii, g.jj, **bk)
+    assert info[2] == 0
+    assert np.abs(p - op).max() <= 1e-4 * max(1.0, np.abs(op).max())
+    assert np.abs(d - od[:, 0]).max() <= 1e-4 * np.abs(od).max()
+    assert np.abs(k - ok_).max() <= 1e-4 * np.abs(ok_).max()

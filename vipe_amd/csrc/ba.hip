@@ -340,7 +340,7 @@ __global__ __launch_bounds__(TILE) void ba_accum_kernel(BAArgs a) {
   constexpr int NRED = NT > NK ? NT : NK;
   const vipe_ba_params& prm = a.p;
   const BAWs& w = a.w;
-  if (!a.force_simple && w.info[6] <= AM_DMAX) return;  // the matrix-core kernel owns this graph
+  if (!a.force_simple) return;  // A/B and debugging only (VIPE_BA_ACCUM_SIMPLE): the matrix-core kernels own every graph
   const int k = blockIdx.y;
   const int beg = w.rowptr[k], end = w.rowptr[k + 1];
   if (beg == end) return;
@@ -1045,6 +1045,389 @@ __global__ __launch_bounds__(TILE) void ba_accum_mfma_kernel(BAArgs a) {
   BA_STAMP(6);
 }
 
+// ---- general accumulate (any number of terms per source frame): the same walk with matrix-core Gram reductions, the
+// terms staged 8 at a time, WITHOUT the Schur complement - that is formed afterwards by ba_schur_kernel from the E rows
+// this kernel leaves in the workspace (E_kk, E_j, E_f, w, C).  LDS per workgroup is independent of the degree (42 KB).
+constexpr int WK_CH = 8;
+constexpr size_t walk_lds() {
+  return sizeof(float) * (NWAVE * 16 * AM_P1 + WK_CH * 256 + 64) + WK_CH * sizeof(TermGeomM);
+}
+
+template <int CAM, int F>
+__global__ __launch_bounds__(TILE) void ba_walk_kernel(BAArgs a) {
+  constexpr int WBUF = 16 * AM_P1;
+  constexpr int FF = F > 0 ? F : 1;
+  constexpr int RPT = F > 0 ? 16 : 8;  // R1 rows per term: 6 J, r, F Jf (padded)
+  constexpr int TPT = 16 / RPT;        // terms per R1 tile
+  const vipe_ba_params& prm = a.p;
+  const BAWs& w = a.w;
+  if (a.force_simple || w.info[6] <= AM_DMAX) return;  // low-degree graphs: the fused kernel
+  const int k = blockIdx.y;
+  const int beg = w.rowptr[k], end = w.rowptr[k + 1];
+  if (beg == end) return;
+  const int deg_all = end - beg;
+  const int P = a.P, V = prm.n_views, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p_raw = blockIdx.x * TILE + tid;
+  const bool inb = p_raw < P;
+  const int p = inb ? p_raw : P - 1;
+  const int flags = w.fflags[k];
+  const bool dfree = flags & 2;
+  const int pose_i = k / V, qi = k % V;
+  const int si = w.pose_slot[pose_i];
+  const bool fi = si >= 0;
+  const int n_free = w.info[0], nrow = w.info[3];
+  const int foff = 6 * n_free;
+
+  extern __shared__ __align__(16) float am_smem[];
+  float* wbuf = am_smem + wave * WBUF;        // wave-private R1 tile
+  float* acc1 = am_smem + NWAVE * WBUF;       // [WK_CH][16][16] per-term Gram accumulators of the current chunk
+  float* accI = acc1 + WK_CH * 256;           // [64] frame level: H_ii 36, v_i 6, H_if 6F, H_ff 3, v_f F
+  TermGeomM* tg = reinterpret_cast<TermGeomM*>(accI + 64);
+  if (tid < 64) accI[tid] = 0.0f;
+
+  const cam::Intr Ii = cam::load_scaled(a.intr + qi * (4 + a.D), a.D, 1.0f / prm.intr_factor);
+  const float u = (float)(p % prm.wd), v = (float)(p / prm.wd);
+  const float d = a.disps[(int64_t)k * P + p];
+  float X0, Y0, dX0[FF], dY0[FF];
+  cam::iproj<CAM, F>(Ii, u, v, X0, Y0, dX0, dY0);
+  float C = 0.f, wz = 0.f, Ei[6] = {0, 0, 0, 0, 0, 0}, Efr[FF] = {};
+  const int l16 = lane & 15, kq = lane >> 4;
+
+  for (int cb = 0; cb < deg_all; cb += WK_CH) {
+    const int deg = min(WK_CH, deg_all - cb);  // terms of this chunk
+    __syncthreads();                            // the previous chunk's flush is done with acc1 / tg
+    for (int i = tid; i < WK_CH * 256; i += TILE) acc1[i] = 0.0f;
+    if (tid < deg) {
+      TermGeomM m;
+      TermGeom& g = m.g;
+      term_setup(a, w.order[beg + cb + tid], g);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        float ec[6] = {0, 0, 0, 0, 0, 0}, col[6];
+        ec[c] = 1.0f;
+        adjT_apply(g.G, ec, col);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) m.Mi[r * 6 + c] = (g.merge == 1 && r == c ? 1.0f : 0.0f) - col[r];
+      }
+      tg[tid] = m;
+    }
+    __syncthreads();
+
+    // target / weight of the next tile's terms are fetched while the current tile is computed (the walk is otherwise
+    // a chain of dependent global-load latencies: measured 5 us per tile)
+    float2 nx_t[TPT], nx_w[TPT];
+    auto prefetch = [&](int t0) {
+#pragma unroll
+      for (int uu = 0; uu < TPT; ++uu) {
+        const int t = min(t0 + uu, deg - 1);
+        load_tw(a, tg[t].g.e, p, P, nx_t[uu], nx_w[uu]);
+      }
+    };
+    prefetch(0);
+    for (int t0 = 0; t0 < deg; t0 += TPT) {
+      float2 cur_t[TPT], cur_w[TPT];
+#pragma unroll
+      for (int uu = 0; uu < TPT; ++uu) { cur_t[uu] = nx_t[uu]; cur_w[uu] = nx_w[uu]; }
+      if (t0 + TPT < deg) prefetch(t0 + TPT);
+#pragma unroll
+      for (int uu = 0; uu < TPT; ++uu) {
+        const int t = t0 + uu;
+        if (t >= deg) break;  // workgroup-uniform
+        const TermGeom& G = tg[t].g;
+        const int e = G.e;
+        const float X = G.T.R[0] * X0 + G.T.R[1] * Y0 + G.T.R[2] + G.T.t[0] * d;
+        const float Y = G.T.R[3] * X0 + G.T.R[4] * Y0 + G.T.R[5] + G.T.t[1] * d;
+        const float Z = G.T.R[6] * X0 + G.T.R[7] * Y0 + G.T.R[8] + G.T.t[2] * d;
+        float x, y, Jp[2][3], Jfj[2][FF];
+        cam::proj<CAM, true, F>(G.Ij, X, Y, Z, x, y, Jp, Jfj);
+        const float2 tgt = cur_t[uu], wg = cur_w[uu];
+        const float val = valid_weight(a, Z, inb);  // geom.py:263, buffer.py:413
+        const float wd2[2] = {val * wg.x, val * wg.y};                     // weights of the disparity system
+        const float wc[2] = {G.merge == 2 ? 0.0f : wd2[0], G.merge == 2 ? 0.0f : wd2[1]};  // ... of the pose blocks
+        const float rc[2] = {x - tgt.x, y - tgt.y};
+        float Ja[3][6] = {{d, 0, 0, 0, Z, -Y}, {0, d, 0, -Z, 0, X}, {0, 0, d, Y, -X, 0}};
+        if (G.rig_adj) {
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            float tmp[6];
+            adjT_apply(G.Rr, Ja[r], tmp);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) Ja[r][q] = tmp[q];
+          }
+        }
+        const bool fj = G.sj >= 0;
+        float Ejv[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          float Jj[6], Ji[6], Jf[FF];
+#pragma unroll
+          for (int q = 0; q < 6; ++q) Jj[q] = Jp[c][0] * Ja[0][q] + Jp[c][1] * Ja[1][q] + Jp[c][2] * Ja[2][q];
+          const float Jz = Jp[c][0] * G.T.t[0] + Jp[c][1] * G.T.t[1] + Jp[c][2] * G.T.t[2];
+          if constexpr (F > 0) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+              const float ax = G.T.R[0] * dX0[f] + G.T.R[1] * dY0[f];
+              const float ay = G.T.R[3] * dX0[f] + G.T.R[4] * dY0[f];
+              const float az = G.T.R[6] * dX0[f] + G.T.R[7] * dY0[f];
+              Jf[f] = (Jp[c][0] * ax + Jp[c][1] * ay + Jp[c][2] * az + Jfj[c][f]) * (1.0f / prm.intr_factor);
+            }
+          }
+          // R1 rows of this term and component
+          const float sw = __builtin_amdgcn_sqrtf(wc[c]);  // v_sqrt_f32 (1 ulp): only splits w between the Gram factors
+          float* col = wbuf + (uu * RPT) * AM_P1 + c * 64 + lane;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) col[q * AM_P1] = Jj[q] * sw;
+          col[6 * AM_P1] = rc[c] * sw;
+          if constexpr (F > 0) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) col[(7 + f) * AM_P1] = Jf[f] * sw;
+          }
+          // per-pixel disparity quantities
+          if (dfree) {
+            const float wJz = wc[c] * Jz;
+            C += wd2[c] * Jz * Jz;
+            wz -= wd2[c] * Jz * rc[c];
+            float tmp[6];
+            adjT_apply(G.G, Jj, tmp);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+              Ji[q] = (G.merge == 1 ? Jj[q] : 0.0f) - tmp[q];
+              Ei[q] += Ji[q] * wJz;
+            }
+            if constexpr (F > 0) {
+#pragma unroll
+              for (int f = 0; f < F; ++f) Efr[f] += Jf[f] * wJz;
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) Ejv[q] += Jj[q] * wJz;
+          }
+        }
+        if (dfree && fj && inb) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) w.Ej[((int64_t)e * 6 + q) * P + p] = Ejv[q];
+        }
+      }
+      // ---- Gram matrix of the tile over this wave's 64 pixels x 2 components
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      float4m g4 = {0.f, 0.f, 0.f, 0.f};
+      const float* arow = wbuf + l16 * AM_P1 + kq;
+#pragma unroll 8
+      for (int s = 0; s < 32; ++s) {
+        const float av = arow[4 * s];
+        g4 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, av, g4, 0, 0, 0);
+      }
+      // D[row = 4 kq + r][col = l16]: keep the diagonal RPT x RPT blocks
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * kq + r;
+        const int tb = row / RPT;
+        if (l16 / RPT == tb && t0 + tb < deg) atomicAdd(&acc1[(t0 + tb) * 256 + (row % RPT) * 16 + (l16 % RPT)], g4[r]);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    __syncthreads();
+    // ---- per-term blocks from the Gram sums (one wave per term)
+    for (int t = wave; t < deg; t += NWAVE) {
+      const TermGeomM& TG = tg[t];
+      const float* Gm = acc1 + t * 256;  // [16][16]: rows/cols 0..5 J, 6 r, 7.. Jf
+      const float* Mi = TG.Mi;
+      const int sj = TG.g.sj;
+      const bool fj = sj >= 0;
+      const int bj = 6 * sj, bi = 6 * si;
+      float* T1 = wbuf;  // [6][6 + F] scratch: Mi Hjj | Mi Hjf
+      if (lane < 36) {
+        const int r = lane / 6, c = lane % 6;
+        const float hjj = Gm[r * 16 + c];
+        if (fj && r >= c) {
+          s_add(w, bj + r, bj + c, (double)hjj);
+          if (r == c) atomicAdd(&w.Hd[bj + r], (double)hjj);
+        }
+        float t1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) t1 += Mi[r * 6 + q] * Gm[q * 16 + c];
+        T1[r * 8 + c] = t1;
+        if (fi && fj) s_add(w, bi + r, bj + c, (double)t1);  // H_ij = Mi H_jj
+      } else if (lane < 42) {
+        const int q = lane - 36;
+        const float vjn = Gm[q * 16 + 6];  // sum w J_q r  (v_j = -that)
+        if (fj) atomicAdd(&w.S[(int64_t)nrow * w.ld + bj + q], -(double)vjn);
+        if (fi) {
+          float vin = 0.f;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) vin += Mi[q * 6 + c] * Gm[c * 16 + 6];
+          atomicAdd(&accI[36 + q], -vin);
+        }
+      } else if (F > 0 && lane < 42 + 6 * F) {
+        const int q = (lane - 42) / FF, f = (lane - 42) % FF;
+        const float hjf = Gm[q * 16 + 7 + f];
+        if (fj) s_add(w, foff + f, bj + q, (double)hjf);
+        if (fi) {
+          float hif = 0.f;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) hif += Mi[q * 6 + c] * Gm[c * 16 + 7 + f];
+          atomicAdd(&accI[42 + q * FF + f], hif);
+        }
+      } else if (F > 0 && lane < 42 + 6 * F + F * F) {
+        const int i2 = lane - 42 - 6 * F, f = i2 / FF, f2 = i2 % FF;
+        if (f >= f2) atomicAdd(&accI[42 + 6 * FF + f * FF + f2], Gm[(7 + f) * 16 + 7 + f2]);
+      } else if (F > 0 && lane < 42 + 6 * F + F * F + F) {
+        const int f = lane - 42 - 6 * F - F * F;
+        atomicAdd(&accI[42 + 6 * FF + FF * FF + f], -Gm[(7 + f) * 16 + 6]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (fi && lane < 36) {
+        const int r = lane / 6, c = lane % 6;
+        float hii = 0.f;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) hii += T1[r * 8 + q] * Mi[c * 6 + q];
+        atomicAdd(&accI[r * 6 + c], hii);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+
+  }
+  __syncthreads();
+
+  // ---- frame level: H_ii, v_i, H_if, H_ff, v_f
+  {
+    const int bi = 6 * si;
+    if (tid < 36) {
+      const int r = tid / 6, c = tid % 6;
+      if (fi && r >= c) {
+        const double s = (double)accI[r * 6 + c];
+        s_add(w, bi + r, bi + c, s);
+        if (r == c) atomicAdd(&w.Hd[bi + r], s);
+      }
+    } else if (tid < 42) {
+      if (fi) atomicAdd(&w.S[(int64_t)nrow * w.ld + bi + (tid - 36)], (double)accI[tid]);
+    } else if (F > 0 && tid < 42 + 6 * F) {
+      const int q = (tid - 42) / FF, f = (tid - 42) % FF;
+      if (fi) s_add(w, foff + f, bi + q, (double)accI[tid]);
+    } else if (F > 0 && tid < 42 + 6 * F + F * F) {
+      const int i2 = tid - 42 - 6 * F, f = i2 / FF, f2 = i2 % FF;
+      if (f >= f2) {
+        const double s = (double)accI[tid];
+        s_add(w, foff + f, foff + f2, s);
+        if (f == f2) atomicAdd(&w.Hd[foff + f], s);
+      }
+    } else if (F > 0 && tid < 42 + 6 * F + F * F + F) {
+      atomicAdd(&w.S[(int64_t)nrow * w.ld + foff + (tid - 42 - 6 * F - F * F)], (double)accI[tid]);
+    }
+  }
+  // ---- finish the disparity block of this pixel: sensor prior, damping (terms.py:258-268, buffer.py:482-489)
+  if (dfree) {
+    const int64_t kp = (int64_t)k * P + p;
+    finish_disp(a, k, p, P, flags, d, C, wz);
+    if (inb) {
+      w.C[kp] = C;
+      w.wv[kp] = wz;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) w.Ekk[((int64_t)k * 6 + q) * P + p] = Ei[q];
+      if constexpr (F > 0) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) w.Ef[((int64_t)k * 2 + f) * P + p] = Efr[f];
+      }
+    }
+  }
+}
+
+// Schur complement of one source frame from the E rows in the workspace (general path, after ba_walk_kernel):
+// rows = sqrt(Q) * [E_kk (pose i); E_j of every term; E_f; w], Gram over all P pixels, one workgroup per 16 x 16 tile
+// pair of the lower triangle.  Each wave takes every fourth 64-pixel chunk: the two row tiles are staged in LDS
+// (coalesced 256-byte row segments), 16 v_mfma_f32_16x16x4_f32 per chunk, partial tiles summed through LDS.
+constexpr int SC_GRID = 24;  // tile pairs processed in parallel per frame (the kernel strides over the rest)
+
+template <int F>
+__global__ __launch_bounds__(TILE) void ba_schur_kernel(BAArgs a) {
+  const BAWs& w = a.w;
+  if (a.force_simple || w.info[6] <= AM_DMAX) return;
+  const int k = blockIdx.y;
+  const int flags = w.fflags[k];
+  const int beg = w.rowptr[k], end = w.rowptr[k + 1];
+  if (!(flags & 2) || beg == end) return;
+  const int deg = end - beg, P = a.P, V = a.p.n_views;
+  const int NR = 6 * (deg + 1) + F + 1, RT = (NR + 15) >> 4, npairs = RT * (RT + 1) / 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+  const int si = w.pose_slot[k / V];
+  const int n_free = w.info[0], nrow = w.info[3], foff = 6 * n_free;
+  __shared__ float tile[NWAVE][2][16 * AM_P2];
+  __shared__ float red[NWAVE][256];
+  __shared__ const float* rowp[32];
+  __shared__ int rowg[32];
+  // source row r of the stacked E matrix: pointer to its P values (or null) and its index in the reduced system
+  auto resolve = [&](int r, const float*& ptr, int& g) {
+    ptr = nullptr; g = -1;
+    if (r >= NR) return;
+    if (r == NR - 1) { ptr = w.wv + (int64_t)k * P; g = -2; return; }
+    if (r >= 6 * (deg + 1)) { const int f = r - 6 * (deg + 1); ptr = w.Ef + ((int64_t)k * 2 + f) * P; g = foff + f; return; }
+    const int m = r / 6, q = r % 6;
+    if (m == 0) {
+      if (si >= 0) { ptr = w.Ekk + ((int64_t)k * 6 + q) * P; g = 6 * si + q; }
+    } else {
+      const int e = w.order[beg + m - 1];
+      const int pj = (int)a.pj[e];
+      const int sj = ((int)a.pi[e] == pj) ? -1 : w.pose_slot[pj];
+      if (sj >= 0) { ptr = w.Ej + (int64_t)e * 6 * P + (int64_t)q * P; g = 6 * sj + q; }
+    }
+  };
+  const float* Ck = w.C + (int64_t)k * P;
+  const int nchunks = (P + 63) / 64;
+  for (int pid = blockIdx.x; pid < npairs; pid += gridDim.x) {
+    int ta = 0;
+    while ((ta + 1) * (ta + 2) / 2 <= pid) ++ta;
+    const int tb = pid - ta * (ta + 1) / 2;
+    __syncthreads();
+    if (tid < 32) {
+      const float* ptr; int g;
+      resolve(16 * (tid < 16 ? ta : tb) + (tid & 15), ptr, g);
+      rowp[tid] = ptr; rowg[tid] = g;
+    }
+    __syncthreads();
+    float4m g4 = {0.f, 0.f, 0.f, 0.f};
+    for (int ch = wave; ch < nchunks; ch += NWAVE) {
+      const int px = ch * 64 + lane;
+      const bool ok = px < P;
+      const float sq = ok ? __builtin_amdgcn_rsqf(Ck[px]) : 0.0f;
+      float va[16], vb[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* pa = rowp[r];
+        const float* pb = rowp[16 + r];
+        va[r] = (ok && pa) ? pa[px] * sq : 0.0f;
+        vb[r] = (ok && pb) ? pb[px] * sq : 0.0f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        tile[wave][0][r * AM_P2 + lane] = va[r];
+        tile[wave][1][r * AM_P2 + lane] = vb[r];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const float* ar = &tile[wave][0][l16 * AM_P2 + kq];
+      const float* br = &tile[wave][1][l16 * AM_P2 + kq];
+#pragma unroll 8
+      for (int s2 = 0; s2 < 16; ++s2) g4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[4 * s2], br[4 * s2], g4, 0, 0, 0);
+      __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][(4 * kq + r) * 16 + l16] = g4[r];
+    __syncthreads();
+    {
+      const float val = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+      const int ra = tid >> 4, cb = tid & 15;
+      const int row = 16 * ta + ra, cc = 16 * tb + cb;
+      const int gr = rowg[ra], gc = rowg[16 + cb];
+      if (row < NR && cc <= row && cc != NR - 1 && gc >= 0) {
+        if (row == NR - 1) atomicAdd(&w.S[(int64_t)nrow * w.ld + gc], -(double)val);
+        else if (gr >= 0) s_add(w, gr, gc, -(double)val);
+      }
+    }
+  }
+}
+
 // 1/sqrt(x) in fp64: hardware estimate + 2 Newton steps (avoids the long sqrt / divide sequences on the
 // factorisation's critical path)
 __device__ __forceinline__ double rsqrt_nr(double x) {
@@ -1729,12 +2112,15 @@ int run_iters(const BAArgs& a, hipStream_t s) {
     attr_set = true;
   }
   (void)hipFuncSetAttribute((const void*)ba_accum_mfma_kernel<CAM, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_mfma_lds());
+  (void)hipFuncSetAttribute((const void*)ba_walk_kernel<CAM, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds());
   for (int it = 0; it < a.p.n_iters; ++it) {
     hipError_t e1 = hipMemsetAsync(a.w.S, 0, sbytes, s);
     hipError_t e2 = hipMemsetAsync(a.w.Hd, 0, sizeof(double) * nmax, s);
     if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
     ba_accum_mfma_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, accum_mfma_lds(), s>>>(a);
-    ba_accum_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
+    ba_walk_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, walk_lds(), s>>>(a);
+    ba_schur_kernel<F><<<dim3(SC_GRID, a.nF), TILE, 0, s>>>(a);
+    if (a.force_simple) ba_accum_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
     ba_solve_band_kernel<<<1, BAND_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)));
     ba_solve_kernel<<<1, SOLVE_T, solve_lds, s>>>(a, panel_cap, getenv("VIPE_BA_DEBUG_TIMING") ? (long long*)(a.w.Hd + nmax) : nullptr);
     if (!a.p.motion_only) ba_retract_kernel<F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
