@@ -340,7 +340,7 @@ __global__ __launch_bounds__(TILE) void ba_accum_kernel(BAArgs a) {
   constexpr int NRED = NT > NK ? NT : NK;
   const vipe_ba_params& prm = a.p;
   const BAWs& w = a.w;
-  if (!a.force_simple) return;  // A/B and debugging only (VIPE_BA_ACCUM_SIMPLE): the matrix-core kernels own every graph
+  if (a.force_simple != 1) return;  // A/B and debugging only (VIPE_BA_ACCUM_SIMPLE): the matrix-core kernels own every graph
   const int k = blockIdx.y;
   const int beg = w.rowptr[k], end = w.rowptr[k + 1];
   if (beg == end) return;
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(TILE) void ba_accum_mfma_kernel(BAArgs a) {
   constexpr int TPT = 16 / RPT;        // terms per R1 tile
   const vipe_ba_params& prm = a.p;
   const BAWs& w = a.w;
-  if (a.force_simple || w.info[6] > AM_DMAX) return;
+  if (a.force_simple || w.info[6] > AM_DMAX) return;  // force_simple: 1 = shuffle kernel, 2 = general walk + Schur
   const int k = blockIdx.y;
   const int beg = w.rowptr[k], end = w.rowptr[k + 1];
   if (beg == end) return;
@@ -1061,7 +1061,7 @@ __global__ __launch_bounds__(TILE) void ba_walk_kernel(BAArgs a) {
   constexpr int TPT = 16 / RPT;        // terms per R1 tile
   const vipe_ba_params& prm = a.p;
   const BAWs& w = a.w;
-  if (a.force_simple || w.info[6] <= AM_DMAX) return;  // low-degree graphs: the fused kernel
+  if (a.force_simple == 1 || (a.force_simple == 0 && w.info[6] <= AM_DMAX)) return;  // low-degree graphs: the fused kernel
   const int k = blockIdx.y;
   const int beg = w.rowptr[k], end = w.rowptr[k + 1];
   if (beg == end) return;
@@ -1343,7 +1343,7 @@ constexpr int SC_GRID = 24;  // tile pairs processed in parallel per frame (the 
 template <int F>
 __global__ __launch_bounds__(TILE) void ba_schur_kernel(BAArgs a) {
   const BAWs& w = a.w;
-  if (a.force_simple || w.info[6] <= AM_DMAX) return;
+  if (a.force_simple == 1 || (a.force_simple == 0 && w.info[6] <= AM_DMAX)) return;
   const int k = blockIdx.y;
   const int flags = w.fflags[k];
   const int beg = w.rowptr[k], end = w.rowptr[k + 1];
@@ -2120,7 +2120,7 @@ int run_iters(const BAArgs& a, hipStream_t s) {
     ba_accum_mfma_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, accum_mfma_lds(), s>>>(a);
     ba_walk_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, walk_lds(), s>>>(a);
     ba_schur_kernel<F><<<dim3(SC_GRID, a.nF), TILE, 0, s>>>(a);
-    if (a.force_simple) ba_accum_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
+    if (a.force_simple == 1) ba_accum_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
     ba_solve_band_kernel<<<1, BAND_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)));
     ba_solve_kernel<<<1, SOLVE_T, solve_lds, s>>>(a, panel_cap, getenv("VIPE_BA_DEBUG_TIMING") ? (long long*)(a.w.Hd + nmax) : nullptr);
     if (!a.p.motion_only) ba_retract_kernel<F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
@@ -2164,7 +2164,7 @@ VIPE_EXPORT int vipe_dense_ba(const vipe_ba_params* p, float* d_poses, float* d_
   a.P = p->ht * p->wd;
   a.nF = p->n_poses * p->n_views;
   a.D = p->camera == VIPE_CAM_MEI ? 1 : 0;
-  a.force_simple = getenv("VIPE_BA_ACCUM_SIMPLE") != nullptr;
+  a.force_simple = getenv("VIPE_BA_ACCUM_SIMPLE") ? 1 : (getenv("VIPE_BA_ACCUM_GENERAL") ? 2 : 0);
   a.droid = 0;
   a.dz_out = nullptr;
   hipStream_t s = as_stream(stream);
@@ -2235,7 +2235,7 @@ VIPE_EXPORT int vipe_ba(float* d_poses, float* d_disps, const float* d_intrinsic
   a.sens = d_disps_sens; a.target = d_targets; a.weight = d_weights; a.eta = d_eta;
   a.pi = d_ii; a.qi = zeros; a.pj = d_jj; a.qj = zeros; a.di = d_ii;
   a.P = ht * wd; a.nF = n_poses; a.D = 0;
-  a.force_simple = getenv("VIPE_BA_ACCUM_SIMPLE") != nullptr;
+  a.force_simple = getenv("VIPE_BA_ACCUM_SIMPLE") ? 1 : (getenv("VIPE_BA_ACCUM_GENERAL") ? 2 : 0);
   a.droid = 1;
   a.dz_out = d_dz;
   if (iterations == 0 || t1 == t0) return VIPE_OK;
