@@ -883,3 +883,39 @@ def test_dense_ba_medium_degree_uses_large_mfma_accumulate():
     assert np.abs(p - op).max() <= 1e-4 * max(1.0, np.abs(op).max())
     assert np.abs(d - od[:, 0]).max() <= 1e-4 * np.abs(od).max()
     assert np.abs(k - ok_).max() <= 1e-4 * np.abs(ok_).max()
+
+
+def test_frontend_mirror_runs_and_keeps_graph_state_consistent():
+    """`SLAMFrontend` (frontend.py:78-167 mirror) on 14 synthetic keyframes of a 128x128 clip: initialisation after the
+    warm-up, proximity edges, update iterations with inactive edges, pose extrapolation.  Checks the bookkeeping
+    invariants the reference's tensors obey (one volume / hidden state / target per edge and view, ages advance, the
+    window holds at most max_factors edges after a removal round) and that the state stays finite."""
+    from vipe_amd.slam.buffer import GraphBuffer
+    from vipe_amd.slam.frontend import FrontendArgs, SLAMFrontend
+    from vipe_amd.slam.networks import UpdateModule
+
+    torch.manual_seed(0)
+    um = UpdateModule().eval()
+    buf = GraphBuffer(128, 128, buffer_size=24, device=dev())
+    buf.intrinsics[:] = torch.tensor([115.0, 115.0, 64.0, 64.0], device=dev())
+    fe = SLAMFrontend(um, buf, FrontendArgs(keyframe_thresh=0.0), dev())
+    gen = torch.Generator().manual_seed(7)
+    for t in range(14):
+        buf.fmaps[t, 0] = torch.randn(128, 16, 16, generator=gen).half().to(dev())
+        buf.nets[t, 0] = torch.randn(128, 16, 16, generator=gen).tanh().half().to(dev())
+        buf.inps[t, 0] = torch.randn(128, 16, 16, generator=gen).relu().half().to(dev())
+        if t < 8:
+            buf.poses[t, 0] = 0.05 * t
+            buf.disps[t, 0] = (1.0 / (1.0 + 4.0 * torch.rand(16, 16, generator=gen))).to(dev())
+        buf.n_frames += 1
+        fe.run()
+    g = fe.graph
+    E = int(g.ii.numel())
+    assert fe.is_initialized and fe.t1 == 14 and fe.n_updates == 8 + 6 * 6
+    assert 0 < E <= 48 + 2 * 3 and g.jj.numel() == E and g.age.numel() == E
+    assert g.corr.corr_pyramid[0].shape[0] == E and g.net_n.shape[0] == E and g.xbuf.shape[0] == E
+    assert g.target.shape[1] == E and g.weight.shape[1] == E
+    assert g.ii_inac.numel() == g.target_inac.shape[1] and g.ii_inac.numel() > 0
+    assert int(g.age.max()) >= 6 and int(g.ii.max()) == 13
+    assert bool(torch.isfinite(buf.poses[:15]).all()) and bool(torch.isfinite(buf.disps[:15]).all())
+    assert bool((buf.disps[:14] >= 1e-3).all())
