@@ -919,3 +919,38 @@ def test_frontend_mirror_runs_and_keeps_graph_state_consistent():
     assert int(g.age.max()) >= 6 and int(g.ii.max()) == 13
     assert bool(torch.isfinite(buf.poses[:15]).all()) and bool(torch.isfinite(buf.disps[:15]).all())
     assert bool((buf.disps[:14] >= 1e-3).all())
+
+
+def test_update_batch_volume_path_matches_altcorr_path(monkeypatch):
+    """Hot loop B (factor_graph.py:316-394): on 288 GB parts the backend builds the per-chunk correlation volume and
+    uses the fused lookup instead of the volume-free AltCorrBlock.  Same graph through both paths: the correlation
+    features differ only by fp16 rounding of the volume (AltCorr accumulates the same dot products in fp32), so targets
+    agree to a few hundredths of a pixel and the BA result to 1e-3."""
+    from vipe_amd.slam.buffer import GraphBuffer
+    from vipe_amd.slam.factor_graph import FactorGraph
+    from vipe_amd.slam.networks import UpdateModule
+
+    def run(altcorr):
+        if altcorr:
+            monkeypatch.setenv("VIPE_AMD_BACKEND_ALTCORR", "1")
+        else:
+            monkeypatch.delenv("VIPE_AMD_BACKEND_ALTCORR", raising=False)
+        g = make_graph(n=4, height=64, width=512, radius=2, seed=52)  # 8 x 64 grid
+        buf = GraphBuffer(64, 512, buffer_size=6, device=dev())
+        buf.n_frames = 4
+        buf.poses[:4], buf.disps[:4, 0], buf.intrinsics[:] = T(g.poses), T(g.disps), T(g.intrinsics)
+        gen = torch.Generator().manual_seed(52)
+        buf.fmaps[:4, 0] = torch.randn(4, 128, 8, 64, generator=gen).half().to(dev())
+        buf.nets[:4, 0] = torch.randn(4, 128, 8, 64, generator=gen).tanh().half().to(dev())
+        buf.inps[:4, 0] = torch.randn(4, 128, 8, 64, generator=gen).relu().half().to(dev())
+        torch.manual_seed(0)
+        graph = FactorGraph(UpdateModule().eval(), buf, dev(), max_factors=-1, incremental=False)
+        graph.add_factors(torch.from_numpy(g.ii), torch.from_numpy(g.jj))
+        graph.update_batch(itrs=2, steps=1, optimize_intrinsics=False, optimize_rig_rotation=False)
+        torch.cuda.synchronize()
+        return graph.target.cpu().numpy(), buf.poses[:4].cpu().numpy(), buf.disps[:4, 0].cpu().numpy()
+
+    ta, pa, da = run(True)
+    tv, pv, dv = run(False)
+    assert np.abs(ta - tv).max() < 0.1
+    assert np.abs(pa - pv).max() < 1e-3 and np.abs(da - dv).max() < 1e-2 * np.abs(da).max()

@@ -6,6 +6,8 @@ correlation lookup -> flow-update operator -> dense BA.  Per iteration it issues
 scatter_mean's index.max(), every _tmult_mat_elements and the CPU spsolve).
 """
 
+import os
+
 import numpy as np
 import torch
 
@@ -281,8 +283,14 @@ class FactorGraph:
         assert self.net_n is not None
         buf = self.buffer
         t = buf.n_frames
-        corr_op = AltCorrBlock(buf.flattened_fmaps[None])
         eng = self.update_op.engine(self.device)
+        # The reference's backend uses the volume-free AltCorrBlock to fit 24 GB devices (droid_net.py:121-176).  With
+        # 288 GB of HBM the per-chunk volume (~33 MB per edge, ~1.5 GB per chunk of 8 source keyframes) is cheap, and
+        # building it (one fused kernel, 10 us per edge) + the fused lookup is >10x faster than 49 x 128-channel dot
+        # products per pixel and level; AltCorrBlock stays the path for grids the volume kernels do not cover.
+        use_volume = (eng.backend == "hip" and self.wd % 64 == 0 and self.ht % 8 == 0
+                      and os.environ.get("VIPE_AMD_BACKEND_ALTCORR") is None)
+        corr_op = None if use_volume else AltCorrBlock(buf.flattened_fmaps[None])
         P = self._edge_plan()
         V = buf.n_views
         for _ in range(steps):
@@ -298,11 +306,16 @@ class FactorGraph:
                 v_exp = v.view(-1, 1).repeat(1, V).view(-1)
                 iis, jjs = self.ii[v], self.jj[v]
                 pis, qis, dis, pjs, qjs, djs = buf.expand_edge_multiview(iis, jjs)
-                corr1 = corr_op(coords1[None][:, v_exp], dis, djs)  # [1,n,196,h,w] fp32
                 du, dixs = torch.unique(dis, return_inverse=True)
                 n = int(v_exp.sum())
-                corr_n = torch.zeros((n, self.ht, self.wd, 200), dtype=torch.half, device=self.device)
-                corr_n[..., :196] = corr1[0].permute(0, 2, 3, 1)
+                if use_volume:
+                    vol = CorrBlock(buf.fmaps[pis, qis][None], buf.fmaps[pjs, qjs][None])
+                    corr_n = vol.lookup_deferred(coords1[v_exp])
+                    corr1 = None
+                else:
+                    corr1 = corr_op(coords1[None][:, v_exp], dis, djs)  # [1,n,196,h,w] fp32
+                    corr_n = torch.zeros((n, self.ht, self.wd, 200), dtype=torch.half, device=self.device)
+                    corr_n[..., :196] = corr1[0].permute(0, 2, 3, 1)
                 xb = torch.empty((n, self.ht, self.wd, 320), dtype=torch.half, device=self.device)
                 xb[..., 0:128] = buf.inps[pis, qis].permute(0, 2, 3, 1)
                 if eng.backend == "hip":
