@@ -178,6 +178,10 @@ def main():
                     help="update: the headline metric (update iterations/s on the 48-keyframe graph); video: frames/s "
                          "of the keyframe frontend on a synthetic video")
     ap.add_argument("--frames", type=int, default=200)
+    ap.add_argument("--also-without-gate-hoist", action="store_true",
+                    help="additionally time the step with the context part of the GRU gates recomputed every iteration "
+                         "(value_all_gate_work_per_iteration); off by default so that every launch of the roofline "
+                         "kernel in the default command is of the same population as the event-timed ones")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -230,7 +234,7 @@ def main():
     # the correlation volume) and enters the gates as the initial accumulator value; this second figure recomputes it
     # every iteration, as the reference does
     value_no_hoist = None
-    if world == 1 and getattr(graph, "pgate", None) is not None:
+    if args.also_without_gate_hoist and world == 1 and getattr(graph, "pgate", None) is not None:
         keep = graph.pgate
         graph.pgate = None
         nb = max(3, args.steps // 4)
