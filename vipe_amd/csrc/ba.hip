@@ -1338,7 +1338,7 @@ __global__ __launch_bounds__(TILE) void ba_walk_kernel(BAArgs a) {
 // rows = sqrt(Q) * [E_kk (pose i); E_j of every term; E_f; w], Gram over all P pixels, one workgroup per 16 x 16 tile
 // pair of the lower triangle.  Each wave takes every fourth 64-pixel chunk: the two row tiles are staged in LDS
 // (coalesced 256-byte row segments), 16 v_mfma_f32_16x16x4_f32 per chunk, partial tiles summed through LDS.
-constexpr int SC_GRID = 24;  // tile pairs processed in parallel per frame (the kernel strides over the rest)
+constexpr int SC_GRID = 96;  // tile pairs processed in parallel per frame (the kernel strides over the rest; idle blocks exit)
 
 template <int F>
 __global__ __launch_bounds__(TILE) void ba_schur_kernel(BAArgs a) {
@@ -1387,18 +1387,25 @@ __global__ __launch_bounds__(TILE) void ba_schur_kernel(BAArgs a) {
     }
     __syncthreads();
     float4m g4 = {0.f, 0.f, 0.f, 0.f};
-    for (int ch = wave; ch < nchunks; ch += NWAVE) {
+    // the rows of the next chunk are fetched while the current chunk's MFMAs run
+    float va[16], vb[16], na[16], nb[16];
+    auto fetch = [&](int ch, float (&da)[16], float (&db)[16]) {
       const int px = ch * 64 + lane;
       const bool ok = px < P;
-      const float sq = ok ? __builtin_amdgcn_rsqf(Ck[px]) : 0.0f;
-      float va[16], vb[16];
+      const float sq = ok ? __builtin_amdgcn_rsqf(Ck[ok ? px : 0]) : 0.0f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float* pa = rowp[r];
         const float* pb = rowp[16 + r];
-        va[r] = (ok && pa) ? pa[px] * sq : 0.0f;
-        vb[r] = (ok && pb) ? pb[px] * sq : 0.0f;
+        da[r] = (ok && pa) ? pa[px] * sq : 0.0f;
+        db[r] = (ok && pb) ? pb[px] * sq : 0.0f;
       }
+    };
+    if (wave < nchunks) fetch(wave, na, nb);
+    for (int ch = wave; ch < nchunks; ch += NWAVE) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { va[r] = na[r]; vb[r] = nb[r]; }
+      if (ch + NWAVE < nchunks) fetch(ch + NWAVE, na, nb);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         tile[wave][0][r * AM_P2 + lane] = va[r];
