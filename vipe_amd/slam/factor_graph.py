@@ -259,13 +259,21 @@ class FactorGraph:
         self.target = coords1[None] + delta
         self.damping[P["du"]] = eta
         if use_inactive:
-            m = (self.ii_inac >= t0 - 3) & (self.jj_inac >= t0 - 3)
-            ii = torch.cat([self.ii_inac[m], self.ii], 0)
-            jj = torch.cat([self.jj_inac[m], self.jj], 0)
-            exp_m = m.view(-1, 1).repeat(1, buf.n_views).view(-1)
-            target = torch.cat([self.target_inac[:, exp_m], self.target], 1)
-            weight = torch.cat([self.weight_inac[:, exp_m], self.weight], 1)
-            plan = None
+            # factor_graph.py:296-304.  The selection of inactive edges and its multiview expansion only change with
+            # the edge sets (or t0): cached in the edge plan, so the steady-state iteration has no boolean-mask
+            # indexing (a device-to-host sync each) and no re-expansion
+            key = ("inac", t0)
+            if key not in P:
+                m = (self.ii_inac >= t0 - 3) & (self.jj_inac >= t0 - 3)
+                sel = torch.nonzero(m).view(-1)
+                ii = torch.cat([self.ii_inac[sel], self.ii], 0)
+                jj = torch.cat([self.jj_inac[sel], self.jj], 0)
+                V = buf.n_views
+                sel_exp = (sel.view(-1, 1) * V + torch.arange(V, device=self.device).view(1, -1)).view(-1)
+                P[key] = (ii, jj, sel_exp, buf.expand_edge_multiview(ii, jj)[:5])
+            ii, jj, sel_exp, plan = P[key]
+            target = torch.cat([self.target_inac.index_select(1, sel_exp), self.target], 1)
+            weight = torch.cat([self.weight_inac.index_select(1, sel_exp), self.weight], 1)
         else:
             ii, jj, target, weight = self.ii, self.jj, self.target, self.weight
             plan = (P["pi"], P["qi"], P["di"], P["pj"], P["qj"])  # cached expand_edge_multiview of the edge set
