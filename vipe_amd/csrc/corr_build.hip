@@ -34,8 +34,8 @@ constexpr int PB_PA = PB_N * 2 + 32;     // byte pitch of the f2 chunk image row
 constexpr int PB_PB = PB_M * 2 + 32;     // byte pitch of the f1 tile image rows (160)
 constexpr int PB_PS = PB_N + 8;          // halves per staged source pixel (136)
 constexpr int PB_IMGA = PB_C * PB_PA;    // 36864
-constexpr int PB_IMGB = PB_C * PB_PB > PB_M * PB_PS * 2 ? PB_C * PB_PB : PB_M * PB_PS * 2;  // 20480
-constexpr int PB_LDS = PB_IMGA + PB_IMGB;
+constexpr int PB_STAGE = PB_M * PB_PS * 2;  // 17408: one staged level-0 tile [64 p1][128 p2 + pad] fp16
+constexpr int PB_LDS = PB_IMGA + 2 * PB_STAGE;  // f2 chunk image + two stage buffers (the f1 image borrows imgA first)
 
 struct BuildArgs {
   const half_t* f1;
@@ -63,8 +63,8 @@ __device__ __forceinline__ half_t pool4(half_t a, half_t b, half_t c, half_t d) 
 
 __global__ __launch_bounds__(512) void corr_pyramid_build_kernel(BuildArgs a) {
   extern __shared__ __align__(16) unsigned char lds[];
-  unsigned char* imgA = lds;             // f2 chunk  [128 c][128 p2]
-  unsigned char* imgB = lds + PB_IMGA;   // f1 tile   [128 c][64 p1], later the staged level-0 tile [64 p1][128 p2]
+  unsigned char* imgA = lds;             // f2 chunk  [128 c][128 p2]; before the first chunk: the f1 tile [128 c][64 p1]
+  unsigned char* imgB = lds;             // (f1 tile image, 20480 B <= imgA)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int P = a.h * a.w;
   const int tiles = P / PB_M;
@@ -119,10 +119,45 @@ __global__ __launch_bounds__(512) void corr_pyramid_build_kernel(BuildArgs a) {
   const int64_t p1g = (int64_t)e * P + p1_0 + sp1;
   half4 l1prev = {0, 0, 0, 0};
   half_t l2prev[2] = {0, 0};
-  half_t* stage = reinterpret_cast<half_t*>(imgB);
+  half_t* stage0 = reinterpret_cast<half_t*>(lds + PB_IMGA);
+  // Software pipeline over the chunks: the level-0 tile of chunk ch is staged in buffer ch & 1 and leaves for HBM one
+  // iteration later, BEFORE the loads of the next f2 chunk are issued - loads and stores share the in-order vmcnt
+  // counter, so a wait for the f2 loads then never has to sit through the HBM write latency of younger stores (it
+  // did: 4.3 us per chunk).
+  auto output = [&](int ch, const half_t* stage) {
+    int y, x0;
+    chunk_origin(ch, y, x0);
+    // level 0 + level 1: the thread reads columns 8s..8s+7 of both chunk rows once; its two 16-byte stores are parts
+    // of two fully covered 128-byte row segments (8 lanes per source pixel and row)
+    const half8 r0 = *reinterpret_cast<const half8*>(stage + sp1 * PB_PS + sseg * 8);
+    const half8 r1 = *reinterpret_cast<const half8*>(stage + sp1 * PB_PS + 64 + sseg * 8);
+    half_t* dst = a.lv[0] + (p1g * a.h + y) * a.w + x0 + sseg * 8;
+    *reinterpret_cast<half8*>(dst) = r0;
+    *reinterpret_cast<half8*>(dst + a.w) = r1;
+    if (a.nlev <= 1) return;
+    half4 l1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) l1[k] = pool4(r0[2 * k], r0[2 * k + 1], r1[2 * k], r1[2 * k + 1]);
+    *reinterpret_cast<half4*>(a.lv[1] + (p1g * (a.h >> 1) + (y >> 1)) * (a.w >> 1) + (x0 >> 1) + sseg * 4) = l1;
+    if (a.nlev > 2 && (ch & 1)) {
+      half_t l2[2];
+      l2[0] = pool4(l1prev[0], l1prev[1], l1[0], l1[1]);
+      l2[1] = pool4(l1prev[2], l1prev[3], l1[2], l1[3]);
+      half_t* d2 = a.lv[2] + (p1g * (a.h >> 2) + (y >> 2)) * (a.w >> 2) + (x0 >> 2) + sseg * 2;
+      d2[0] = l2[0];
+      d2[1] = l2[1];
+      if (a.nlev > 3 && (ch & 3) == 3)
+        a.lv[3][(p1g * (a.h >> 3) + (y >> 3)) * (a.w >> 3) + (x0 >> 3) + sseg] = pool4(l2prev[0], l2prev[1], l2[0], l2[1]);
+      l2prev[0] = l2[0];
+      l2prev[1] = l2[1];
+    }
+    l1prev = l1;
+  };
   for (int ch = 0; ch < nchunks; ++ch) {
+    __syncthreads();  // every wave is done reading imgA (previous chunk's fragments, or the f1 tile)
     commit();
-    __syncthreads();  // imgA ready; previous chunk's stage reads are done
+    __syncthreads();  // imgA ready; the previous chunk's staged tile is complete
+    if (ch > 0) output(ch - 1, stage0 + ((ch - 1) & 1) * (PB_STAGE / 2));
     if (ch + 1 < nchunks) fetch(ch + 1);
     float4v acc[2][2];
 #pragma unroll
@@ -141,6 +176,7 @@ __global__ __launch_bounds__(512) void corr_pyramid_build_kernel(BuildArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j][kk], acc[i][j], 0, 0, 0);
     }
     // D: rows = target pixels wn*32 + i*16 + 4g + r, column = source pixel wp*32 + j*16 + l16
+    half_t* stage = stage0 + (ch & 1) * (PB_STAGE / 2);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -150,39 +186,9 @@ __global__ __launch_bounds__(512) void corr_pyramid_build_kernel(BuildArgs a) {
         for (int r = 0; r < 4; ++r) hv[r] = (half_t)(acc[i][j][r] * 0.0625f);
         *reinterpret_cast<half4*>(stage + (wp * 32 + j * 16 + l16) * PB_PS + wn * 32 + i * 16 + 4 * g) = hv;
       }
-    __syncthreads();  // stage ready; imgA free
-    int y, x0;
-    chunk_origin(ch, y, x0);
-    // level 0: 32 contiguous bytes per thread (row sseg / 4 of the pair, columns (sseg % 4) * 16 ..)
-    {
-      const half8 v0 = *reinterpret_cast<const half8*>(stage + sp1 * PB_PS + sseg * 16);
-      const half8 v1 = *reinterpret_cast<const half8*>(stage + sp1 * PB_PS + sseg * 16 + 8);
-      half_t* dst = a.lv[0] + (p1g * a.h + y + (sseg >> 2)) * a.w + x0 + (sseg & 3) * 16;
-      *reinterpret_cast<half8*>(dst) = v0;
-      *reinterpret_cast<half8*>(dst + 8) = v1;
-    }
-    if (a.nlev > 1) {
-      const half8 r0 = *reinterpret_cast<const half8*>(stage + sp1 * PB_PS + sseg * 8);
-      const half8 r1 = *reinterpret_cast<const half8*>(stage + sp1 * PB_PS + 64 + sseg * 8);
-      half4 l1;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) l1[k] = pool4(r0[2 * k], r0[2 * k + 1], r1[2 * k], r1[2 * k + 1]);
-      *reinterpret_cast<half4*>(a.lv[1] + (p1g * (a.h >> 1) + (y >> 1)) * (a.w >> 1) + (x0 >> 1) + sseg * 4) = l1;
-      if (a.nlev > 2 && (ch & 1)) {
-        half_t l2[2];
-        l2[0] = pool4(l1prev[0], l1prev[1], l1[0], l1[1]);
-        l2[1] = pool4(l1prev[2], l1prev[3], l1[2], l1[3]);
-        half_t* d2 = a.lv[2] + (p1g * (a.h >> 2) + (y >> 2)) * (a.w >> 2) + (x0 >> 2) + sseg * 2;
-        d2[0] = l2[0];
-        d2[1] = l2[1];
-        if (a.nlev > 3 && (ch & 3) == 3)
-          a.lv[3][(p1g * (a.h >> 3) + (y >> 3)) * (a.w >> 3) + (x0 >> 3) + sseg] = pool4(l2prev[0], l2prev[1], l2[0], l2[1]);
-        l2prev[0] = l2[0];
-        l2prev[1] = l2[1];
-      }
-      l1prev = l1;
-    }
   }
+  __syncthreads();
+  output(nchunks - 1, stage0 + ((nchunks - 1) & 1) * (PB_STAGE / 2));
 }
 
 }  // namespace
