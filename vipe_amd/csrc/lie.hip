@@ -1,8 +1,7 @@
 // lietorch_ext: batched Lie-group ops, one group element per lane, grid-stride (device) or a plain
 // loop (host) over the SAME closed forms (lie_math.h).  Replaces csrc/lietorch_ext/lietorch_gpu.cu:24-299
-// and lietorch_cpu.cpp of the reference for SO3 (group_id 1) and SE3 (group_id 3), float32/float64.
-// Forward AND backward passes, projector, Jinv.  RxSO3 / Sim3 (ids 2, 4) are not on the SLAM path and return
-// VIPE_EUNSUPPORTED.
+// and lietorch_cpu.cpp of the reference for SO3 (group_id 1), RxSO3 (2), SE3 (3) and Sim3 (4), float32/float64.
+// Forward AND backward passes, projector, Jinv.
 #include "common.cuh"
 #include "lie_math.h"
 
@@ -12,14 +11,9 @@ using namespace lie;
 
 // ---- per-element functors: in0 [n,A], in1 [n,B] (optional), out [n,C]; `bc` = rows per element of in0
 template <typename G, typename S>
-struct OpExp {
+struct OpExp {  // SE3, RxSO3, Sim3: exp takes the tangent row
   static constexpr int A = G::K, B = 0, C = G::N;
-  static LIE_HD void run(const S* a, const S*, S* o);
-};
-template <typename S>
-struct OpExp<SE3<S>, S> {
-  static constexpr int A = 6, B = 0, C = 7;
-  static LIE_HD void run(const S* a, const S*, S* o) { SE3<S>::exp(a).store(o); }
+  static LIE_HD void run(const S* a, const S*, S* o) { G::exp(a).store(o); }
 };
 template <typename S>
 struct OpExp<SO3<S>, S> {
@@ -28,11 +22,9 @@ struct OpExp<SO3<S>, S> {
 };
 
 template <typename G, typename S>
-struct OpLog;
-template <typename S>
-struct OpLog<SE3<S>, S> {
-  static constexpr int A = 7, B = 0, C = 6;
-  static LIE_HD void run(const S* x, const S*, S* o) { SE3<S>(x).log(o); }
+struct OpLog {
+  static constexpr int A = G::N, B = 0, C = G::K;
+  static LIE_HD void run(const S* x, const S*, S* o) { G(x).log(o); }
 };
 template <typename S>
 struct OpLog<SO3<S>, S> {
@@ -55,7 +47,18 @@ struct OpMul {
 };
 
 template <typename G, typename S>
-struct OpAdj;
+struct OpAdj {  // RxSO3 / Sim3: dense K x K adjoint (rxso3.h:110, sim3.h:101)
+  static constexpr int A = G::N, B = G::K, C = G::K;
+  static LIE_HD void run(const S* x, const S* a, S* o) {
+    S Ad[G::K][G::K];
+    Jac<G, S>::Adj(G(x), Ad);
+    for (int i = 0; i < G::K; ++i) {
+      S acc = 0;
+      for (int j = 0; j < G::K; ++j) acc += Ad[i][j] * a[j];
+      o[i] = acc;
+    }
+  }
+};
 template <typename S>
 struct OpAdj<SE3<S>, S> {
   static constexpr int A = 7, B = 6, C = 6;
@@ -70,7 +73,18 @@ struct OpAdj<SO3<S>, S> {
   }
 };
 template <typename G, typename S>
-struct OpAdjT;
+struct OpAdjT {
+  static constexpr int A = G::N, B = G::K, C = G::K;
+  static LIE_HD void run(const S* x, const S* a, S* o) {
+    S Ad[G::K][G::K];
+    Jac<G, S>::Adj(G(x), Ad);
+    for (int j = 0; j < G::K; ++j) {
+      S acc = 0;
+      for (int i = 0; i < G::K; ++i) acc += Ad[i][j] * a[i];
+      o[j] = acc;
+    }
+  }
+};
 template <typename S>
 struct OpAdjT<SE3<S>, S> {
   static constexpr int A = 7, B = 6, C = 6;
@@ -94,11 +108,9 @@ struct OpAct {
   }
 };
 template <typename G, typename S>
-struct OpAct4;
-template <typename S>
-struct OpAct4<SE3<S>, S> {
-  static constexpr int A = 7, B = 4, C = 4;
-  static LIE_HD void run(const S* x, const S* p, S* o) { SE3<S>(x).act4(p, o); }
+struct OpAct4 {
+  static constexpr int A = G::N, B = 4, C = 4;
+  static LIE_HD void run(const S* x, const S* p, S* o) { G(x).act4(p, o); }
 };
 template <typename S>
 struct OpAct4<SO3<S>, S> {
@@ -110,7 +122,15 @@ struct OpAct4<SO3<S>, S> {
 };
 
 template <typename G, typename S>
-struct OpMatrix;
+struct OpMatrix {
+  static constexpr int A = G::N, B = 0, C = 16;
+  static LIE_HD void run(const S* x, const S*, S* o) {
+    S T[4][4];
+    Jac<G, S>::matrix4(G(x), T);
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) o[4 * i + j] = T[i][j];
+  }
+};
 template <typename S>
 struct OpMatrix<SE3<S>, S> {
   static constexpr int A = 7, B = 0, C = 16;
@@ -178,13 +198,17 @@ int dispatch(int gid, const void* in0, const void* in1, void* out, int64_t n, in
   if (dtype == VIPE_F32) {
     if (gid == 3) return run_op<Op<SE3<float>, float>, float>(in0, in1, out, n, rpe, on_device, s);
     if (gid == 1) return run_op<Op<SO3<float>, float>, float>(in0, in1, out, n, rpe, on_device, s);
+    if (gid == 4) return run_op<Op<Sim3<float>, float>, float>(in0, in1, out, n, rpe, on_device, s);
+    if (gid == 2) return run_op<Op<RxSO3<float>, float>, float>(in0, in1, out, n, rpe, on_device, s);
   } else if (dtype == VIPE_F64) {
     if (gid == 3) return run_op<Op<SE3<double>, double>, double>(in0, in1, out, n, rpe, on_device, s);
     if (gid == 1) return run_op<Op<SO3<double>, double>, double>(in0, in1, out, n, rpe, on_device, s);
+    if (gid == 4) return run_op<Op<Sim3<double>, double>, double>(in0, in1, out, n, rpe, on_device, s);
+    if (gid == 2) return run_op<Op<RxSO3<double>, double>, double>(in0, in1, out, n, rpe, on_device, s);
   } else {
     return VIPE_EINVAL;
   }
-  return (gid == 2 || gid == 4) ? VIPE_EUNSUPPORTED : VIPE_EINVAL;
+  return VIPE_EINVAL;
 }
 
 }  // namespace
@@ -414,13 +438,17 @@ int dispatch_bwd(int gid, const void* grad, const void* in0, const void* in1, vo
   if (dtype == VIPE_F32) {
     if (gid == 3) return run_bwd<Op<SE3<float>, float>, float>(grad, in0, in1, out0, out1, n, on_device, s);
     if (gid == 1) return run_bwd<Op<SO3<float>, float>, float>(grad, in0, in1, out0, out1, n, on_device, s);
+    if (gid == 4) return run_bwd<Op<Sim3<float>, float>, float>(grad, in0, in1, out0, out1, n, on_device, s);
+    if (gid == 2) return run_bwd<Op<RxSO3<float>, float>, float>(grad, in0, in1, out0, out1, n, on_device, s);
   } else if (dtype == VIPE_F64) {
     if (gid == 3) return run_bwd<Op<SE3<double>, double>, double>(grad, in0, in1, out0, out1, n, on_device, s);
     if (gid == 1) return run_bwd<Op<SO3<double>, double>, double>(grad, in0, in1, out0, out1, n, on_device, s);
+    if (gid == 4) return run_bwd<Op<Sim3<double>, double>, double>(grad, in0, in1, out0, out1, n, on_device, s);
+    if (gid == 2) return run_bwd<Op<RxSO3<double>, double>, double>(grad, in0, in1, out0, out1, n, on_device, s);
   } else {
     return VIPE_EINVAL;
   }
-  return (gid == 2 || gid == 4) ? VIPE_EUNSUPPORTED : VIPE_EINVAL;
+  return VIPE_EINVAL;
 }
 
 }  // namespace
