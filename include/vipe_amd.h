@@ -303,6 +303,32 @@ int vipe_conv2d_fused(const void* d_x0, int x0_ctot, int x0_coff, const void* d_
                       const void* d_accinit, int ai_ctot, int ai_coff, int B, int H, int W, int Cin, int Cout, int KH,
                       int KW, int act, int mode, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Frame encoders: BasicEncoder fnet / cnet (vipe/slam/networks/droid_net.py:290-370,
+ * DroidNet.encode_features / encode_context :510-527), run per frame by MotionFilter.check
+ * (vipe/slam/components/motion_filter.py:58-150).  NHWC fp16 activations, fp32 bias, packed fp16 weights:
+ *   conv: [k*k][Cin/32][Cout][32] (tap-major, 32-channel chunks);  stem: [7][32][32] with k = tap*4 + c (c = 3 and
+ *   taps >= 49 zero).  Instance-norm statistics are [B, C, 2] fp32 (sum, sum of squares of the fp16 outputs),
+ *   accumulated by the producing kernel (zero them first) and applied (x - mean) * rstd, eps 1e-5, + ReLU by the
+ *   consumer while it loads.
+ * ------------------------------------------------------------------------------------------- */
+/* [V,3,H,W] fp32 RGB in [0,1] -> [V,H,W,4] fp16 ((x - mean) / std, 4th channel 0) */
+int vipe_enc_prep(const float* d_img, void* d_x4, int V, int H, int W, void* stream);
+/* 7x7 stride-2 pad-3 stem, 3(+1) -> 32 channels: y [B,H/2,W/2,32] = conv + bias (+ReLU if relu) */
+int vipe_enc_stem(const void* d_x4, const void* d_w, const float* d_bias, void* d_y, float* d_out_stats, int B, int H,
+                  int W, int relu, void* stream);
+/* ksize in {1,3} (pad ksize/2), stride in {1,2}, Cin in {32,64,96,128}, Cout % 32 == 0.
+ * d_in_stats != null: the input is relu(instance_norm(x)) formed on load.  d_res != null (NHWC only):
+ * y = relu(res + act(conv)).  nchw: y is [B,Cout,Ho,Wo].  tanh_split >= 0: channels < split get tanh, the others
+ * ReLU (context net output, droid_net.py:525-527). */
+int vipe_enc_conv(const void* d_x, const float* d_in_stats, const void* d_w, const float* d_bias, const void* d_res,
+                  void* d_y, float* d_out_stats, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
+                  int relu, int nchw, int tanh_split, void* stream);
+/* residual tail of a normalised block: out = relu(xres + relu(IN(raw))); xres = res, or IN(res) if d_res_stats;
+ * d_res == null: out = relu(IN(raw)).  All [B,HW,C] fp16. */
+int vipe_enc_finish(const void* d_raw, const float* d_raw_stats, const void* d_res, const float* d_res_stats,
+                    void* d_out, int B, int HW, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

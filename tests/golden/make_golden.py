@@ -337,11 +337,43 @@ def gen_edge_selection(R):
     print("edge selection:", {k: v.shape for k, v in out.items() if k.endswith("_es")})
 
 
+def gen_encoder(R):
+    """BasicEncoder fnet (instance norm) / cnet (no norm) with seeded default-init weights (droid_net.py:290-370) and the
+    DroidNet.encode_features / encode_context arithmetic around them (:510-527, restated inline because DroidNet()
+    itself downloads weights), fp32 CPU.  Weights and images are re-created from the seeds by the tests; the fixture
+    keeps their checksums and the outputs."""
+    torch.manual_seed(0)
+    fnet = R.droid_net.BasicEncoder(output_dim=128, norm_fn="instance").eval()
+    cnet = R.droid_net.BasicEncoder(output_dim=256, norm_fn="none").eval()
+    gen = torch.Generator().manual_seed(5)
+    out = {}
+    for tag, (V, H, W) in {"small": (2, 96, 128), "odd": (1, 72, 104)}.items():
+        images = torch.rand(V, 3, H, W, generator=gen)
+        mean = torch.as_tensor([0.485, 0.456, 0.406])
+        std = torch.as_tensor([0.229, 0.224, 0.225])
+        x = (images[None] - mean[:, None, None]) / std[:, None, None]
+        with torch.no_grad():
+            fmap = fnet(x).squeeze(0)
+            net, inp = cnet(x).split([128, 128], dim=2)
+            net, inp = net.tanh().squeeze(0), inp.relu().squeeze(0)
+        out[tag + "/shape"] = np.array([V, H, W])
+        out[tag + "/image_sum"] = np.array([float(images.double().sum())])
+        out[tag + "/fmap"], out[tag + "/net"], out[tag + "/inp"] = _np(fmap), _np(net), _np(inp)
+    for name, m in (("fnet", fnet), ("cnet", cnet)):
+        for k, v in m.state_dict().items():
+            out[f"sdsum/{name}.{k}"] = np.array([float(v.double().sum()), float(v.double().abs().sum())])
+    np.savez_compressed(os.path.join(HERE, "encoder_reference.npz"), **out)
+    print("encoder:", {k: v.shape for k, v in out.items() if not k.startswith("sdsum")})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     R = load_reference()
     if os.environ.get("GOLDEN_ONLY") == "edges":
         gen_edge_selection(R)
+        sys.exit(0)
+    if os.environ.get("GOLDEN_ONLY") == "encoder":
+        gen_encoder(R)
         sys.exit(0)
     gen_edge_selection(R)
     gen_lie_wrapper(R)
@@ -349,4 +381,5 @@ if __name__ == "__main__":
     gen_ba(R)
     gen_update_module(R)
     gen_corr(R)
+    gen_encoder(R)
     print("golden fixtures written to", HERE)

@@ -239,3 +239,40 @@ def test_add_proximity_factors_edge_lists_match_reference(case):
     es = g[case + "_es"]
     assert got["remove"] is True
     assert np.array_equal(np.stack([got["ii"], got["jj"]], 1), es)
+
+
+def _seeded_encoders():
+    """fnet, cnet with the weights the fixture was made with (same seed, same construction order as the reference)"""
+    from vipe_amd.slam.encoders import BasicEncoder
+    G = np.load(os.path.join(GOLD, "encoder_reference.npz"))
+    torch.manual_seed(0)
+    fnet = BasicEncoder(output_dim=128, norm_fn="instance").eval()
+    cnet = BasicEncoder(output_dim=256, norm_fn="none").eval()
+    for name, m in (("fnet", fnet), ("cnet", cnet)):
+        for k, v in m.state_dict().items():
+            ref = G[f"sdsum/{name}.{k}"]
+            assert abs(float(v.double().sum()) - ref[0]) < 1e-6 * max(1, ref[1]), (name, k)
+    return G, fnet, cnet
+
+
+def _encoder_images(G, tag, gen):
+    V, H, W = [int(x) for x in G[tag + "/shape"]]
+    images = torch.rand(V, 3, H, W, generator=gen)
+    assert abs(float(images.double().sum()) - float(G[tag + "/image_sum"][0])) < 1e-6 * images.numel()
+    return images
+
+
+def test_encoders_match_reference():
+    """oracle/encoder.py against the outputs of the reference's BasicEncoder classes (droid_net.py:290-370) with the
+    encode_features / encode_context arithmetic (:510-527)."""
+    from oracle import encoder
+    G, fnet, cnet = _seeded_encoders()
+    gen = torch.Generator().manual_seed(5)
+    for tag in ("small", "odd"):
+        images = _encoder_images(G, tag, gen)
+        with torch.no_grad():
+            fmap = encoder.encode_features(fnet.state_dict(), images)
+            net, inp = encoder.encode_context(cnet.state_dict(), images)
+        assert np.allclose(fmap.numpy(), G[tag + "/fmap"], atol=2e-5)
+        assert np.allclose(net.numpy(), G[tag + "/net"], atol=2e-5)
+        assert np.allclose(inp.numpy(), G[tag + "/inp"], atol=2e-5)
