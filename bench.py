@@ -95,37 +95,50 @@ def cpu_baseline(seconds_budget=20.0):
 
 def video_mode(args, device, world, rank):
     """Secondary figure of SURVEY 8(d): frames/s of the keyframe frontend (frontend.py:78-167 mirror) on a synthetic
-    512x384xN "video" in which every frame is a keyframe: per frame = proximity-edge proposal (frame_distance kernel),
+    512x384xN "video" in which every frame is a keyframe: per frame = motion filter on the RGB frame (feature encoder,
+    one flow-update application against the last keyframe, context encoder), proximity-edge proposal (frame_distance kernel),
     correlation volume + pyramid + gate-context build for the new edges, 4 (+2) update iterations over the <= 48-edge
-    window incl. the dense BA with inactive edges.  Feature maps / hidden states are seeded N(0,1) fp16 (the encoders
-    are out of scope), poses follow a smooth seeded trajectory (constant-velocity initialisation, then the BA moves
+    window incl. the dense BA with inactive edges.  Frames are seeded uniform RGB images resident in HBM
+    (`--video-features`: seeded N(0,1) feature maps instead, encoders skipped), poses follow a smooth seeded trajectory (constant-velocity initialisation, then the BA moves
     them), random-init operator weights."""
     import torch.distributed as dist
 
     from vipe_amd.slam.buffer import GraphBuffer
     from vipe_amd.slam.frontend import FrontendArgs, SLAMFrontend
-    from vipe_amd.slam.networks import UpdateModule
+    from vipe_amd.slam.motion_filter import DroidNet, MotionFilter
 
     N = args.frames
     torch.manual_seed(1234 + rank)
     buf = GraphBuffer(384, 512, buffer_size=N + 16, device=device)
     buf.intrinsics[:] = torch.tensor([460.8, 460.8, 256.0, 192.0], device=device)
     torch.manual_seed(0)
-    um = UpdateModule().eval()
+    dn = DroidNet()  # fnet + cnet + update operator, random-init weights (no checkpoint offline)
+    um = dn.update
     # keyframe_thresh = 0: every synthetic frame stays a keyframe (random-weight flow would otherwise make the
     # distance test drop about half of them and the window would hold ~16 instead of <= 48 edges)
     fe = SLAMFrontend(um, buf, FrontendArgs(keyframe_thresh=0.0), device)
-    # the "decoded + encoded" frames: a pool of seeded feature maps resident in HBM before the timed region (inputs of
-    # the path are resident when timing starts); frame t uses pool entry t % 32
     gen = torch.Generator(device="cpu").manual_seed(99 + rank)
-    pool_f = torch.randn(32, 128, 48, 64, generator=gen).half().to(device)
-    pool_n = torch.randn(32, 128, 48, 64, generator=gen).tanh().half().to(device)
-    pool_i = torch.randn(32, 128, 48, 64, generator=gen).relu().half().to(device)
     pool_d = (1.0 / (1.0 + 4.0 * torch.rand(32, 48, 64, generator=gen))).to(device)
+    if args.video_features:
+        # legacy variant: the "decoded + encoded" frames are a pool of seeded feature maps resident in HBM
+        pool_f = torch.randn(32, 128, 48, 64, generator=gen).half().to(device)
+        pool_n = torch.randn(32, 128, 48, 64, generator=gen).tanh().half().to(device)
+        pool_i = torch.randn(32, 128, 48, 64, generator=gen).relu().half().to(device)
+    else:
+        # decoded RGB frames resident in HBM before the timed region (decode / resize are host work outside the path);
+        # every frame goes through the motion filter: feature encoder, one flow-update application against the last
+        # keyframe, context encoder (thresh 0: every frame becomes a keyframe)
+        pool_img = torch.rand(32, 1, 3, 384, 512, generator=gen).to(device)
+        mf = MotionFilter(dn, thresh=0.0, device=device)
 
     def feed():
         t = buf.n_frames
-        buf.fmaps[t, 0], buf.nets[t, 0], buf.inps[t, 0] = pool_f[t % 32], pool_n[t % 32], pool_i[t % 32]
+        if args.video_features:
+            buf.fmaps[t, 0], buf.nets[t, 0], buf.inps[t, 0] = pool_f[t % 32], pool_n[t % 32], pool_i[t % 32]
+        else:
+            keep = mf.check(pool_img[t % 32], None)
+            assert keep, "threshold 0 keeps every frame"
+            buf.fmaps[t], buf.nets[t], buf.inps[t] = mf.f_fmap, mf.f_net, mf.f_inp
         if t < fe.args.warmup:  # until the frontend owns the poses: smooth trajectory along x
             buf.poses[t, 0] = 0.05 * t
             buf.disps[t, 0] = pool_d[t % 32]
@@ -161,6 +174,8 @@ def video_mode(args, device, world, rank):
             "config": {"workload": f"{N} synthetic keyframes per clip, frontend window <= 48 edges, 4+2 update iterations "
                                    f"per keyframe, one clip per GPU", "update_iterations": fe.n_updates - u0,
                        "keyframes_kept": int(buf.n_frames), "edges_final": int(fe.graph.ii.numel()),
+                       "input": "feature maps (encoders skipped)" if args.video_features else
+                                "RGB frames: motion filter + feature / context encoders in the timed region",
                        "state_finite": finite}}))
 
 
@@ -178,6 +193,8 @@ def main():
                     help="update: the headline metric (update iterations/s on the 48-keyframe graph); video: frames/s "
                          "of the keyframe frontend on a synthetic video")
     ap.add_argument("--frames", type=int, default=200)
+    ap.add_argument("--video-features", action="store_true",
+                    help="video mode: feed seeded feature maps instead of RGB frames (skips motion filter + encoders)")
     ap.add_argument("--also-without-gate-hoist", action="store_true",
                     help="additionally time the step with the context part of the GRU gates recomputed every iteration "
                          "(value_all_gate_work_per_iteration); off by default so that every launch of the roofline "

@@ -141,3 +141,51 @@ def test_encoder_rejects_cpu_tensors():
     enc = BasicEncoder(128, "instance")
     with pytest.raises(RuntimeError):
         enc.forward_x4(torch.zeros(1, 16, 16, 4, dtype=torch.float16))
+
+
+def test_motion_filter_score_matches_oracle():
+    """MotionFilter.check (motion_filter.py:58-150): first frame -> keyframe; afterwards the mean flow magnitude of one
+    update-operator application on the identity grid.  Oracle: fp32 CPU encoders + correlation pyramid / lookup +
+    update operator restatements.  fp16 device path vs fp32 oracle: 3e-2 relative on the score."""
+    from oracle import corr as ocorr
+    from oracle import encoder as oenc
+    from oracle import update_module as oum
+    from vipe_amd.slam.motion_filter import DroidNet, MotionFilter
+    torch.manual_seed(0)
+    dn = DroidNet()
+    sd_f = {k: v.clone() for k, v in dn.fnet.state_dict().items()}
+    sd_c = {k: v.clone() for k, v in dn.cnet.state_dict().items()}
+    sd_u = {k: v.clone() for k, v in dn.update.state_dict().items()}
+    gen = torch.Generator().manual_seed(21)
+    V, H, W = 1, 96, 128
+    img0 = torch.rand(V, 3, H, W, generator=gen)
+    img1 = (img0 + 0.1 * torch.rand(V, 3, H, W, generator=gen)).clamp(0, 1)
+    mf = MotionFilter(dn, thresh=1e9, device=dev())
+    assert mf.check(img0.to(dev()).contiguous(), None) is True
+    assert mf.check(img1.to(dev()).contiguous(), None) is False
+    # masked variant: the left half of the keyframe is invalid
+    mask = torch.zeros(V, H // 8, W // 8, dtype=torch.bool)
+    mask[:, :, : W // 16] = True
+    mf_m = MotionFilter(dn, thresh=1e9, device=dev())
+    mf_m.check(img0.to(dev()).contiguous(), mask.to(dev()))
+    mf_m.check(img1.to(dev()).contiguous(), None)
+    with torch.no_grad():
+        f0, f1 = oenc.encode_features(sd_f, img0), oenc.encode_features(sd_f, img1)
+        net, inp = oenc.encode_context(sd_c, img0)
+        ht, wd = H // 8, W // 8
+        pyr = [l.numpy() for l in ocorr.corr_pyramid(f0[None], f1[None])]
+        coords0 = MotionFilter.coords_grid(ht, wd)[None, None].repeat(1, V, 1, 1, 1).numpy()
+        corr = torch.from_numpy(ocorr.corr_lookup(pyr, coords0, 3))
+        _, delta, _ = oum.update_forward(sd_u, net[None], inp[None], corr, torch.zeros(1, V, 4, ht, wd))
+        flow = delta.norm(dim=-1)[0]
+        ref = float(flow.mean([1, 2]).min())
+        fw = (~mask).float()
+        ref_m = float(((flow * fw).mean([1, 2]) / (fw.mean([1, 2]) + 1e-6)).min())
+    assert abs(mf.last_score - ref) < 3e-2 * max(ref, 1e-3), (mf.last_score, ref)
+    assert abs(mf_m.last_score - ref_m) < 3e-2 * max(ref_m, 1e-3), (mf_m.last_score, ref_m)
+    # a zero threshold keeps the frame and refreshes the keyframe features
+    mf0 = MotionFilter(dn, thresh=0.0, device=dev())
+    mf0.check(img0.to(dev()).contiguous(), None)
+    old = mf0.f_fmap.clone()
+    assert mf0.check(img1.to(dev()).contiguous(), None) is True and mf0.last_kf_frame_idx == 1
+    assert not torch.equal(old, mf0.f_fmap)

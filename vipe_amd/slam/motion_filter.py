@@ -1,0 +1,101 @@
+"""Keyframe selection on every incoming frame - host-side mirror of `MotionFilter`
+(vipe/slam/components/motion_filter.py:27-150) and of the `DroidNet` container it drives
+(vipe/slam/networks/droid_net.py:503-552).  SURVEY 8(f) row 2.
+
+Per frame: feature encoder (HIP, `encoders.py`) -> correlation pyramid between the last keyframe's features and the
+new ones -> ONE application of the flow-update operator on the identity grid -> mean flow magnitude against the
+threshold; the context encoder runs only when the frame becomes a keyframe.  Everything that is constant while the
+last keyframe stays (its hidden state / context features in channels-last form, the hoisted gate-context term of the
+GRU) is prepared once per keyframe.  Sparse tracks (`sparse_tracks.enabled`) are outside the dense path and treated as
+disabled, as `SparseTracks` is when the reference runs without a tracker."""
+import torch
+
+from .._lib import require
+from .encoders import DroidEncoders, normalize_images
+from .networks import CorrBlock, UpdateModule
+
+
+class DroidNet(DroidEncoders):
+    """fnet + cnet + update (droid_net.py:503-509).  The reference constructor downloads `droid.pth`; here weights
+    are random-initialised unless `load_weights(path)` is given a local checkpoint (there is no network)."""
+
+    def __init__(self):
+        super().__init__()
+        self.update = UpdateModule()
+        self.eval()
+
+    def load_weights(self, ckpt_path):
+        """droid_net.py:529-552: strip `module.`, keep the first 2 output channels of the flow / weight heads.
+        `weights_only=True`: nothing in the file is executed."""
+        sd = torch.load(ckpt_path, map_location="cpu", weights_only=True)
+        sd = {k.replace("module.", ""): v for k, v in sd.items()}
+        for k in ("update.weight.2.weight", "update.weight.2.bias", "update.delta.2.weight", "update.delta.2.bias"):
+            sd[k] = sd[k][:2]
+        # norm layers of the reference hold no parameters for norm_fn instance / none; ignore running-stat leftovers
+        own = self.state_dict()
+        missing = [k for k in own if k not in sd]
+        require(not missing, f"checkpoint lacks {missing[:4]}...")
+        self.load_state_dict({k: sd[k] for k in own})
+        self.update._engine = None
+        self.eval()
+        return self
+
+
+class MotionFilter:
+    def __init__(self, droid_net, sparse_tracks=None, thresh=2.5, device=torch.device("cuda")):
+        self.net = droid_net
+        self.thresh = thresh
+        self.device = device
+        self.sparse_tracks = sparse_tracks
+        self.initialized = False
+        self.last_score = None
+
+    @staticmethod
+    def coords_grid(ht, wd, **kwargs):
+        y, x = torch.meshgrid(torch.arange(ht).to(**kwargs).float(), torch.arange(wd).to(**kwargs).float(), indexing="ij")
+        return torch.stack([x, y], dim=-1)
+
+    def _set_keyframe(self, images, x4, gmap, buffer_masks):
+        net, inp = self.net.encode_context(images, x4)
+        self.f_net, self.f_inp, self.f_fmap = net, inp, gmap
+        self.f_mask = buffer_masks
+        V, _, ht, wd = net.shape
+        eng = self.net.update.engine(net.device)
+        # channels-last state of the keyframe side of the one-iteration flow estimate, prepared once per keyframe
+        self._net_nhwc = net.permute(0, 2, 3, 1).contiguous()
+        self._xbuf = torch.empty((V, ht, wd, 320), dtype=torch.float16, device=net.device)
+        self._xbuf[..., :128] = inp.permute(0, 2, 3, 1)
+        self._pgate = eng.gate_context(self._xbuf) if eng.supports_gate_split(ht, wd) else None
+        self._motn0 = torch.zeros((V, ht, wd, 4), dtype=torch.float16, device=net.device)
+        self._coords0 = self.coords_grid(ht, wd, device=net.device)[None].repeat(V, 1, 1, 1).contiguous()
+
+    @torch.no_grad()
+    def check(self, images, buffer_masks=None):
+        """images [V,3,H,W] fp32 RGB in [0,1] on the device; buffer_masks [V,h,w] bool (True = invalid) or None.
+        Returns True when the frame is to become a keyframe (its features are then in f_fmap / f_net / f_inp)."""
+        require(not (self.sparse_tracks is not None and getattr(self.sparse_tracks, "enabled", False)),
+                "sparse tracks are outside the dense path")
+        x4 = normalize_images(images)
+        gmap = self.net.encode_features(images, x4)
+        if not self.initialized:
+            self._set_keyframe(images, x4, gmap, buffer_masks)
+            self.current_frame_idx = 0
+            self.last_kf_frame_idx = 0
+            self.initialized = True
+            return True
+        self.current_frame_idx += 1
+        eng = self.net.update.engine(gmap.device)
+        corr = CorrBlock(self.f_fmap[None], gmap[None]).lookup_deferred(self._coords0)
+        _, dw, _, _ = eng.forward_nhwc(self._net_nhwc, self._xbuf, corr, self._motn0, pgate=self._pgate)
+        dense_flow = dw[..., 0:2].half().float().norm(dim=-1)  # fp16 head output, norm in fp32 (autocast rules)
+        if self.f_mask is not None:
+            f_weight = (~self.f_mask).float()
+            score = (dense_flow * f_weight).mean([1, 2]) / (f_weight.mean([1, 2]) + 1e-6)
+        else:
+            score = dense_flow.mean([1, 2])
+        self.last_score = score.min().item()
+        if self.last_score > self.thresh:
+            self._set_keyframe(images, x4, gmap, buffer_masks)
+            self.last_kf_frame_idx = self.current_frame_idx
+            return True
+        return False
