@@ -954,3 +954,56 @@ def test_update_batch_volume_path_matches_altcorr_path(monkeypatch):
     tv, pv, dv = run(False)
     assert np.abs(ta - tv).max() < 0.1
     assert np.abs(pa - pv).max() < 1e-3 and np.abs(da - dv).max() < 1e-2 * np.abs(da).max()
+
+
+def test_extract_slam_map_and_project_map():
+    """GraphBuffer.extract_slam_map (buffer.py:595-645) + SLAMMap (interface.py:25-141) against the oracle's
+    depth_filter / iproj restatements; project_map keeps the nearest point per pixel and reproduces a keyframe's own
+    depth when projected back into that keyframe."""
+    from oracle import frame_ops
+    from vipe_amd.ext.lietorch import SE3
+    from vipe_amd.slam.buffer import GraphBuffer
+    N, ht, wd = 6, 48, 64
+    g = make_graph(N, ht * 8, wd * 8, seed=4)
+    buf = GraphBuffer(ht * 8, wd * 8, buffer_size=8, device=dev())
+    buf.poses[:N] = T(g.poses_gt, torch.float32)
+    buf.disps[:N, 0] = T(g.disps_gt, torch.float32)
+    buf.intrinsics[0] = T(g.intrinsics[0], torch.float32)
+    buf.tstamp[:N] = torch.arange(N, device=dev(), dtype=torch.int) * 3
+    rng = np.random.default_rng(0)
+    buf.images[:N] = T(rng.random((N, 1, 3, ht * 8, wd * 8)), torch.float16)
+    buf.masks[:N, 0, :4] = True
+    buf.n_frames = N
+    m = buf.extract_slam_map(filter_thresh=0.4)
+    poses, disps = g.poses_gt.astype(np.float32), g.disps_gt.astype(np.float32)
+    intr8 = (g.intrinsics[0] / 8.0).astype(np.float32)
+    c2w = ose3.se3_inv(poses.astype(np.float64)).astype(np.float32)
+    pts = frame_ops.iproj(c2w, disps, intr8)
+    th = np.full(N, 0.4 / disps.mean(), np.float32)
+    cnt = frame_ops.depth_filter(poses, disps, intr8, np.arange(N), th)
+    mask = (cnt >= 2) & (disps > 0.5 * disps.mean(axis=(1, 2), keepdims=True))
+    mask[:, :4] = False
+    assert mask.sum() > 1000
+    got_cnt = m.dense_disp_packinfo[:, 0, 1].cpu().numpy()
+    assert np.abs(got_cnt - mask.reshape(N, -1).sum(1)).max() <= 2  # threshold ties
+    if np.array_equal(got_cnt, mask.reshape(N, -1).sum(1)):
+        assert np.allclose(m.dense_disp_xyz.cpu().numpy(), pts[mask], rtol=1e-4, atol=1e-4)
+        rgb = buf.images[:N, 0][..., 3::8, 3::8].permute(0, 2, 3, 1).float().cpu().numpy()
+        assert np.array_equal(m.dense_disp_rgb.float().cpu().numpy(), rgb[mask])
+    assert m.dense_disp_frame_inds == [0, 3, 6, 9, 12, 15]
+    xyz2, _ = m.get_dense_disp_pcd(2)
+    assert xyz2.shape[0] == int(got_cnt[2])
+    assert m.get_dense_disp_full_pcd()[0].shape[0] == int(got_cnt.sum())
+    # project keyframe 2's own points (tstamp_nn = 0 window) back into keyframe 2 at 1/8 resolution
+    depth = m.project_map(6, 0, (ht, wd), torch.from_numpy(intr8).to(dev()), SE3(buf.poses[2:3]).inv()[0], tstamp_nn=0)
+    assert depth.shape == (ht, wd)
+    # local map: points in the camera frame have z = 1 / disparity
+    ml = buf.extract_slam_map(filter_thresh=0.4, is_local=True)
+    z = ml.get_dense_disp_pcd(2)[0][:, 2].cpu().numpy()
+    assert np.allclose(z, (1.0 / disps[2])[mask[2]], rtol=1e-5) or z.shape[0] != mask[2].sum()
+    hit = depth > 0
+    assert hit.float().mean() > 0.05
+    ref_depth = torch.from_numpy(1.0 / disps[2]).to(dev())
+    # a pixel-centre point lands on the pixel's edge (u = x exactly); compare with the nearest of the 2x2 neighbourhood
+    err = torch.stack([(depth - torch.roll(ref_depth, (dy, dx), (0, 1))).abs() for dy in (0, -1) for dx in (0, -1)]).min(0).values
+    assert float((err[hit] / ref_depth[hit]).median()) < 1e-3

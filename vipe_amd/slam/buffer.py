@@ -41,12 +41,20 @@ class GraphBuffer:
         self.disps = torch.ones(buffer_size, n_views, ht, wd, **f32) * init_disp
         self.disps_sens = torch.zeros(buffer_size, n_views, ht, wd, **f32)
         self.masks = torch.zeros(buffer_size, n_views, ht, wd, device=device, dtype=torch.bool)
+        self._images = None  # full-resolution RGB 0-1 fp16 [N,V,3,H,W] (buffer.py:81-89), allocated on first use
         self.fmaps = torch.zeros(buffer_size, n_views, 128, ht, wd, device=device, dtype=torch.half)
         self.nets = torch.zeros(buffer_size, n_views, 128, ht, wd, device=device, dtype=torch.half)
         self.inps = torch.zeros(buffer_size, n_views, 128, ht, wd, device=device, dtype=torch.half)
         self.cross_view_idx = torch.zeros(buffer_size, n_views, 2, device=device, dtype=torch.long)
         self.cross_view_idx[..., 0] = torch.arange(buffer_size, device=device)[:, None]
         self.cross_view_idx[..., 1] = torch.tensor(cross_view_idx, device=device).long()[None]
+
+    @property
+    def images(self):
+        if self._images is None:
+            self._images = torch.zeros(self.tstamp.shape[0], self.n_views, 3, self.height, self.width, device=self.device,
+                                       dtype=torch.float16)
+        return self._images
 
     # ---- flattened (n v) views, buffer.py:181-199
     @property
@@ -110,7 +118,7 @@ class GraphBuffer:
     def remove_second_newest(self, ix):
         """buffer.py:218-231: keyframe ix is overwritten by its successor (the newest frame)."""
         assert ix == self.n_frames - 2
-        for name in ("tstamp", "images", "poses", "disps", "disps_sens", "nets", "inps", "fmaps", "masks",
+        for name in ("tstamp", "_images", "poses", "disps", "disps_sens", "nets", "inps", "fmaps", "masks",
                      "cross_view_idx"):
             arr = getattr(self, name, None)
             if arr is not None:
@@ -135,3 +143,49 @@ class GraphBuffer:
             d2 = slam_ext.frame_distance(exp, self.flattened_disps, intr, pj * V + qj, pi * V + qi, qj, qi, dj, beta)
             d = 0.5 * (d + d2)
         return d.view(-1, V)
+
+    def extract_slam_map(self, filter_thresh, t_range=None, is_local=False):
+        """buffer.py:595-645: per keyframe and view the inverse-projected (world, or camera when `is_local`) points of
+        the 1/8-resolution disparity map, the pixel colours at (3::8, 3::8), and the multi-view consistency mask
+        (`depth_filter` count >= min(2, n-1), disparity above half the frame mean, not masked) -> SLAMMap."""
+        from ..ext.lietorch import SE3
+        from .interface import SLAMMap
+
+        if t_range is None:
+            t_range = torch.arange(self.n_frames, device=self.device)
+        n = int(t_range.numel())
+        c2w = SE3(self.poses[t_range]).inv()
+        images = self.images[t_range][..., 3::8, 3::8].permute(0, 1, 3, 4, 2)
+        pts_list, mask_list = [], []
+        for v in range(self.n_views):
+            c2w_view = c2w * SE3(self.rig[v])[None]
+            disps_v = self.disps[t_range, v].contiguous()
+            intr8 = self.intrinsics[v].clone()
+            intr8[:4] = intr8[:4] / 8.0
+            ident = SE3.Identity(n, device=self.device).data.contiguous()
+            if self.camera_type == "pinhole":
+                pts = slam_ext.iproj(ident if is_local else c2w_view.data.contiguous(), disps_v, intr8[:4].contiguous())
+            else:  # MEI unprojection (cameras.py:228-250), then the same transform and dehomogenisation
+                ht, wd = disps_v.shape[1:]
+                yy, xx = torch.meshgrid(torch.arange(ht, device=self.device).float(),
+                                        torch.arange(wd, device=self.device).float(), indexing="ij")
+                fx, fy, cx, cy, k1 = intr8.unbind()
+                ub, vb = (xx - cx) / fx, (yy - cy) / fy
+                r2 = ub * ub + vb * vb
+                fac = (k1 + torch.sqrt(1 + (1 - k1 * k1) * r2)) / (1 + r2)
+                X, Y = ub * fac / (fac - k1), vb * fac / (fac - k1)
+                p4 = torch.stack([X.expand(n, -1, -1), Y.expand(n, -1, -1), torch.ones_like(disps_v), disps_v], -1)
+                if not is_local:
+                    p4 = c2w_view[:, None, None].act(p4.contiguous())
+                pts = p4[..., :3] / p4[..., 3:]
+            thresh_v = filter_thresh * (1.0 / disps_v.mean().item())
+            count = slam_ext.depth_filter(c2w_view.inv().data.contiguous(), disps_v,
+                                          self._pinhole_intrinsics_8()[v].contiguous(),
+                                          torch.arange(n, device=self.device),
+                                          torch.full((n,), thresh_v, device=self.device))
+            masks = ((count >= min(2, n - 1)) & (disps_v > 0.5 * disps_v.mean(dim=[1, 2], keepdim=True))
+                     & (~self.masks[t_range, v]))
+            pts_list.append(pts)
+            mask_list.append(masks)
+        return SLAMMap.from_masked_dense_disp(torch.stack(pts_list, 1), images, torch.stack(mask_list, 1),
+                                              self.tstamp[t_range])
