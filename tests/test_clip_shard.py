@@ -75,3 +75,31 @@ def test_single_process_gather_is_identity():
     r = [ClipResult(1, torch.ones(3, 7), torch.arange(4.0)), ClipResult(0, torch.zeros(2, 7), torch.zeros(4))]
     out = gather_results(r, n_clips=2, f_max=4)
     assert [o.clip_id for o in out] == [0, 1] and out[1].poses.shape == (3, 7)
+
+
+def test_pose_and_intrinsics_artifacts_round_trip(tmp_path):
+    """Reference on-disk formats (vipe/utils/io.py:144-225): `data` = OpenCV cam2world 4x4 float32, `inds` = frame ids."""
+    import numpy as np
+    from oracle import se3 as ose3
+    from vipe_amd.driver import artifacts
+    from vipe_amd.driver.clip_shard import ClipResult
+    rng = np.random.default_rng(0)
+    w2c = ose3.se3_exp(0.3 * rng.standard_normal((5, 6)))
+    p = tmp_path / "pose" / "a.npz"
+    artifacts.save_pose_artifacts(str(p), w2c, inds=[0, 2, 4, 6, 8])
+    raw = np.load(p)
+    assert sorted(raw.files) == ["data", "inds"] and raw["data"].dtype == np.float32 and raw["data"].shape == (5, 4, 4)
+    inds, c2w = artifacts.read_pose_artifacts(str(p))
+    assert list(inds) == [0, 2, 4, 6, 8]
+    ref = np.linalg.inv(ose3.se3_matrix(w2c))
+    assert np.allclose(c2w, ref, atol=1e-5)
+    ip = tmp_path / "intrinsics" / "a.npz"
+    cp = tmp_path / "intrinsics" / "a_camera.txt"
+    artifacts.save_intrinsics_artifacts(str(ip), np.tile([460.8, 460.8, 256.0, 192.0], (5, 1)), camera_path=str(cp))
+    inds, K, types = artifacts.read_intrinsics_artifacts(str(ip), str(cp))
+    assert K.shape == (5, 4) and K.dtype == np.float32 and types == ["PINHOLE"] * 5 and list(inds) == list(range(5))
+    assert cp.read_text().splitlines()[3] == "3: PINHOLE"
+    res = [ClipResult(3, torch.from_numpy(w2c).float(), torch.tensor([1.0, 2.0, 3.0, 4.0])),
+           ClipResult(4, torch.zeros(0, 7), torch.zeros(4), ok=False)]
+    assert artifacts.save_clip_results(str(tmp_path / "out"), res) == ["clip_00003"]
+    assert np.allclose(artifacts.read_pose_artifacts(str(tmp_path / "out" / "pose" / "clip_00003.npz"))[1], ref, atol=1e-5)
