@@ -84,25 +84,31 @@ class FactorGraph:
 
     @torch.no_grad()
     def rm_factors(self, mask, store=False):
-        """factor_graph.py:175-202."""
-        mask = mask.to(self.device)
-        exp_mask = mask.view(-1, 1).repeat(1, self.buffer.n_views).view(-1)
+        """factor_graph.py:175-202.  The mask is read back ONCE; every tensor is then compacted with the same index
+        vectors (boolean-mask indexing would synchronise per tensor)."""
+        m = mask.detach().cpu().numpy().astype(bool)
+        V = self.buffer.n_views
+        keep = torch.from_numpy(np.flatnonzero(~m)).to(self.device)
+        drop = torch.from_numpy(np.flatnonzero(m)).to(self.device)
+        views = torch.arange(V, device=self.device)
+        keep_x = (keep[:, None] * V + views).view(-1) if V > 1 else keep
+        drop_x = (drop[:, None] * V + views).view(-1) if V > 1 else drop
         if store:
-            self.ii_inac = torch.cat([self.ii_inac, self.ii[mask]], 0)
-            self.jj_inac = torch.cat([self.jj_inac, self.jj[mask]], 0)
-            self.target_inac = torch.cat([self.target_inac, self.target[:, exp_mask]], 1)
-            self.weight_inac = torch.cat([self.weight_inac, self.weight[:, exp_mask]], 1)
-        self.ii, self.jj, self.age = self.ii[~mask], self.jj[~mask], self.age[~mask]
+            self.ii_inac = torch.cat([self.ii_inac, self.ii[drop]], 0)
+            self.jj_inac = torch.cat([self.jj_inac, self.jj[drop]], 0)
+            self.target_inac = torch.cat([self.target_inac, self.target[:, drop_x]], 1)
+            self.weight_inac = torch.cat([self.weight_inac, self.weight[:, drop_x]], 1)
+        self.ii, self.jj, self.age = self.ii[keep], self.jj[keep], self.age[keep]
         if self.corr is not None:
-            self.corr = self.corr[~exp_mask]
+            self.corr = self.corr[keep_x]
         if self.net_n is not None:
-            self.net_n = self.net_n[~exp_mask]
+            self.net_n = self.net_n[keep_x]
         if self.xbuf is not None:
-            self.xbuf = self.xbuf[~exp_mask]
+            self.xbuf = self.xbuf[keep_x]
         if self.pgate is not None:
-            self.pgate = self.pgate[~exp_mask]
-        self.target = self.target[:, ~exp_mask]
-        self.weight = self.weight[:, ~exp_mask]
+            self.pgate = self.pgate[keep_x]
+        self.target = self.target[:, keep_x]
+        self.weight = self.weight[:, keep_x]
         self._plan = None
 
     def add_neighborhood_factors(self, t0, t1, r=3):
@@ -144,10 +150,18 @@ class FactorGraph:
                     if abs(di) + abs(dj) <= lim:
                         suppress(i + di, j + dj)
 
-        for i, j in zip(self.ii.tolist(), self.jj.tolist()):
-            suppress_nms(i, j)
-        for i, j in zip(self.ii_inac.tolist(), self.jj_inac.tolist()):
-            suppress_nms(i, j)
+        # edges already in the graph (active + inactive): the same suppression, all edges at once per window offset
+        D = d.reshape(t - t0, nj)  # view of d
+        I = np.concatenate([self.ii.cpu().numpy(), self.ii_inac.cpu().numpy()]).astype(np.int64)
+        J = np.concatenate([self.jj.cpu().numpy(), self.jj_inac.cpu().numpy()]).astype(np.int64)
+        if I.size:
+            lim = np.maximum(np.minimum(np.abs(I - J) - 2, nms), 0)
+            for di in range(-nms, nms + 1):
+                for dj in range(-nms, nms + 1):
+                    sel = (abs(di) + abs(dj)) <= lim
+                    a, b = I[sel] + di, J[sel] + dj
+                    ok = (a >= t0) & (a < t) & (b >= t1) & (b < t)
+                    D[a[ok] - t0, b[ok] - t1] = np.inf
         d[(iin - rad < jjn) | (d > thresh)] = np.inf
         es = []
         for i in range(t0, t):
@@ -176,17 +190,19 @@ class FactorGraph:
     def rm_second_newest_keyframe(self, ix):
         """factor_graph.py:204-228: drop keyframe ix (= n_frames - 2) from the buffer and the graph."""
         self.buffer.remove_second_newest(ix)
-        m = (self.ii_inac == ix) | (self.jj_inac == ix)
-        self.ii_inac[self.ii_inac >= ix] -= 1
-        self.jj_inac[self.jj_inac >= ix] -= 1
-        if bool(m.any()):
-            self.ii_inac, self.jj_inac = self.ii_inac[~m], self.jj_inac[~m]
-            m_exp = m.view(-1, 1).repeat(1, self.buffer.n_views).view(-1)
-            self.target_inac = self.target_inac[:, ~m_exp]
-            self.weight_inac = self.weight_inac[:, ~m_exp]
+        m = ((self.ii_inac == ix) | (self.jj_inac == ix)).cpu().numpy()  # one readback; no per-tensor mask syncs below
+        self.ii_inac = self.ii_inac - (self.ii_inac >= ix).long()
+        self.jj_inac = self.jj_inac - (self.jj_inac >= ix).long()
+        if m.any():
+            V = self.buffer.n_views
+            keep = torch.from_numpy(np.flatnonzero(~m)).to(self.device)
+            keep_x = (keep[:, None] * V + torch.arange(V, device=self.device)).view(-1) if V > 1 else keep
+            self.ii_inac, self.jj_inac = self.ii_inac[keep], self.jj_inac[keep]
+            self.target_inac = self.target_inac[:, keep_x]
+            self.weight_inac = self.weight_inac[:, keep_x]
         m = (self.ii == ix) | (self.jj == ix)
-        self.ii[self.ii >= ix] -= 1
-        self.jj[self.jj >= ix] -= 1
+        self.ii = self.ii - (self.ii >= ix).long()
+        self.jj = self.jj - (self.jj >= ix).long()
         self.rm_factors(m, store=False)
 
     def get_edges_np(self):
