@@ -1007,3 +1007,24 @@ def test_extract_slam_map_and_project_map():
     # a pixel-centre point lands on the pixel's edge (u = x exactly); compare with the nearest of the 2x2 neighbourhood
     err = torch.stack([(depth - torch.roll(ref_depth, (dy, dx), (0, 1))).abs() for dy in (0, -1) for dx in (0, -1)]).min(0).values
     assert float((err[hit] / ref_depth[hit]).median()) < 1e-3
+
+
+@pytest.mark.parametrize("intr", [False, True])
+def test_dense_ba_dense_window_of_twelve_poses(intr):
+    """The frontend's steady state (12 free poses, every pair coupled, source degree 12): the reduced system is a dense
+    72 x 72 block matrix (+ focal) - the widest band the LDS solver takes (two band columns per lane in the back
+    substitution, six trailing-update pairs per thread).  HIP fp32 vs the fp64 oracle."""
+    g = make_graph(n=13, height=96, width=128, radius=12, seed=31)
+    assert len(g.ii) == 156
+    bk = dict(t0=1, t1=13, n_iters=2, pose_damping=1e-4, pose_ep=1e-2, motion_only=False, limited_disp=False,
+              optimize_intrinsics=intr)
+    p, d, k, info = run_hip_ba(g, g.intrinsics, "pinhole", bk)
+    E = len(g.ii)
+    op, od, ok_, _ = oba.bundle_adjustment(g.poses, g.disps[:, None], g.disps_sens[:, None], g.intrinsics,
+                                           ose3.se3_identity(1), g.target.reshape(E, -1, 2), g.weight.reshape(E, -1, 2),
+                                           g.eta[:, None], g.ii, g.jj, **bk)
+    assert info[0] == 12 and info[2] == 0
+    assert np.abs(p - op).max() <= 1e-4 * max(1.0, np.abs(op).max())
+    assert np.abs(d - od[:, 0]).max() <= 1e-4 * np.abs(od).max()
+    if intr:
+        assert np.abs(k - ok_).max() <= 1e-4 * np.abs(ok_).max()

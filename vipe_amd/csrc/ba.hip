@@ -1479,6 +1479,7 @@ __device__ __forceinline__ void apply_retraction(const BAArgs& a, int t, int nth
 // stored reciprocal pivots - no workgroup barrier and no division on the dependent chain.
 // Sets info[5] = 1 when it solved the system (the global-memory kernel launched after it then exits).
 constexpr int BAND_T = 512;
+constexpr int BAND_UPT = 6;  // trailing-update pairs per thread: dense 12-pose windows (PB = 66: 2277 pairs) still fit
 
 #define VIPE_DPP_F64(v, ctrl)                                                                                    \
   __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(                         \
@@ -1512,7 +1513,7 @@ __global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds
   const int RD0 = TL0 + ntail * (n + 1);
   const int need = RD0 + npr + 64;
   if (t == 0) w.info[5] = 0;
-  if (n == 0 || need > lds_doubles || npair > 21 + 2 * (BAND_T - 64) || PB + ntail > BAND_T || WBP > 64 || F > 2) {
+  if (n == 0 || need > lds_doubles || npair > 21 + BAND_UPT * (BAND_T - 64) || PB + ntail > BAND_T || WBP > 128 || F > 2) {
 #ifdef VIPE_BA_STAMPS
     if (t == 0) printf("band solve skipped: n %d need %d lds %d npair %d PB %d ntail %d F %d bandblk %d\n", n, need, lds_doubles, npair, PB, ntail, F, bandblk);
 #endif
@@ -1536,13 +1537,15 @@ __global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds
     const int wv = t >> 6, ln = t & 63;
 #pragma unroll 12
     for (int r = wv; r < npr; r += BAND_T / 64) {
-      const int c = 6 * (r / 6) - PB + ln;
-      double v = 0.0;
-      if (ln < WB && c >= 0 && c <= r) {
-        v = S[(int64_t)r * ld + c];
-        if (c == r) v += (double)prm.pose_ep + (double)prm.pose_damping * (a.droid ? v : w.Hd[r]);  // DROID: geom_kernels.cu:1176
+      for (int l2 = ln; l2 < WBP; l2 += 64) {  // one pass for the neighbourhood graphs (WBP <= 64), two for dense windows
+        const int c = 6 * (r / 6) - PB + l2;
+        double v = 0.0;
+        if (l2 < WB && c >= 0 && c <= r) {
+          v = S[(int64_t)r * ld + c];
+          if (c == r) v += (double)prm.pose_ep + (double)prm.pose_damping * (a.droid ? v : w.Hd[r]);  // DROID: geom_kernels.cu:1176
+        }
+        L[r * WBP + l2] = v;
       }
-      if (ln < WBP) L[r * WBP + ln] = v;
     }
   }
   for (int idx = t; idx < ntail * (n + 1); idx += BAND_T) {
@@ -1564,7 +1567,7 @@ __global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds
     else { prow_off = TL0 + (t - PB) * (n + 1); prow_str = 6; }
   }
   // update: pair index t + BAND_T * slot (slot < UPT) -> one (a, b) pair, b <= a: pose-pose, tail-pose, tail-tail
-  constexpr int UPT = 2;
+  constexpr int UPT = BAND_UPT;
   int uA[UPT], uB[UPT], uD[UPT], sA[UPT], sB[UPT], sD[UPT], u_ia[UPT], u_ib[UPT];
   bool has_pair[UPT];
 #pragma unroll
@@ -1722,13 +1725,15 @@ __global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds
       const double* Dk = L + bofs(j0, j0);
       // operands that do not depend on the running y: block factor, reciprocal pivots, this lane's column of the
       // six block rows (entries L[j0 + j][6 kb - PB + t])
-      double Lk[6][6], rp[6], lc[6];
-      const int rt = j0 - PB + t;
+      double Lk[6][6], rp[6], lc[6], lc2[6];
+      const int rt = j0 - PB + t, rt2 = rt + 64;  // second column for bands wider than one wave (PB > 64)
       const bool upd = t < PB && rt >= 0;
+      const bool upd2 = t + 64 < PB && rt2 >= 0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         rp[i] = rdall[j0 + i];
         lc[i] = upd ? L[(j0 + i) * WBP + t] : 0.0;
+        lc2[i] = upd2 ? L[(j0 + i) * WBP + t + 64] : 0.0;
 #pragma unroll
         for (int j = 0; j < i; ++j) Lk[i][j] = Dk[i * WBP + j];
       }
@@ -1751,6 +1756,12 @@ __global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds
 #pragma unroll
         for (int j = 1; j < 6; ++j) sacc += lc[j] * x[j];
         y[rt] -= sacc;
+      }
+      if (upd2) {
+        double sacc = lc2[0] * x[0];
+#pragma unroll
+        for (int j = 1; j < 6; ++j) sacc += lc2[j] * x[j];
+        y[rt2] -= sacc;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
