@@ -1356,6 +1356,7 @@ __global__ __launch_bounds__(TILE) void ba_schur_kernel(BAArgs a) {
   __shared__ float tile[NWAVE][2][16 * AM_P2];
   __shared__ float red[NWAVE][256];
   __shared__ const float* rowp[32];
+  __shared__ float rowm[32];  // 1 for a live row, 0 for an absent one (its pointer then aims at valid memory: loads stay unconditional)
   __shared__ int rowg[32];
   // source row r of the stacked E matrix: pointer to its P values (or null) and its index in the reduced system
   auto resolve = [&](int r, const float*& ptr, int& g) {
@@ -1383,7 +1384,7 @@ __global__ __launch_bounds__(TILE) void ba_schur_kernel(BAArgs a) {
     if (tid < 32) {
       const float* ptr; int g;
       resolve(16 * (tid < 16 ? ta : tb) + (tid & 15), ptr, g);
-      rowp[tid] = ptr; rowg[tid] = g;
+      rowp[tid] = ptr ? ptr : (w.C + (int64_t)k * P); rowm[tid] = ptr ? 1.0f : 0.0f; rowg[tid] = g;
     }
     __syncthreads();
     float4m g4 = {0.f, 0.f, 0.f, 0.f};
@@ -1392,13 +1393,19 @@ __global__ __launch_bounds__(TILE) void ba_schur_kernel(BAArgs a) {
     auto fetch = [&](int ch, float (&da)[16], float (&db)[16]) {
       const int px = ch * 64 + lane;
       const bool ok = px < P;
-      const float sq = ok ? __builtin_amdgcn_rsqf(Ck[ok ? px : 0]) : 0.0f;
+      const int pxc = ok ? px : 0;
+      const float sq = ok ? __builtin_amdgcn_rsqf(Ck[pxc]) : 0.0f;
+      // all 32 row loads are unconditional (absent rows read a valid dummy row and are scaled by 0), so they are in
+      // flight together instead of one L2 round trip per guarded load
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float* pa = rowp[r];
-        const float* pb = rowp[16 + r];
-        da[r] = (ok && pa) ? pa[px] * sq : 0.0f;
-        db[r] = (ok && pb) ? pb[px] * sq : 0.0f;
+        da[r] = rowp[r][pxc];
+        db[r] = rowp[16 + r][pxc];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        da[r] *= sq * rowm[r];
+        db[r] *= sq * rowm[16 + r];
       }
     };
     if (wave < nchunks) fetch(wave, na, nb);
