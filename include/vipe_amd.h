@@ -68,10 +68,12 @@ int vipe_corr_pyramid_lookup_nhwc(const void* const* h_levels, const float* d_co
 /* [fused] 4-level radius-3 lookup (droid_net.py:71-82) + the correlation encoder's first layer, Conv2d(196, Cout, 1)
  * + bias + activation (droid_net.py:436-437, 481): out[B,h1,w1,out_ctot] channels [out_coff, out_coff+Cout) fp16.
  * d_w_packed / d_bias as produced by vipe_conv_pack_weights for a [Cout, 200, 1, 1] weight (196 + 4 zero inputs).
- * fp16 volume levels, Cout == 128; other configurations return VIPE_EUNSUPPORTED (use lookup_nhwc + conv2d). */
+ * fp16 volume levels, Cout == 128; other configurations return VIPE_EUNSUPPORTED (use lookup_nhwc + conv2d).
+ * d_slots (optional, [B] int32): edge b reads slot d_slots[b] of the level buffers (a pool of pyramids with capacity
+ * >= B whose edges come and go without compaction, factor_graph.py:147-152,194-196); null: slot b. */
 int vipe_corr_lookup_conv1x1(const void* const* h_levels, const float* d_coords, const void* d_w_packed,
                              const float* d_bias, void* d_out, int out_ctot, int out_coff, int B, int h1, int w1,
-                             int h2, int w2, int Cout, int act, void* stream);
+                             int h2, int w2, int Cout, int act, const int* d_slots, void* stream);
 
 /* [fused] CorrBlock.corr + pyramid (droid_net.py:56-69,94-102): volume = (f1/4)^T (f2/4) on MFMA (fp16 in,
  * fp32 accumulate, stored as dtype), then 2x2 average pooling of the target dims for levels 1..num_levels-1.

@@ -1028,3 +1028,48 @@ def test_dense_ba_dense_window_of_twelve_poses(intr):
     assert np.abs(d - od[:, 0]).max() <= 1e-4 * np.abs(od).max()
     if intr:
         assert np.abs(k - ok_).max() <= 1e-4 * np.abs(ok_).max()
+
+
+def test_corr_pool_matches_corr_block_through_add_and_remove():
+    """CorrPool (pooled pyramids + slot indirection in the fused lookup kernel) against plain CorrBlock cat / index:
+    identical lookups after appends, removals (slot reuse) and growth beyond the initial capacity."""
+    from vipe_amd.ext import droid_net_ext
+    from vipe_amd.slam.networks import CorrBlock, CorrPool
+    from vipe_amd.slam.networks import UpdateModule
+    torch.manual_seed(0)
+    eng = UpdateModule().eval().engine(dev())
+    g = torch.Generator().manual_seed(8)
+    h, w = 8, 64
+
+    def block(n):
+        f1 = torch.randn(1, n, 128, h, w, generator=g).half().to(dev())
+        f2 = torch.randn(1, n, 128, h, w, generator=g).half().to(dev())
+        return CorrBlock(f1, f2)
+
+    pool = CorrPool(capacity=4)
+    ref = None
+    steps = [("add", 3), ("rm", [0, 2]), ("add", 2), ("add", 4), ("rm", [1, 2, 3, 5]), ("add", 3)]
+    for op, arg in steps:
+        if op == "add":
+            b = block(arg)
+            lv = [l.clone() for l in b.corr_pyramid]
+            pool.cat(b)
+            ref = lv if ref is None else [torch.cat([r, l], 0) for r, l in zip(ref, lv)]
+        else:
+            keep = np.array(arg)
+            pool = pool[keep]
+            ref = [r[torch.from_numpy(keep).to(dev())] for r in ref]
+        E = ref[0].shape[0]
+        assert len(pool) == E and tuple(pool.slots.shape) == (E,)
+        for a, b_ in zip(pool.corr_pyramid, ref):
+            assert torch.equal(a, b_)
+        coords = (torch.rand(E, h, w, 2, generator=g) * torch.tensor([w - 1.0, h - 1.0])).to(dev())
+        handle = pool.lookup_deferred(coords)
+        assert handle[0] == "lookup" and len(handle) == 4
+        out_p = torch.zeros(E, h, w, 128, dtype=torch.float16, device=dev())
+        out_r = torch.zeros_like(out_p)
+        droid_net_ext.corr_lookup_conv1x1(handle[1], handle[2], eng.corr0.packed, eng.corr0.bias, out_p, act="relu",
+                                          slots=handle[3])
+        droid_net_ext.corr_lookup_conv1x1(ref, coords, eng.corr0.packed, eng.corr0.bias, out_r, act="relu")
+        assert torch.equal(out_p, out_r)
+        assert torch.equal(pool.lookup_nhwc(coords), droid_net_ext.corr_pyramid_lookup_nhwc(ref, coords, 3, 200))

@@ -342,7 +342,8 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void corr_lookup_conv_kernel(
     LevelPtrs lv, const float* __restrict__ coords, const half_t* __restrict__ wpk, const float* __restrict__ bias,
-    half_t* __restrict__ out, int out_ctot, int out_coff, int h1, int w1, int h2, int w2, int B, int cout_pad, int act) {
+    half_t* __restrict__ out, int out_ctot, int out_coff, int h1, int w1, int h2, int w2, int B, int cout_pad, int act,
+    const int* __restrict__ slots) {
   constexpr int R = 3, RD = 7, L = 4;
   using A = Acc<half_t>;
   __shared__ __align__(16) half_t stage[32 * LKC_PITCH];
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const bool pok = p < P;
     const int pc = pok ? p : P - 1;
     const float2 c = reinterpret_cast<const float2*>(coords)[(int64_t)n * P + pc];
+    const int ns = slots ? slots[n] : n;  // pooled pyramids: edge n lives in slot slots[n] of the level buffers
     uint4v lo[L], hi[L];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const int bx = (int)floorf(c.x * sc) - R, by = (int)floorf(c.y * sc) - R;
       const int y1 = by + j, c0 = bx >> 3, nchunks = w2l >> 3;
       const bool rowok = (y1 >= 0) & (y1 < h2l);
-      const half_t* slab = reinterpret_cast<const half_t*>(lv.p[l]) + ((int64_t)n * P + pc) * ((int64_t)h2l * w2l);
+      const half_t* slab = reinterpret_cast<const half_t*>(lv.p[l]) + ((int64_t)ns * P + pc) * ((int64_t)h2l * w2l);
       const uint4v* rowp = reinterpret_cast<const uint4v*>(slab + (int64_t)(rowok ? y1 : 0) * w2l);
       lo[l] = uint4v{0, 0, 0, 0};
       hi[l] = uint4v{0, 0, 0, 0};
@@ -643,7 +645,7 @@ VIPE_EXPORT int vipe_corr_pyramid_lookup_nhwc(const void* const* h_levels, const
 
 VIPE_EXPORT int vipe_corr_lookup_conv1x1(const void* const* h_levels, const float* d_coords, const void* d_w_packed,
                                          const float* d_bias, void* d_out, int out_ctot, int out_coff, int B, int h1,
-                                         int w1, int h2, int w2, int Cout, int act, void* stream) {
+                                         int w1, int h2, int w2, int Cout, int act, const int* d_slots, void* stream) {
   VIPE_CHECK_ARG(B >= 0 && h1 > 0 && w1 > 0 && h2 > 0 && w2 > 0);
   if (B == 0) return VIPE_OK;
   VIPE_CHECK_ARG(h_levels && d_coords && d_w_packed && d_bias && d_out);
@@ -660,6 +662,6 @@ VIPE_EXPORT int vipe_corr_lookup_conv1x1(const void* const* h_levels, const floa
   const int blocks = (int)std::min<int64_t>(ngroups, 256 * 4);
   corr_lookup_conv_kernel<<<blocks, 256, 0, as_stream(stream)>>>(lv, d_coords, (const half_t*)d_w_packed, d_bias,
                                                                  (half_t*)d_out, out_ctot, out_coff, h1, w1, h2, w2, B,
-                                                                 128, act);
+                                                                 128, act, d_slots);
   return vipe_launch_status();
 }

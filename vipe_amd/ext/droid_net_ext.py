@@ -133,7 +133,7 @@ def corr_pyramid_lookup_nhwc(levels, coords, radius=3, channel_stride=200):
     return out
 
 
-def corr_lookup_conv1x1(levels, coords, w_packed, bias, out, out_coff=0, cout=128, act="relu"):
+def corr_lookup_conv1x1(levels, coords, w_packed, bias, out, out_coff=0, cout=128, act="relu", slots=None):
     """[fused] `CorrBlock.__call__` (4 levels, radius 3) + the correlation encoder's first 1x1 convolution
     (droid_net.py:436-437): writes out[E,h,w,C] channels [out_coff, out_coff + cout) without materialising the
     196-channel lookup.  levels: fp16 pyramid of `corr_pyramid_build`; coords [E,h,w,2] f32.
@@ -141,11 +141,16 @@ def corr_lookup_conv1x1(levels, coords, w_packed, bias, out, out_coff=0, cout=12
     `corr_pyramid_lookup_nhwc` + the conv)."""
     check_gpu_contig(coords, out, *levels)
     require(len(levels) == 4 and levels[0].dtype == torch.float16 and coords.dtype == torch.float32, "fp16 4-level pyramid")
-    E, h1, w1, h2, w2 = levels[0].shape
+    cap, h1, w1, h2, w2 = levels[0].shape
+    E = cap if slots is None else int(slots.shape[0])  # slots [E] int32: edge e reads pyramid slot slots[e] (pooled store)
+    if slots is not None:
+        check_gpu_contig(slots)
+        require(slots.dtype == torch.int32 and E <= cap, "slots must be int32 [E], E <= pool capacity")
     require(tuple(coords.shape) == (E, h1, w1, 2) and tuple(out.shape[:3]) == (E, h1, w1) and out.dtype == torch.float16,
             "bad coords / out shape")
     arr = (ctypes.c_void_p * 4)(*[lv.data_ptr() for lv in levels])
     check(lib().vipe_corr_lookup_conv1x1(ctypes.cast(arr, ctypes.c_void_p), ptr(coords), ptr(w_packed), ptr(bias), ptr(out),
                                          out.shape[-1], out_coff, E, h1, w1, h2, w2, cout, {"none": 0, "relu": 1}[act],
-                                         stream_ptr(coords)), "corr_lookup_conv1x1")
+                                         ptr(slots) if slots is not None else None, stream_ptr(coords)),
+          "corr_lookup_conv1x1")
     return out

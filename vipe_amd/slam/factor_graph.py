@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from ..ext import slam_ext
-from .networks import AltCorrBlock, CorrBlock
+from .networks import AltCorrBlock, CorrBlock, CorrPool
 
 
 class FactorGraph:
@@ -62,7 +62,7 @@ class FactorGraph:
         pi, qi, _, pj, qj, _ = self.buffer.expand_edge_multiview(ii, jj)
         if self.incremental:
             corr = CorrBlock(self.buffer.fmaps[pi, qi][None], self.buffer.fmaps[pj, qj][None])
-            self.corr = corr if self.corr is None else self.corr.cat(corr)
+            self.corr = (CorrPool(capacity=max(64, self.max_factors + 16)) if self.corr is None else self.corr).cat(corr)
             xb = torch.zeros((ii.shape[0] * self.buffer.n_views, self.ht, self.wd, 320), dtype=torch.half,
                              device=self.device)
             xb[..., 0:128] = self.buffer.inps[pi, qi].permute(0, 2, 3, 1)
@@ -93,6 +93,8 @@ class FactorGraph:
         views = torch.arange(V, device=self.device)
         keep_x = (keep[:, None] * V + views).view(-1) if V > 1 else keep
         drop_x = (drop[:, None] * V + views).view(-1) if V > 1 else drop
+        keep_np = np.flatnonzero(~m)
+        keep_x_np = (keep_np[:, None] * V + np.arange(V)).reshape(-1) if V > 1 else keep_np
         if store:
             self.ii_inac = torch.cat([self.ii_inac, self.ii[drop]], 0)
             self.jj_inac = torch.cat([self.jj_inac, self.jj[drop]], 0)
@@ -100,7 +102,7 @@ class FactorGraph:
             self.weight_inac = torch.cat([self.weight_inac, self.weight[:, drop_x]], 1)
         self.ii, self.jj, self.age = self.ii[keep], self.jj[keep], self.age[keep]
         if self.corr is not None:
-            self.corr = self.corr[keep_x]
+            self.corr = self.corr[keep_x_np]  # host-side index: the pool only edits its slot vector
         if self.net_n is not None:
             self.net_n = self.net_n[keep_x]
         if self.xbuf is not None:

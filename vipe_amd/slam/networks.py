@@ -65,6 +65,139 @@ class CorrBlock:
         return vol.view(batch, num, ht, wd, ht, wd)
 
 
+class CorrPool:
+    """Edge-indexed store of correlation pyramids for a graph whose edges come and go every keyframe
+    (factor_graph.py:147-152 appends with `corr.cat`, :194-196 drops with `corr[~mask]` - each a copy of the whole
+    pyramid, 25 MB per edge).  Here the level buffers have spare capacity and edge e owns slot `slots[e]`: adding
+    writes only the new edges' volumes into free slots, removing only edits the slot vector, and the fused lookup
+    kernel follows the indirection.  Same call surface as CorrBlock (`cat`, `__getitem__`, `__call__`,
+    `lookup_nhwc`, `lookup_deferred`, `corr_pyramid`)."""
+
+    def __init__(self, num_levels=4, radius=3, capacity=64):
+        self.num_levels, self.radius, self.capacity = num_levels, radius, capacity
+        self.pool = None
+        self.slots = None        # int32 [E] on the device
+        self._slots_host = []    # the same, host side (edge bookkeeping never reads the device copy back)
+        self._free = []
+
+    def __len__(self):
+        return len(self._slots_host)
+
+    def _grow(self, like, need):
+        if self.pool is None:
+            cap = self.capacity
+            while cap < need:
+                cap *= 2
+            self.pool = [torch.empty((cap,) + tuple(lv.shape[1:]), dtype=lv.dtype, device=lv.device) for lv in like]
+            self._free = list(range(cap))
+            return
+        cap = new_cap = self.pool[0].shape[0]
+        while len(self._free) + (new_cap - cap) < need:
+            new_cap *= 2
+        if new_cap > cap:
+            self.pool = [torch.cat([p, torch.empty((new_cap - cap,) + tuple(p.shape[1:]), dtype=p.dtype, device=p.device)], 0)
+                         for p in self.pool]
+            self._free += list(range(cap, new_cap))
+
+    def cat(self, other):
+        for i in range(self.num_levels):
+            self.corr_pyramid[i] = torch.cat([self.corr_pyramid[i], other.corr_pyramid[i]], 0)
+        return self
+
+    def __getitem__(self, index):
+        for i in range(self.num_levels):
+            self.corr_pyramid[i] = self.corr_pyramid[i][index]
+        return self
+
+    @staticmethod
+    def corr(fmap1, fmap2):
+        """all-pairs correlation (droid_net.py:94-102): (fmap1/4)^T (fmap2/4) -> [B,num,ht,wd,ht,wd]"""
+        batch, num, dim, ht, wd = fmap1.shape
+        vol = droid_net_ext.corr_volume(fmap1.reshape(batch * num, dim, ht, wd), fmap2.reshape(batch * num, dim, ht, wd))
+        return vol.view(batch, num, ht, wd, ht, wd)
+
+
+class CorrPool:
+    """Edge-indexed store of correlation pyramids for a graph whose edges come and go every keyframe
+    (factor_graph.py:147-152 appends with `corr.cat`, :194-196 drops with `corr[~mask]` - each a copy of the whole
+    pyramid, 25 MB per edge).  Here the level buffers have spare capacity and edge e owns slot `slots[e]`: adding
+    writes only the new edges' volumes into free slots, removing only edits the slot vector, and the fused lookup
+    kernel follows the indirection.  Same call surface as CorrBlock (`cat`, `__getitem__`, `__call__`,
+    `lookup_nhwc`, `lookup_deferred`, `corr_pyramid`)."""
+
+    def __init__(self, num_levels=4, radius=3, capacity=64):
+        self.num_levels, self.radius, self.capacity = num_levels, radius, capacity
+        self.pool = None
+        self.slots = None        # int32 [E] on the device
+        self._slots_host = []    # the same, host side (edge bookkeeping never reads the device copy back)
+        self._free = []
+
+    def __len__(self):
+        return len(self._slots_host)
+
+    def _grow(self, like, need):
+        cap = self.capacity if self.pool is None else self.pool[0].shape[0]
+        new_cap = cap
+        while new_cap - (0 if self.pool is None else cap - len(self._free)) < need:
+            new_cap *= 2
+        if self.pool is None:
+            self.pool = [torch.empty((new_cap,) + tuple(lv.shape[1:]), dtype=lv.dtype, device=lv.device) for lv in like]
+            self._free = list(range(new_cap))
+        elif new_cap > cap:
+            self.pool = [torch.cat([p, torch.empty((new_cap - cap,) + tuple(p.shape[1:]), dtype=p.dtype, device=p.device)], 0)
+                         for p in self.pool]
+            self._free += list(range(cap, new_cap))
+
+    def cat(self, other):
+        """append the edges of a CorrBlock (its volumes are copied into free slots)"""
+        lv = other.corr_pyramid
+        k = lv[0].shape[0]
+        if self.pool is None or len(self._free) < k:
+            self._grow(lv, k)
+        ids = [self._free.pop(0) for _ in range(k)]
+        idt = torch.tensor(ids, dtype=torch.long, device=lv[0].device)
+        for p, l in zip(self.pool, lv):
+            p.index_copy_(0, idt, l)
+        self._slots_host += ids
+        new = idt.to(torch.int32)
+        self.slots = new if self.slots is None else torch.cat([self.slots, new], 0)
+        return self
+
+    def __getitem__(self, index):
+        """keep the edges at positions `index` (1-D integer array / tensor or boolean mask), in that order"""
+        import numpy as np
+        idx = index.detach().cpu().numpy() if torch.is_tensor(index) else np.asarray(index)
+        if idx.dtype == np.bool_:
+            idx = np.flatnonzero(idx)
+        kept = [self._slots_host[int(i)] for i in idx]
+        gone = set(self._slots_host) - set(kept)
+        self._free += sorted(gone)
+        self._slots_host = kept
+        self.slots = torch.tensor(kept, dtype=torch.int32, device=self.pool[0].device)
+        return self
+
+    @property
+    def corr_pyramid(self):
+        """materialised [E, ...] levels in edge order (reference layout; copies)"""
+        idx = self.slots.long()
+        return [p.index_select(0, idx) for p in self.pool]
+
+    def __call__(self, coords):
+        batch, num, ht, wd, _ = coords.shape
+        out = droid_net_ext.corr_pyramid_lookup(self.corr_pyramid, coords.reshape(batch * num, ht, wd, 2), self.radius)
+        return out.view(batch, num, -1, ht, wd)
+
+    def lookup_nhwc(self, coords, channel_stride=200):
+        return droid_net_ext.corr_pyramid_lookup_nhwc(self.corr_pyramid, coords, self.radius, channel_stride)
+
+    def lookup_deferred(self, coords):
+        lv = self.pool
+        if (self.num_levels == 4 and self.radius == 3 and lv[0].dtype == torch.float16 and lv[0].is_cuda
+                and (lv[0].shape[-1] >> 3) % 8 == 0 and (lv[0].shape[-2] >> 3) >= 1):
+            return ("lookup", lv, coords.contiguous(), self.slots)
+        return self.lookup_nhwc(coords)
+
+
 class AltCorrBlock:
     """Volume-free correlation (droid_net.py:121-176): pyramid of channels-last fmaps/4, looked up on the fly."""
 

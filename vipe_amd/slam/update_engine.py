@@ -172,7 +172,8 @@ class UpdateEngine:
         # first 1x1 convolution then run as ONE kernel and the [E,h,w,200] tensor never exists
         if isinstance(corr, tuple):
             from ..ext import droid_net_ext
-            droid_net_ext.corr_lookup_conv1x1(corr[1], corr[2], self.corr0.packed, self.corr0.bias, c1, act="relu")
+            droid_net_ext.corr_lookup_conv1x1(corr[1], corr[2], self.corr0.packed, self.corr0.bias, c1, act="relu",
+                                              slots=corr[3] if len(corr) > 3 else None)
         else:
             self._conv(self.corr0, corr, 0, E, H, W, y=c1, act="relu", cin=CORR_CH)
         self._conv(self.corr2, c1, 0, E, H, W, y=xbuf, y_coff=128, act="relu")
