@@ -1073,3 +1073,43 @@ def test_corr_pool_matches_corr_block_through_add_and_remove():
         droid_net_ext.corr_lookup_conv1x1(ref, coords, eng.corr0.packed, eng.corr0.bias, out_r, act="relu")
         assert torch.equal(out_p, out_r)
         assert torch.equal(pool.lookup_nhwc(coords), droid_net_ext.corr_pyramid_lookup_nhwc(ref, coords, 3, 200))
+
+
+def test_update_batch_merged_chunks_equal_reference_groups_of_eight(monkeypatch):
+    """The reference applies the operator per group of 8 source keyframes (factor_graph.py:337-343); merging the groups
+    into one chunk (the default here) must not change anything: GraphAgg only couples edges of the same source frame.
+    20 keyframes -> 3 groups; VIPE_AMD_BACKEND_CHUNK_EDGES=1 forces one group per chunk like the reference."""
+    from vipe_amd.slam.buffer import GraphBuffer
+    from vipe_amd.slam.factor_graph import FactorGraph
+    from vipe_amd.slam.networks import UpdateModule
+    N = 20
+
+    def run(chunk_edges):
+        if chunk_edges is None:
+            monkeypatch.delenv("VIPE_AMD_BACKEND_CHUNK_EDGES", raising=False)
+        else:
+            monkeypatch.setenv("VIPE_AMD_BACKEND_CHUNK_EDGES", str(chunk_edges))
+        g = make_graph(n=N, height=64, width=512, radius=2, seed=53)
+        buf = GraphBuffer(64, 512, buffer_size=N + 2, device=dev())
+        buf.n_frames = N
+        buf.poses[:N], buf.disps[:N, 0], buf.intrinsics[:] = T(g.poses), T(g.disps), T(g.intrinsics)
+        gen = torch.Generator().manual_seed(53)
+        buf.fmaps[:N, 0] = torch.randn(N, 128, 8, 64, generator=gen).half().to(dev())
+        buf.nets[:N, 0] = torch.randn(N, 128, 8, 64, generator=gen).tanh().half().to(dev())
+        buf.inps[:N, 0] = torch.randn(N, 128, 8, 64, generator=gen).relu().half().to(dev())
+        buf.masks[3, 0, :2] = True
+        torch.manual_seed(0)
+        graph = FactorGraph(UpdateModule().eval(), buf, dev(), max_factors=-1, incremental=False)
+        perm = np.random.default_rng(1).permutation(len(g.ii))  # edges not sorted by source frame
+        graph.add_factors(torch.from_numpy(g.ii[perm]), torch.from_numpy(g.jj[perm]))
+        graph.update_batch(itrs=2, steps=2, optimize_intrinsics=False, optimize_rig_rotation=False)
+        torch.cuda.synchronize()
+        return (graph.target.cpu().numpy(), graph.weight.cpu().numpy(), graph.net_n.float().cpu().numpy(),
+                graph.damping[:N].cpu().numpy(), buf.poses[:N].cpu().numpy(), buf.disps[:N, 0].cpu().numpy())
+
+    merged = run(None)
+    grouped = run(1)
+    # target / weight / hidden state / eta: the same kernels on the same rows; only the global-context mean inside a
+    # workgroup reduction and the BA's atomics may reorder float sums (fp16 state: ~1e-3 px on the targets, 1e-5 on the map)
+    for a, b, tol in zip(merged, grouped, (2e-3, 2e-3, 2e-3, 1e-4, 1e-4, 1e-4)):
+        assert a.shape == b.shape and np.abs(a - b).max() <= tol * max(1.0, np.abs(a).max()), (np.abs(a - b).max(), tol)

@@ -323,42 +323,76 @@ class FactorGraph:
             coords1, motn = slam_ext.reproject_motion_nhwc(buf.poses, buf.flattened_disps, buf.intrinsics, buf.rig,
                                                            P["pi"], P["qi"], P["pj"], P["qj"], P["di"],
                                                            self.target[0].contiguous(), camera=buf.camera_type)
-            s = 8
-            assert self.jj.max() >= self.ii.max()
-            for i in range(0, int(self.jj.max()) + 1, s):
-                v = (self.ii >= i) & (self.ii < i + s)
-                if not bool(v.any()):
+            # The reference walks the source keyframes in groups of 8 (factor_graph.py:337-343) to bound memory.  The
+            # operator couples edges only through GraphAgg's per-source-frame mean, so ANY partition that keeps every
+            # source frame's edges together gives the same result: with 288 GB of HBM the groups are merged until a
+            # chunk holds up to VIPE_AMD_BACKEND_CHUNK_EDGES edges (default 1024, ~34 GB of pyramids) - normally one chunk.
+            # Edge indices come from ONE read-back of (ii, jj); chunks are selected with index vectors, not masks.
+            ii_np, jj_np = self.ii.cpu().numpy(), self.jj.cpu().numpy()
+            assert jj_np.max() >= ii_np.max()
+            E_all = ii_np.shape[0]
+            max_edges = int(os.environ.get("VIPE_AMD_BACKEND_CHUNK_EDGES", "1024"))
+            cnt = np.bincount(ii_np)
+            groups, cur, cur_n = [], [], 0
+            for g0 in range(0, len(cnt), 8):  # the reference's groups of 8 source frames are the merge unit
+                n8 = int(cnt[g0:g0 + 8].sum())
+                if n8 == 0:
                     continue
-                v_exp = v.view(-1, 1).repeat(1, V).view(-1)
-                iis, jjs = self.ii[v], self.jj[v]
+                if cur and cur_n + n8 > max_edges:
+                    groups.append(cur)
+                    cur, cur_n = [], 0
+                cur.append(g0)
+                cur_n += n8
+            if cur:
+                groups.append(cur)
+            for grp in groups:
+                sel = np.flatnonzero(np.isin(ii_np // 8 * 8, grp))
+                whole = sel.shape[0] == E_all
+                if whole:
+                    iis, jjs = self.ii, self.jj
+                    take = lambda x, dim=0: x  # noqa: E731
+                else:
+                    idx = torch.from_numpy(sel).to(self.device)
+                    idx_x = (idx[:, None] * V + torch.arange(V, device=self.device)).view(-1) if V > 1 else idx
+                    iis, jjs = self.ii[idx], self.jj[idx]
+                    take = lambda x, dim=0: x.index_select(dim, idx_x)  # noqa: E731
                 pis, qis, dis, pjs, qjs, djs = buf.expand_edge_multiview(iis, jjs)
-                du, dixs = torch.unique(dis, return_inverse=True)
-                n = int(v_exp.sum())
+                dis_np = (ii_np[sel][:, None] * V + np.arange(V)).reshape(-1)
+                du_np, dixs_np = np.unique(dis_np, return_inverse=True)
+                du = torch.from_numpy(du_np).to(self.device)
+                dixs = torch.from_numpy(dixs_np.astype(np.int64)).to(self.device)
+                n = sel.shape[0] * V
+                c1 = take(coords1)
                 if use_volume:
                     vol = CorrBlock(buf.fmaps[pis, qis][None], buf.fmaps[pjs, qjs][None])
-                    corr_n = vol.lookup_deferred(coords1[v_exp])
+                    corr_n = vol.lookup_deferred(c1)
                     corr1 = None
                 else:
-                    corr1 = corr_op(coords1[None][:, v_exp], dis, djs)  # [1,n,196,h,w] fp32
+                    corr1 = corr_op(c1[None], dis, djs)  # [1,n,196,h,w] fp32
                     corr_n = torch.zeros((n, self.ht, self.wd, 200), dtype=torch.half, device=self.device)
                     corr_n[..., :196] = corr1[0].permute(0, 2, 3, 1)
                 xb = torch.empty((n, self.ht, self.wd, 320), dtype=torch.half, device=self.device)
                 xb[..., 0:128] = buf.inps[pis, qis].permute(0, 2, 3, 1)
                 if eng.backend == "hip":
-                    net, dw, eta, _ = eng.forward_nhwc(self.net_n[v_exp].contiguous(), xb, corr_n, motn[v_exp].contiguous(),
-                                                       ix=dixs, n_src=int(du.numel()))
+                    net, dw, eta, _ = eng.forward_nhwc(take(self.net_n).contiguous(), xb, corr_n, take(motn).contiguous(),
+                                                       ix=dixs, n_src=int(du_np.shape[0]))
                     delta, weight = dw[..., 0:2], dw[..., 2:4].clone()
                 else:
                     f_net, delta, weight, eta, _ = eng.forward(
-                        self.net_n[v_exp].permute(0, 3, 1, 2)[None], xb[..., 0:128].permute(0, 3, 1, 2)[None],
-                        corr1.half(), motn[v_exp].permute(0, 3, 1, 2)[None], ix=dixs, skip_upmask=True,
-                        n_src=int(du.numel()))
+                        take(self.net_n).permute(0, 3, 1, 2)[None], xb[..., 0:128].permute(0, 3, 1, 2)[None],
+                        corr1.half(), take(motn).permute(0, 3, 1, 2)[None], ix=dixs, skip_upmask=True,
+                        n_src=int(du_np.shape[0]))
                     net = f_net[0].permute(0, 2, 3, 1).contiguous()
                     delta, weight, eta = delta[0].float(), weight[0].float(), eta[0]
-                weight[buf.masks[pis, qis]] = 0.0
-                self.net_n[v_exp] = net
-                self.target[0, v_exp] = coords1[v_exp] + delta
-                self.weight[0, v_exp] = weight
+                weight = weight.masked_fill(buf.masks[pis, qis].unsqueeze(-1), 0.0)
+                if whole:
+                    self.net_n = net if net.data_ptr() != self.net_n.data_ptr() else net.clone()
+                    self.target[0] = c1 + delta
+                    self.weight[0] = weight
+                else:
+                    self.net_n[idx_x] = net
+                    self.target[0, idx_x] = c1 + delta
+                    self.weight[0, idx_x] = weight
                 self.damping[du] = eta
             E = self.target.shape[1]
             buf.bundle_adjustment(self.target.view(E, -1, 2), self.weight.view(E, -1, 2), self.damping, self.ii, self.jj,
