@@ -93,6 +93,43 @@ def cpu_baseline(seconds_budget=20.0):
     }
 
 
+def backend_mode(args, device, world, rank):
+    """Secondary figure: hot loop B of SURVEY 3.4 - `FactorGraph.update_batch(itrs=2, steps=1)` (reproject, correlation
+    volume build + lookup, flow-update operator over all E = 276 edges, one global BA with 2 GN iterations) on the
+    headline graph, one clip per GPU."""
+    import torch.distributed as dist
+
+    g, buf, graph = build_problem(device, args.keyframes, 384, 512, 3, args.extra_edges, args.conv, seed=1234 + rank)
+
+    def step():
+        graph.update_batch(itrs=2, steps=1, optimize_intrinsics=False, optimize_rig_rotation=False)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "backend update_batch calls/s, 512x384 48-KF graph", "value": world * args.steps / dt,
+            "unit": "calls/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16 (correlation, GRU) + f32 geometry/BA", "data": "synthetic",
+            "config": {"workload": f"update_batch(itrs=2, steps=1), E={int(graph.ii.numel())} edges, "
+                                   f"{args.keyframes} keyframes, one clip per GPU"}}))
+
+
 def video_mode(args, device, world, rank):
     """Secondary figure of SURVEY 8(d): frames/s of the keyframe frontend (frontend.py:78-167 mirror) on a synthetic
     512x384xN "video" in which every frame is a keyframe: per frame = motion filter on the RGB frame (feature encoder,
@@ -189,9 +226,10 @@ def main():
     ap.add_argument("--conv", default=os.environ.get("VIPE_AMD_CONV", "hip"), choices=["hip", "miopen"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-steps", type=int, default=2)
-    ap.add_argument("--mode", default="update", choices=["update", "video"],
+    ap.add_argument("--mode", default="update", choices=["update", "video", "backend"],
                     help="update: the headline metric (update iterations/s on the 48-keyframe graph); video: frames/s "
-                         "of the keyframe frontend on a synthetic video")
+                         "of the keyframe frontend on a synthetic video; backend: FactorGraph.update_batch calls/s "
+                         "(hot loop B: operator over all edges + 2 GN iterations of global BA) on the same graph")
     ap.add_argument("--frames", type=int, default=200)
     ap.add_argument("--video-features", action="store_true",
                     help="video mode: feed seeded feature maps instead of RGB frames (skips motion filter + encoders)")
@@ -215,6 +253,11 @@ def main():
 
     if args.mode == "video":
         video_mode(args, device, world, rank)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    if args.mode == "backend":
+        backend_mode(args, device, world, rank)
         if world > 1:
             dist.destroy_process_group()
         return
