@@ -193,6 +193,15 @@ def video_mode(args, device, world, rank):
     u0 = fe.n_updates
     for _ in range(N - fed):
         feed()
+    backend_edges = None
+    if args.with_backend:  # system.py:272-275: global BA over all keyframes, twice (fresh graph each time)
+        from vipe_amd.slam.backend import BackendArgs, SLAMBackend
+        be = SLAMBackend(um, buf, BackendArgs(), device)
+        torch.cuda.synchronize()
+        t_fe = time.perf_counter() - t0
+        be.run(7)
+        gb = be.run(BackendArgs().backend_iters, update_depth=False)
+        backend_edges = int(gb.ii.numel())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -211,6 +220,9 @@ def video_mode(args, device, world, rank):
             "config": {"workload": f"{N} synthetic keyframes per clip, frontend window <= 48 edges, 4+2 update iterations "
                                    f"per keyframe, one clip per GPU", "update_iterations": fe.n_updates - u0,
                        "keyframes_kept": int(buf.n_frames), "edges_final": int(fe.graph.ii.numel()),
+                       "global_ba": None if backend_edges is None else
+                       {"passes": "backend.run(7) + backend.run(24), 8 GN iterations per step", "edges": backend_edges,
+                        "frontend_seconds": t_fe, "backend_seconds": dt - t_fe},
                        "input": "feature maps (encoders skipped)" if args.video_features else
                                 "RGB frames: motion filter + feature / context encoders in the timed region",
                        "state_finite": finite}}))
@@ -231,6 +243,9 @@ def main():
                          "of the keyframe frontend on a synthetic video; backend: FactorGraph.update_batch calls/s "
                          "(hot loop B: operator over all edges + 2 GN iterations of global BA) on the same graph")
     ap.add_argument("--frames", type=int, default=200)
+    ap.add_argument("--with-backend", action="store_true",
+                    help="video mode: after the frontend pass also run the two global-BA passes of SLAMSystem.run "
+                         "(backend.run(7), backend.run(24): system.py:272-275) inside the timed region")
     ap.add_argument("--video-features", action="store_true",
                     help="video mode: feed seeded feature maps instead of RGB frames (skips motion filter + encoders)")
     ap.add_argument("--also-without-gate-hoist", action="store_true",

@@ -1113,3 +1113,41 @@ def test_update_batch_merged_chunks_equal_reference_groups_of_eight(monkeypatch)
     # workgroup reduction and the BA's atomics may reorder float sums (fp16 state: ~1e-3 px on the targets, 1e-5 on the map)
     for a, b, tol in zip(merged, grouped, (2e-3, 2e-3, 2e-3, 1e-4, 1e-4, 1e-4)):
         assert a.shape == b.shape and np.abs(a - b).max() <= tol * max(1.0, np.abs(a).max()), (np.abs(a - b).max(), tol)
+
+
+def test_backend_global_ba_pass():
+    """SLAMBackend.run (backend.py:73-117): fresh non-incremental graph with max_factors = 16 t, proximity edges with the
+    backend thresholds (the neighbourhood part is deterministic: 3 predecessors per keyframe, both directions), `steps`
+    passes of update_batch.  Perfect-geometry buffer: the global BA must keep poses / disparities finite and close."""
+    from vipe_amd.slam.backend import BackendArgs, SLAMBackend
+    from vipe_amd.slam.buffer import GraphBuffer
+    from vipe_amd.slam.networks import UpdateModule
+    N = 10
+    g = make_graph(n=N, height=64, width=512, radius=2, seed=61)
+    buf = GraphBuffer(64, 512, buffer_size=N + 2, device=dev())
+    buf.n_frames = N
+    buf.poses[:N], buf.disps[:N, 0], buf.intrinsics[:] = T(g.poses_gt, torch.float32), T(g.disps_gt, torch.float32), T(g.intrinsics)
+    gen = torch.Generator().manual_seed(61)
+    buf.fmaps[:N, 0] = torch.randn(N, 128, 8, 64, generator=gen).half().to(dev())
+    buf.nets[:N, 0] = torch.randn(N, 128, 8, 64, generator=gen).tanh().half().to(dev())
+    buf.inps[:N, 0] = torch.randn(N, 128, 8, 64, generator=gen).relu().half().to(dev())
+    torch.manual_seed(0)
+    be = SLAMBackend(UpdateModule().eval(), buf, BackendArgs(), dev())
+    graph = be.run(steps=2)
+    ii, jj = graph.ii.cpu().numpy(), graph.jj.cpu().numpy()
+    assert graph.max_factors == 16 * N and not graph.incremental
+    es = set(zip(ii.tolist(), jj.tolist()))
+    for i in range(N):
+        for j in range(max(i - 3, 0), i):
+            assert (i, j) in es and (j, i) in es
+    assert len(es) == len(ii)  # no repeated edge
+    assert tuple(graph.target.shape) == (1, len(ii), 8, 64, 2)
+    assert bool(torch.isfinite(buf.poses[:N]).all()) and bool(torch.isfinite(buf.disps[:N]).all())
+    assert float(buf.disps[:N].min()) >= 1e-3
+    assert torch.equal(buf.poses[0].cpu(), torch.from_numpy(g.poses_gt[0]).float())  # pose 0 is the gauge
+    # a single keyframe: the graph stays empty and the sensor depth is taken where present
+    buf1 = GraphBuffer(64, 512, buffer_size=2, device=dev())
+    buf1.n_frames = 1
+    buf1.disps_sens[0, 0, :4] = 0.5
+    g1 = SLAMBackend(UpdateModule().eval(), buf1, BackendArgs(), dev()).run(steps=1)
+    assert len(g1.ii) == 0 and float(buf1.disps[0, 0, :4].max()) == 0.5 and float(buf1.disps[0, 0, 4:].min()) == 1.0

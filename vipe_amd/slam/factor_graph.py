@@ -319,6 +319,11 @@ class FactorGraph:
         corr_op = None if use_volume else AltCorrBlock(buf.flattened_fmaps[None])
         P = self._edge_plan()
         V = buf.n_views
+        # The feature maps do not change during the `steps` passes: each chunk's correlation pyramid is built in the
+        # first pass and kept for the others while all of them fit VIPE_AMD_BACKEND_VOLUME_GB (default 160 of 288 GB).
+        vol_bytes = self.ii.shape[0] * V * (self.ht * self.wd) ** 2 * 2 * (1 + 1 / 4 + 1 / 16 + 1 / 64)
+        keep_vols = use_volume and steps > 1 and vol_bytes <= float(os.environ.get("VIPE_AMD_BACKEND_VOLUME_GB", "160")) * 2**30
+        vols = {}
         for _ in range(steps):
             coords1, motn = slam_ext.reproject_motion_nhwc(buf.poses, buf.flattened_disps, buf.intrinsics, buf.rig,
                                                            P["pi"], P["qi"], P["pj"], P["qj"], P["di"],
@@ -345,7 +350,7 @@ class FactorGraph:
                 cur_n += n8
             if cur:
                 groups.append(cur)
-            for grp in groups:
+            for gi, grp in enumerate(groups):
                 sel = np.flatnonzero(np.isin(ii_np // 8 * 8, grp))
                 whole = sel.shape[0] == E_all
                 if whole:
@@ -364,7 +369,11 @@ class FactorGraph:
                 n = sel.shape[0] * V
                 c1 = take(coords1)
                 if use_volume:
-                    vol = CorrBlock(buf.fmaps[pis, qis][None], buf.fmaps[pjs, qjs][None])
+                    vol = vols.get(gi)
+                    if vol is None:
+                        vol = CorrBlock(buf.fmaps[pis, qis][None], buf.fmaps[pjs, qjs][None])
+                        if keep_vols:
+                            vols[gi] = vol
                     corr_n = vol.lookup_deferred(c1)
                     corr1 = None
                 else:
