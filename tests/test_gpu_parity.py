@@ -1151,3 +1151,23 @@ def test_backend_global_ba_pass():
     buf1.disps_sens[0, 0, :4] = 0.5
     g1 = SLAMBackend(UpdateModule().eval(), buf1, BackendArgs(), dev()).run(steps=1)
     assert len(g1.ii) == 0 and float(buf1.disps[0, 0, :4].max()) == 0.5 and float(buf1.disps[0, 0, 4:].min()) == 1.0
+
+
+@pytest.mark.parametrize("intr", [False, True])
+def test_dense_ba_long_trajectory_band_exceeds_lds(intr):
+    """120 keyframes, radius-3 graph: the band of the 714-unknown reduced system (245 KB in fp64) exceeds the LDS, so the
+    blocked global-memory Cholesky (which still restricts its trailing update to the band) takes it.  HIP fp32 vs the
+    fp64 oracle."""
+    g = make_graph(n=120, height=96, width=128, radius=3, seed=17)
+    bk = dict(t0=1, t1=120, n_iters=2, pose_damping=1e-4, pose_ep=1e-2, motion_only=False, limited_disp=False,
+              optimize_intrinsics=intr)
+    p, d, k, info = run_hip_ba(g, g.intrinsics, "pinhole", bk)
+    E = len(g.ii)
+    op, od, ok_, _ = oba.bundle_adjustment(g.poses, g.disps[:, None], g.disps_sens[:, None], g.intrinsics,
+                                           ose3.se3_identity(1), g.target.reshape(E, -1, 2), g.weight.reshape(E, -1, 2),
+                                           g.eta[:, None], g.ii, g.jj, **bk)
+    assert info[0] == 119 and info[2] == 0
+    assert np.abs(p - op).max() <= 1e-4 * max(1.0, np.abs(op).max())
+    assert np.abs(d - od[:, 0]).max() <= 1e-4 * np.abs(od).max()
+    if intr:
+        assert np.abs(k - ok_).max() <= 1e-4 * np.abs(ok_).max()
