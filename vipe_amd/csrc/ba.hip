@@ -1502,8 +1502,11 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-__global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds_doubles) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
+// UPT_: trailing-update pair slots per thread, TWO: two band columns per lane (bands wider than one wave).  The
+// neighbourhood graphs of the headline configuration run the <2, false> instantiation (fewer slots to walk per step, one
+// pipelined load pass); the frontend's dense windows the <BAND_UPT, true> one.
+template <int UPT_, bool TWO>
+__device__ __forceinline__ void band_solve_body(const BAArgs& a, int lds_doubles, unsigned char* smem_raw) {
   double* const L = reinterpret_cast<double*>(smem_raw);
   const vipe_ba_params& prm = a.p;
   const BAWs& w = a.w;
@@ -1520,7 +1523,7 @@ __global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds
   const int RD0 = TL0 + ntail * (n + 1);
   const int need = RD0 + npr + 64;
   if (t == 0) w.info[5] = 0;
-  if (n == 0 || need > lds_doubles || npair > 21 + BAND_UPT * (BAND_T - 64) || PB + ntail > BAND_T || WBP > 128 || F > 2) {
+  if (n == 0 || need > lds_doubles || npair > 21 + UPT_ * (BAND_T - 64) || PB + ntail > BAND_T || WBP > (TWO ? 128 : 64) || F > 2) {
 #ifdef VIPE_BA_STAMPS
     if (t == 0) printf("band solve skipped: n %d need %d lds %d npair %d PB %d ntail %d F %d bandblk %d\n", n, need, lds_doubles, npair, PB, ntail, F, bandblk);
 #endif
@@ -1542,16 +1545,23 @@ __global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds
     // one band row (WB <= 64 doubles, contiguous in S) per wave and iteration; unrolled so that a dozen row loads are
     // in flight per wave (the loop is otherwise one L2 round trip per row)
     const int wv = t >> 6, ln = t & 63;
+    auto load_entry = [&](int r, int l2) {
+      const int c = 6 * (r / 6) - PB + l2;
+      double v = 0.0;
+      if (l2 < WB && c >= 0 && c <= r) {
+        v = S[(int64_t)r * ld + c];
+        if (c == r) v += (double)prm.pose_ep + (double)prm.pose_damping * (a.droid ? v : w.Hd[r]);  // DROID: geom_kernels.cu:1176
+      }
+      if (l2 < WBP) L[r * WBP + l2] = v;
+    };
+    if constexpr (!TWO) {  // neighbourhood graphs: one lane per band column, a dozen row loads in flight per wave
 #pragma unroll 12
-    for (int r = wv; r < npr; r += BAND_T / 64) {
-      for (int l2 = ln; l2 < WBP; l2 += 64) {  // one pass for the neighbourhood graphs (WBP <= 64), two for dense windows
-        const int c = 6 * (r / 6) - PB + l2;
-        double v = 0.0;
-        if (l2 < WB && c >= 0 && c <= r) {
-          v = S[(int64_t)r * ld + c];
-          if (c == r) v += (double)prm.pose_ep + (double)prm.pose_damping * (a.droid ? v : w.Hd[r]);  // DROID: geom_kernels.cu:1176
-        }
-        L[r * WBP + l2] = v;
+      for (int r = wv; r < npr; r += BAND_T / 64) load_entry(r, ln);
+    } else {  // dense windows: two band columns per lane
+#pragma unroll 6
+      for (int r = wv; r < npr; r += BAND_T / 64) {
+        load_entry(r, ln);
+        load_entry(r, ln + 64);
       }
     }
   }
@@ -1574,7 +1584,7 @@ __global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds
     else { prow_off = TL0 + (t - PB) * (n + 1); prow_str = 6; }
   }
   // update: pair index t + BAND_T * slot (slot < UPT) -> one (a, b) pair, b <= a: pose-pose, tail-pose, tail-tail
-  constexpr int UPT = BAND_UPT;
+  constexpr int UPT = UPT_;
   int uA[UPT], uB[UPT], uD[UPT], sA[UPT], sB[UPT], sD[UPT], u_ia[UPT], u_ib[UPT];
   bool has_pair[UPT];
 #pragma unroll
@@ -1735,12 +1745,13 @@ __global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds
       double Lk[6][6], rp[6], lc[6], lc2[6];
       const int rt = j0 - PB + t, rt2 = rt + 64;  // second column for bands wider than one wave (PB > 64)
       const bool upd = t < PB && rt >= 0;
-      const bool upd2 = t + 64 < PB && rt2 >= 0;
+      const bool upd2 = TWO && t + 64 < PB && rt2 >= 0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         rp[i] = rdall[j0 + i];
         lc[i] = upd ? L[(j0 + i) * WBP + t] : 0.0;
-        lc2[i] = upd2 ? L[(j0 + i) * WBP + t + 64] : 0.0;
+        if constexpr (TWO) lc2[i] = upd2 ? L[(j0 + i) * WBP + t + 64] : 0.0;
+        else lc2[i] = 0.0;
 #pragma unroll
         for (int j = 0; j < i; ++j) Lk[i][j] = Dk[i * WBP + j];
       }
@@ -1764,7 +1775,7 @@ __global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds
         for (int j = 1; j < 6; ++j) sacc += lc[j] * x[j];
         y[rt] -= sacc;
       }
-      if (upd2) {
+      if (TWO && upd2) {
         double sacc = lc2[0] * x[0];
 #pragma unroll
         for (int j = 1; j < 6; ++j) sacc += lc2[j] * x[j];
@@ -1789,6 +1800,17 @@ __global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds
   __syncthreads();
   apply_retraction(a, t, BAND_T, n_free);
   SOLVE_STAMP(5);
+}
+
+__global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds_doubles) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const BAWs& w = a.w;
+  const int n = w.info[3], n_free = w.info[0], bandblk = w.info[4];
+  const int ntail = n - 6 * n_free + 1, F = ntail - 1;
+  const int PB = 6 * bandblk;
+  const int npair = PB * (PB + 1) / 2 + ntail * PB + (F == 0 ? 0 : (F == 1 ? 2 : 5));
+  if (PB + 7 > 64 || npair > 21 + 2 * (BAND_T - 64)) band_solve_body<BAND_UPT, true>(a, lds_doubles, smem_raw);
+  else band_solve_body<2, false>(a, lds_doubles, smem_raw);
 }
 
 // ------------------------------------------------------------------------------------------------ solve
