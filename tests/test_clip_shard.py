@@ -103,3 +103,33 @@ def test_pose_and_intrinsics_artifacts_round_trip(tmp_path):
            ClipResult(4, torch.zeros(0, 7), torch.zeros(4), ok=False)]
     assert artifacts.save_clip_results(str(tmp_path / "out"), res) == ["clip_00003"]
     assert np.allclose(artifacts.read_pose_artifacts(str(tmp_path / "out" / "pose" / "clip_00003.npz"))[1], ref, atol=1e-5)
+
+
+def test_corr_pool_slot_bookkeeping_on_host():
+    """CorrPool (vipe_amd/slam/networks.py): slots are handed out, released and reused without moving the level buffers;
+    `corr_pyramid` materialises the edge-ordered levels.  Pure tensor bookkeeping - runs on CPU tensors."""
+    import types
+    import numpy as np
+    from vipe_amd.slam.networks import CorrPool
+
+    def block(n, tag):
+        lv = [torch.full((n, 2, 2, 4 >> i, 4 >> i), float(tag), dtype=torch.float16) + torch.arange(n).view(n, 1, 1, 1, 1)
+              for i in range(3)]
+        return types.SimpleNamespace(corr_pyramid=lv)
+
+    pool = CorrPool(num_levels=3, capacity=4)
+    pool.cat(block(3, 10))                      # edges 0,1,2 -> slots 0,1,2
+    assert pool._slots_host == [0, 1, 2] and pool._free == [3] and len(pool) == 3
+    pool = pool[np.array([0, 2])]               # drop edge 1 -> slot 1 is free again
+    assert pool._slots_host == [0, 2] and sorted(pool._free) == [1, 3]
+    pool.cat(block(2, 20))                      # reuses slots 1 and 3
+    assert pool._slots_host[:2] == [0, 2] and sorted(pool._slots_host[2:]) == [1, 3] and pool._free == []
+    pool.cat(block(3, 30))                      # grows: capacity doubles until 3 more fit
+    assert pool.pool[0].shape[0] == 8 and pool._slots_host[-3:] == [4, 5, 6] and pool._free == [7]
+    want = [10, 12, 20, 21, 30, 31, 32]
+    for lv in pool.corr_pyramid:
+        assert lv.shape[0] == 7 and [float(x) for x in lv[:, 0, 0, 0, 0]] == want
+    assert pool.slots.dtype == torch.int32 and pool.slots.tolist() == pool._slots_host
+    pool = pool[torch.tensor([True, False, True, False, True, False, True])]  # boolean masks work too
+    assert [float(x) for x in pool.corr_pyramid[0][:, 0, 0, 0, 0]] == [10, 20, 30, 32]
+    assert len(pool._free) == 4 and set(pool._free).isdisjoint(pool._slots_host) and len(set(pool._slots_host)) == 4

@@ -62,7 +62,7 @@ def test_encoder_conv_against_torch_fp32(k, stride, cin, cout, mode):
                               ptr(res) if res is not None else None, ptr(y), ptr(out_stats), B, H, W, cin, cout, k, stride,
                               relu, 0, -1, stream_ptr(x)), "vipe_enc_conv")
     got = y.permute(0, 3, 1, 2).float()
-    scale = float(ref.abs().max())
+    scale = float(ref.detach().abs().max())
     assert float((got - ref).abs().max()) < 4e-3 * scale
     if mode != "residual":  # statistics are those of the raw fp16 outputs
         st = _stats_of(y)
