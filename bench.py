@@ -243,6 +243,8 @@ def main():
                          "of the keyframe frontend on a synthetic video; backend: FactorGraph.update_batch calls/s "
                          "(hot loop B: operator over all edges + 2 GN iterations of global BA) on the same graph")
     ap.add_argument("--frames", type=int, default=200)
+    ap.add_argument("--no-hipgraph", action="store_true",
+                    help="update mode: time eager launches instead of replaying the captured two-step HIP graph")
     ap.add_argument("--with-backend", action="store_true",
                     help="video mode: after the frontend pass also run the two global-BA passes of SLAMSystem.run "
                          "(backend.run(7), backend.run(24): system.py:272-275) inside the timed region")
@@ -291,11 +293,43 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # The update iteration has no host read-back and no shape that changes from step to step, so TWO consecutive steps
+    # (the hidden state ping-pongs between two buffers) are captured once into a HIP graph and the timed region replays
+    # it: the same kernels on the same stream, minus the ~45 Python / ctypes launches per step - which keeps the figure
+    # independent of host jitter (eight ranks share one host's cores in the multi-GPU run; back-to-back runs on one box
+    # lost up to 15 % to slow launch loops with identical kernel times).  `--no-hipgraph` times eager launches.
+    launch, cg = "eager", None
+    if not args.no_hipgraph and args.steps >= 2:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):  # allocate everything the two steps need outside the capture
+                step()
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            cg = torch.cuda.CUDAGraph()
+            # thread_local: the RCCL watchdog thread of a multi-GPU run may touch the runtime while this thread captures
+            with torch.cuda.graph(cg, capture_error_mode="thread_local"):
+                step()
+                step()
+            torch.cuda.synchronize()
+            cg.replay()  # one untimed replay
+            launch = "hipgraph (2 steps per replay)"
+        except Exception as e:  # noqa: BLE001 - fall back to eager launches and say so
+            cg = None
+            launch = f"eager (graph capture failed: {type(e).__name__})"
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    if cg is not None:
+        for _ in range(args.steps // 2):
+            cg.replay()
+        if args.steps % 2:
+            step()
+    else:
+        for _ in range(args.steps):
+            step()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -380,7 +414,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"configs[2]-shaped: 512x384, {args.keyframes}-keyframe factor graph, E={E} edges "
                                    f"(radius-3 bidirectional), 3 GN iterations per update, one clip per GPU",
-                       "conv_backend": args.conv, "parallelism": f"clip-sharded x{world}",
+                       "conv_backend": args.conv, "parallelism": f"clip-sharded x{world}", "launch": launch,
                        "gate_context": "context-feature part of the GRU gates computed once per edge (at add_factors, "
                                        "like the correlation volume), not per iteration"
                                        if getattr(graph, "pgate", None) is not None else "recomputed every iteration"},

@@ -691,7 +691,7 @@ def test_add_proximity_factors_on_device_buffer():
     ref.device, ref.cross_view, ref.max_factors = torch.device("cpu"), False, 64
     ref.ii = ref.jj = ref.ii_inac = ref.jj_inac = torch.zeros(0, dtype=torch.long)
     out = {}
-    ref.add_factors = lambda a, b, remove=False: out.update(e=torch.stack([a, b], 1).numpy())
+    ref.add_factors = lambda a, b, remove=False: out.update(e=np.stack([np.asarray(a), np.asarray(b)], 1))
     ref.add_proximity_factors(t0=0, t1=0, rad=1, nms=1, beta=0.25, thresh=1e3, remove=False)
     assert len(got) > 2 * (n - 1) and np.array_equal(got, out["e"])
 

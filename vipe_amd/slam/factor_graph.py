@@ -39,26 +39,45 @@ class FactorGraph:
         self.target_inac = torch.zeros([1, 0, ht, wd, 2], device=device, dtype=torch.float)
         self.weight_inac = torch.zeros([1, 0, ht, wd, 2], device=device, dtype=torch.float)
         self._plan = None
+        self._h = None  # host mirror of the integer edge state (ii, jj, age, ii_inac, jj_inac), see host_edges()
+
+    def host_edges(self):
+        """Host-side copy of the integer edge bookkeeping {ii, jj, age, ii_inac, jj_inac} (numpy int64).  Every method
+        of this class that changes the edge lists updates the mirror alongside the device tensors, so the scheduling
+        logic around the update iteration (duplicate filtering, suppression, age eviction, plan building) reads no
+        device memory back.  If the tensors were replaced from outside, the mirror is rebuilt from them (one read-back)."""
+        h = getattr(self, "_h", None)
+        age = getattr(self, "age", None)
+        if (h is None or h["ii"].shape[0] != self.ii.shape[0] or h["ii_inac"].shape[0] != self.ii_inac.shape[0]
+                or (age is not None and h["age"].shape[0] != age.shape[0])):
+            h = {k: getattr(self, k).detach().cpu().numpy().astype(np.int64).copy() for k in ("ii", "jj", "ii_inac", "jj_inac")}
+            h["age"] = age.detach().cpu().numpy().astype(np.int64).copy() if age is not None else np.zeros_like(h["ii"])
+            self._h = h
+        return h
 
     def _filter_repeated_edges(self, ii, jj):
-        """factor_graph.py:96-108 (one D2H copy instead of a .item() per edge)."""
-        have = set(zip(self.ii.tolist(), self.jj.tolist())) | set(zip(self.ii_inac.tolist(), self.jj_inac.tolist()))
-        keep = torch.tensor([(i, j) not in have for i, j in zip(ii.tolist(), jj.tolist())], dtype=torch.bool,
-                            device=ii.device)
+        """factor_graph.py:96-108 on the host mirror (the reference pays a .item() per edge).  ii, jj: numpy."""
+        h = self.host_edges()
+        have = set(zip(h["ii"].tolist(), h["jj"].tolist())) | set(zip(h["ii_inac"].tolist(), h["jj_inac"].tolist()))
+        keep = np.array([(i, j) not in have for i, j in zip(ii.tolist(), jj.tolist())], dtype=bool)
         return ii[keep], jj[keep]
 
     @torch.no_grad()
     def add_factors(self, ii, jj, remove=False):
         """factor_graph.py:119-173."""
-        ii = torch.as_tensor(ii, dtype=torch.long, device=self.device)
-        jj = torch.as_tensor(jj, dtype=torch.long, device=self.device)
-        ii, jj = self._filter_repeated_edges(ii, jj)
-        if ii.shape[0] == 0:
+        ii_h = (ii.detach().cpu().numpy() if torch.is_tensor(ii) else np.asarray(ii)).astype(np.int64).reshape(-1)
+        jj_h = (jj.detach().cpu().numpy() if torch.is_tensor(jj) else np.asarray(jj)).astype(np.int64).reshape(-1)
+        ii_h, jj_h = self._filter_repeated_edges(ii_h, jj_h)
+        if ii_h.shape[0] == 0:
             return
-        if (self.max_factors > 0 and self.ii.shape[0] + ii.shape[0] > self.max_factors and self.corr is not None
+        if (self.max_factors > 0 and self.ii.shape[0] + ii_h.shape[0] > self.max_factors and self.corr is not None
                 and remove):
-            ix = torch.arange(len(self.age))[torch.argsort(self.age).cpu()]
-            self.rm_factors(ix >= self.max_factors - ii.shape[0], store=True)
+            # factor_graph.py:136-139 (the reference's `arange[argsort(age)]` is the permutation itself; torch's sort
+            # leaves the order of equal ages unspecified - the stable order is used here)
+            ix = np.argsort(self.host_edges()["age"], kind="stable")
+            self.rm_factors(ix >= self.max_factors - ii_h.shape[0], store=True)
+        ii = torch.from_numpy(ii_h).to(self.device)
+        jj = torch.from_numpy(jj_h).to(self.device)
         pi, qi, _, pj, qj, _ = self.buffer.expand_edge_multiview(ii, jj)
         if self.incremental:
             corr = CorrBlock(self.buffer.fmaps[pi, qi][None], self.buffer.fmaps[pj, qj][None])
@@ -73,6 +92,9 @@ class FactorGraph:
                 self.pgate = pg if self.pgate is None else torch.cat([self.pgate, pg], 0)
         target, _ = self.buffer.reproject_dense_disp(ii, jj)
         target = target[None]
+        h = self.host_edges()
+        h["ii"], h["jj"] = np.concatenate([h["ii"], ii_h]), np.concatenate([h["jj"], jj_h])
+        h["age"] = np.concatenate([h["age"], np.zeros_like(ii_h)])
         self.ii = torch.cat([self.ii, ii], 0)
         self.jj = torch.cat([self.jj, jj], 0)
         self.age = torch.cat([self.age, torch.zeros_like(ii)], 0)
@@ -86,7 +108,12 @@ class FactorGraph:
     def rm_factors(self, mask, store=False):
         """factor_graph.py:175-202.  The mask is read back ONCE; every tensor is then compacted with the same index
         vectors (boolean-mask indexing would synchronise per tensor)."""
-        m = mask.detach().cpu().numpy().astype(bool)
+        m = (mask.detach().cpu().numpy() if torch.is_tensor(mask) else np.asarray(mask)).astype(bool)
+        h = self.host_edges()
+        if store:
+            h["ii_inac"] = np.concatenate([h["ii_inac"], h["ii"][m]])
+            h["jj_inac"] = np.concatenate([h["jj_inac"], h["jj"][m]])
+        h["ii"], h["jj"], h["age"] = h["ii"][~m], h["jj"][~m], h["age"][~m]
         V = self.buffer.n_views
         keep = torch.from_numpy(np.flatnonzero(~m)).to(self.device)
         drop = torch.from_numpy(np.flatnonzero(m)).to(self.device)
@@ -131,14 +158,12 @@ class FactorGraph:
         the host exactly as the reference's Python does (which instead pays one `.item()` sync per candidate)."""
         assert t0 >= t1, "t0 should be a subset of t1"
         t = self.buffer.n_frames
-        ix = torch.arange(t0, t, device=self.device)
-        jx = torch.arange(t1, t, device=self.device)
-        ii, jj = torch.meshgrid(ix, jx, indexing="ij")
-        ii, jj = ii.reshape(-1), jj.reshape(-1)
-        if ii.numel() == 0:
+        iin, jjn = np.meshgrid(np.arange(t0, t, dtype=np.int64), np.arange(t1, t, dtype=np.int64), indexing="ij")
+        iin, jjn = iin.reshape(-1), jjn.reshape(-1)
+        if iin.size == 0:
             return
+        ii, jj = torch.from_numpy(iin).to(self.device), torch.from_numpy(jjn).to(self.device)
         d = self.buffer.frame_distance_dense_disp(ii, jj, beta=beta).mean(-1).cpu().numpy().astype(np.float32)
-        iin, jjn = ii.cpu().numpy(), jj.cpu().numpy()
         nj = t - t1
 
         def suppress(i, j):
@@ -154,8 +179,9 @@ class FactorGraph:
 
         # edges already in the graph (active + inactive): the same suppression, all edges at once per window offset
         D = d.reshape(t - t0, nj)  # view of d
-        I = np.concatenate([self.ii.cpu().numpy(), self.ii_inac.cpu().numpy()]).astype(np.int64)
-        J = np.concatenate([self.jj.cpu().numpy(), self.jj_inac.cpu().numpy()]).astype(np.int64)
+        h = self.host_edges()
+        I = np.concatenate([h["ii"], h["ii_inac"]])
+        J = np.concatenate([h["jj"], h["jj_inac"]])
         if I.size:
             lim = np.maximum(np.minimum(np.abs(I - J) - 2, nms), 0)
             for di in range(-nms, nms + 1):
@@ -185,16 +211,19 @@ class FactorGraph:
             suppress_nms(i, j)
         if len(es) == 0:
             return
-        e = torch.as_tensor(es, device=self.device)
+        e = np.asarray(es, dtype=np.int64)
         self.add_factors(e[:, 0], e[:, 1], remove)
 
     @torch.no_grad()
     def rm_second_newest_keyframe(self, ix):
         """factor_graph.py:204-228: drop keyframe ix (= n_frames - 2) from the buffer and the graph."""
         self.buffer.remove_second_newest(ix)
-        m = ((self.ii_inac == ix) | (self.jj_inac == ix)).cpu().numpy()  # one readback; no per-tensor mask syncs below
+        h = self.host_edges()
+        m = (h["ii_inac"] == ix) | (h["jj_inac"] == ix)
         self.ii_inac = self.ii_inac - (self.ii_inac >= ix).long()
         self.jj_inac = self.jj_inac - (self.jj_inac >= ix).long()
+        h["ii_inac"] = h["ii_inac"] - (h["ii_inac"] >= ix)
+        h["jj_inac"] = h["jj_inac"] - (h["jj_inac"] >= ix)
         if m.any():
             V = self.buffer.n_views
             keep = torch.from_numpy(np.flatnonzero(~m)).to(self.device)
@@ -202,9 +231,12 @@ class FactorGraph:
             self.ii_inac, self.jj_inac = self.ii_inac[keep], self.jj_inac[keep]
             self.target_inac = self.target_inac[:, keep_x]
             self.weight_inac = self.weight_inac[:, keep_x]
-        m = (self.ii == ix) | (self.jj == ix)
+            h["ii_inac"], h["jj_inac"] = h["ii_inac"][~m], h["jj_inac"][~m]
+        m = (h["ii"] == ix) | (h["jj"] == ix)
         self.ii = self.ii - (self.ii >= ix).long()
         self.jj = self.jj - (self.jj >= ix).long()
+        h["ii"] = h["ii"] - (h["ii"] >= ix)
+        h["jj"] = h["jj"] - (h["jj"] >= ix)
         self.rm_factors(m, store=False)
 
     def get_edges_np(self):
@@ -236,12 +268,22 @@ class FactorGraph:
         torch.unique sync, on every update: factor_graph.py:267-268)."""
         if self._plan is None:
             pi, qi, di, pj, qj, _ = self.buffer.expand_edge_multiview(self.ii, self.jj)
-            du, dix = torch.unique(di, return_inverse=True)
+            h = self.host_edges()
+            V = self.buffer.n_views
+            di_h = (h["ii"][:, None] * V + np.arange(V)).reshape(-1)  # = di for edges that are not cross-view self edges
+            if self.cross_view or V > 1:
+                du, dix = torch.unique(di, return_inverse=True)  # multi-view: take the expansion as computed on the device
+                n_src = int(du.numel())
+            else:
+                du_h, dix_h = np.unique(di_h, return_inverse=True)
+                du = torch.from_numpy(du_h).to(self.device)
+                dix = torch.from_numpy(dix_h.astype(np.int64)).to(self.device)
+                n_src = int(du_h.shape[0])
             from .update_engine import segment_csr
-            self._plan = dict(pi=pi, qi=qi, di=di, pj=pj, qj=qj, du=du, dix=dix, n_src=int(du.numel()),
-                              csr=segment_csr(dix, int(du.numel())),
-                              t0=int(max(1, self.ii.min().item() + 1)),
-                              t1=int(max(self.ii.max().item(), self.jj.max().item()) + 1))
+            self._plan = dict(pi=pi, qi=qi, di=di, pj=pj, qj=qj, du=du, dix=dix, n_src=n_src,
+                              csr=segment_csr(dix, n_src),
+                              t0=int(max(1, h["ii"].min() + 1)),
+                              t1=int(max(h["ii"].max(), h["jj"].max()) + 1))
         return self._plan
 
     @torch.no_grad()
@@ -300,6 +342,8 @@ class FactorGraph:
                               t1 if not fixed_motion else t0, itrs, 1e-3, 0.1, motion_only, limited_disp, False, False,
                               plan=plan)
         self.age += 1
+        if getattr(self, "_h", None) is not None and self._h["age"].shape[0] == self.age.shape[0]:
+            self._h["age"] += 1
 
     @torch.no_grad()
     def update_batch(self, itrs, steps, optimize_intrinsics, optimize_rig_rotation, solver_verbose=False):

@@ -54,7 +54,7 @@ class SLAMFrontend:
         a = self.args
         self.t1 += 1
         if self.graph.corr is not None:
-            self.graph.rm_factors(self.graph.age > self.max_age, store=True)
+            self.graph.rm_factors(self.graph.host_edges()["age"] > self.max_age, store=True)  # host mirror: no read-back
         self.graph.add_proximity_factors(self.t1 - 5, max(self.t1 - a.frontend_window, 0), rad=a.frontend_radius,
                                          nms=a.frontend_nms, thresh=a.frontend_thresh, beta=a.beta, remove=True)
         self._iterate(self.iters1)
@@ -85,7 +85,7 @@ class SLAMFrontend:
         for v in range(self.video.n_views):
             self.video.disps[self.t1, v] = self.video.disps[self.t1 - 4:self.t1, v].mean()
         self.is_initialized = True
-        self.graph.rm_factors(self.graph.ii < a.warmup - 4, store=True)
+        self.graph.rm_factors(self.graph.host_edges()["ii"] < a.warmup - 4, store=True)
 
     def run(self):
         """frontend.py:157-167: call after every keyframe appended to the buffer."""
