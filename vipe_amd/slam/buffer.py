@@ -92,11 +92,20 @@ class GraphBuffer:
         """buffer.py:373-525, in place on self.poses / self.disps (/ self.intrinsics).  `plan` = (pi, qi, di, pj, qj)
         of `expand_edge_multiview(ii, jj)` when the caller already holds it (the reference re-expands every call)."""
         assert t0 <= t1
-        pi, qi, di, pj, qj = plan if plan is not None else self.expand_edge_multiview(ii, jj)[:5]
-        n_poses = max(self.n_frames, int(t1))
+        base = 0
+        if plan is not None and len(plan) == 6:
+            # (pi, qi, di, pj, qj, base): indices already relative to keyframe `base`, the oldest one any term touches.
+            # The library then sees only the buffer rows from `base` on: its per-frame launches (grid.y = frames) do
+            # not grow with the length of the video, only with the window the edges span.
+            pi, qi, di, pj, qj, base = plan
+        else:
+            pi, qi, di, pj, qj = plan if plan is not None else self.expand_edge_multiview(ii, jj)[:5]
+        V = self.n_views
+        n_poses = max(self.n_frames, int(t1)) - base
         return slam_ext.dense_ba(
-            self.poses, self.flattened_disps, self.flattened_disps_sens, self.intrinsics, self.rig,
-            target.contiguous(), weight.contiguous(), disp_damping.contiguous(), pi, qi, pj, qj, di, t0, t1, n_iters,
+            self.poses[base:], self.flattened_disps[base * V:], self.flattened_disps_sens[base * V:], self.intrinsics,
+            self.rig, target.contiguous(), weight.contiguous(), disp_damping[base * V:].contiguous(), pi, qi, pj, qj, di,
+            max(int(t0) - base, 0), max(int(t1) - base, 0), n_iters,
             pose_damping, pose_ep, motion_only, limited_disp, optimize_intrinsics, optimize_rig_rotation,
             camera=self.camera_type, alpha=self.ba_config.dense_disp_alpha, n_poses=n_poses, want_info=verbose)
 

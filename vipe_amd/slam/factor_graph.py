@@ -57,10 +57,20 @@ class FactorGraph:
 
     def _filter_repeated_edges(self, ii, jj):
         """factor_graph.py:96-108 on the host mirror (the reference pays a .item() per edge).  ii, jj: numpy."""
-        h = self.host_edges()
-        have = set(zip(h["ii"].tolist(), h["jj"].tolist())) | set(zip(h["ii_inac"].tolist(), h["jj_inac"].tolist()))
+        have = self._edge_set()
         keep = np.array([(i, j) not in have for i, j in zip(ii.tolist(), jj.tolist())], dtype=bool)
         return ii[keep], jj[keep]
+
+    def _edge_set(self):
+        """{(i, j)} of all active + inactive edges, kept incrementally (the inactive list grows with the video: rebuilding
+        the set on every call is O(length of the video) of Python per keyframe).  Rebuilt when it is out of step."""
+        h = self.host_edges()
+        n = h["ii"].shape[0] + h["ii_inac"].shape[0]
+        have = getattr(self, "_have", None)
+        if have is None or len(have) != n:
+            have = set(zip(h["ii"].tolist(), h["jj"].tolist())) | set(zip(h["ii_inac"].tolist(), h["jj_inac"].tolist()))
+            self._have = have
+        return have
 
     @torch.no_grad()
     def add_factors(self, ii, jj, remove=False):
@@ -93,6 +103,7 @@ class FactorGraph:
         target, _ = self.buffer.reproject_dense_disp(ii, jj)
         target = target[None]
         h = self.host_edges()
+        self._edge_set().update(zip(ii_h.tolist(), jj_h.tolist()))
         h["ii"], h["jj"] = np.concatenate([h["ii"], ii_h]), np.concatenate([h["jj"], jj_h])
         h["age"] = np.concatenate([h["age"], np.zeros_like(ii_h)])
         self.ii = torch.cat([self.ii, ii], 0)
@@ -113,6 +124,8 @@ class FactorGraph:
         if store:
             h["ii_inac"] = np.concatenate([h["ii_inac"], h["ii"][m]])
             h["jj_inac"] = np.concatenate([h["jj_inac"], h["jj"][m]])
+        elif getattr(self, "_have", None) is not None:
+            self._have.difference_update(zip(h["ii"][m].tolist(), h["jj"][m].tolist()))
         h["ii"], h["jj"], h["age"] = h["ii"][~m], h["jj"][~m], h["age"][~m]
         V = self.buffer.n_views
         keep = torch.from_numpy(np.flatnonzero(~m)).to(self.device)
@@ -125,8 +138,7 @@ class FactorGraph:
         if store:
             self.ii_inac = torch.cat([self.ii_inac, self.ii[drop]], 0)
             self.jj_inac = torch.cat([self.jj_inac, self.jj[drop]], 0)
-            self.target_inac = torch.cat([self.target_inac, self.target[:, drop_x]], 1)
-            self.weight_inac = torch.cat([self.weight_inac, self.weight[:, drop_x]], 1)
+            self._append_inactive(self.target[:, drop_x], self.weight[:, drop_x])
         self.ii, self.jj, self.age = self.ii[keep], self.jj[keep], self.age[keep]
         if self.corr is not None:
             self.corr = self.corr[keep_x_np]  # host-side index: the pool only edits its slot vector
@@ -218,6 +230,7 @@ class FactorGraph:
     def rm_second_newest_keyframe(self, ix):
         """factor_graph.py:204-228: drop keyframe ix (= n_frames - 2) from the buffer and the graph."""
         self.buffer.remove_second_newest(ix)
+        self._have = None  # frame indices shift: the edge set is rebuilt on next use
         h = self.host_edges()
         m = (h["ii_inac"] == ix) | (h["jj_inac"] == ix)
         self.ii_inac = self.ii_inac - (self.ii_inac >= ix).long()
@@ -286,6 +299,30 @@ class FactorGraph:
                               t1=int(max(h["ii"].max(), h["jj"].max()) + 1))
         return self._plan
 
+    def _append_inactive(self, t_new, w_new):
+        """target_inac / weight_inac grow for the whole video (factor_graph.py:184-189 concatenates, i.e. copies the
+        whole store, on every eviction): append into buffers with spare capacity instead; the attributes stay views."""
+        n, k = self.target_inac.shape[1], t_new.shape[1]
+        cap = getattr(self, "_inac_cap", None)
+        if cap is None or cap[0].shape[1] < n + k or cap[0].data_ptr() != self.target_inac.data_ptr():
+            size = max(2 * (n + k), 256)
+            cap = tuple(torch.empty((1, size) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+                        for x in (self.target_inac, self.weight_inac))
+            cap[0][:, :n] = self.target_inac
+            cap[1][:, :n] = self.weight_inac
+            self._inac_cap = cap
+        cap[0][:, n:n + k] = t_new
+        cap[1][:, n:n + k] = w_new
+        self.target_inac, self.weight_inac = cap[0][:, :n + k], cap[1][:, :n + k]
+
+    def _shift_plan(self, plan5, base):
+        """(pi, qi, di, pj, qj) -> the same relative to keyframe `base` (+ base), see GraphBuffer.bundle_adjustment"""
+        pi, qi, di, pj, qj = plan5
+        if self.cross_view or base <= 0:  # cross-view self edges may point anywhere in the buffer: keep absolute indices
+            return (pi, qi, di, pj, qj, 0)
+        V = self.buffer.n_views
+        return (pi - base, qi, di - base * V, pj - base, qj, base)
+
     @torch.no_grad()
     def update(self, t0=None, t1=None, itrs=3, use_inactive=False, motion_only=False, fixed_motion=False,
                limited_disp=False):
@@ -324,19 +361,25 @@ class FactorGraph:
             # indexing (a device-to-host sync each) and no re-expansion
             key = ("inac", t0)
             if key not in P:
-                m = (self.ii_inac >= t0 - 3) & (self.jj_inac >= t0 - 3)
-                sel = torch.nonzero(m).view(-1)
+                h = self.host_edges()
+                sel_h = np.flatnonzero((h["ii_inac"] >= t0 - 3) & (h["jj_inac"] >= t0 - 3))  # host mirror: no read-back
+                sel = torch.from_numpy(sel_h).to(self.device)
                 ii = torch.cat([self.ii_inac[sel], self.ii], 0)
                 jj = torch.cat([self.jj_inac[sel], self.jj], 0)
                 V = buf.n_views
                 sel_exp = (sel.view(-1, 1) * V + torch.arange(V, device=self.device).view(1, -1)).view(-1)
-                P[key] = (ii, jj, sel_exp, buf.expand_edge_multiview(ii, jj)[:5])
+                base = int(min(h["ii"].min(), h["jj"].min(), *(h[k][sel_h].min() for k in ("ii_inac", "jj_inac") if sel_h.size)))
+                P[key] = (ii, jj, sel_exp, self._shift_plan(buf.expand_edge_multiview(ii, jj)[:5], base))
             ii, jj, sel_exp, plan = P[key]
             target = torch.cat([self.target_inac.index_select(1, sel_exp), self.target], 1)
             weight = torch.cat([self.weight_inac.index_select(1, sel_exp), self.weight], 1)
         else:
             ii, jj, target, weight = self.ii, self.jj, self.target, self.weight
-            plan = (P["pi"], P["qi"], P["di"], P["pj"], P["qj"])  # cached expand_edge_multiview of the edge set
+            if "ba_plan" not in P:  # cached expand_edge_multiview of the edge set, relative to the oldest keyframe used
+                h = self.host_edges()
+                P["ba_plan"] = self._shift_plan((P["pi"], P["qi"], P["di"], P["pj"], P["qj"]),
+                                                int(min(h["ii"].min(), h["jj"].min())))
+            plan = P["ba_plan"]
         E = target.shape[1]
         buf.bundle_adjustment(target.view(E, -1, 2), weight.view(E, -1, 2), self.damping, ii, jj, t0,
                               t1 if not fixed_motion else t0, itrs, 1e-3, 0.1, motion_only, limited_disp, False, False,
