@@ -194,6 +194,10 @@ typedef struct {
   float alpha;       /* ba.dense_disp_alpha, configs/slam/default.yaml:48-49 */
   float weight_scale;/* 0.001, buffer.py:396 */
   float intr_factor; /* 8.0, buffer.py:415 */
+  int reuse_plan;    /* 1: the workspace still holds the plan (term order, pose slots, band, flags) of the previous
+                        call with IDENTICAL index arrays and parameters - skip rebuilding it.  The caller owns that
+                        guarantee (same workspace, nothing else ran in it); everything data dependent (sensor-depth
+                        frames, damping) is re-read every call. */
 } vipe_ba_params;
 
 int64_t vipe_dense_ba_workspace_bytes(const vipe_ba_params* p);

@@ -1171,3 +1171,35 @@ def test_dense_ba_long_trajectory_band_exceeds_lds(intr):
     assert np.abs(d - od[:, 0]).max() <= 1e-4 * np.abs(od).max()
     if intr:
         assert np.abs(k - ok_).max() <= 1e-4 * np.abs(ok_).max()
+
+
+def test_ba_plan_reuse_equals_rebuilding_the_plan(monkeypatch):
+    """FactorGraph keeps a private BA workspace and tells the library when the edge plan in it is still the one of the
+    previous call (vipe_ba_params.reuse_plan): three update iterations with reuse must equal three with the plan rebuilt
+    every call - including when the sensor depth of a frame appears between two calls (data the plan must not freeze)."""
+    import bench
+
+    def run(no_reuse):
+        if no_reuse:
+            monkeypatch.setenv("VIPE_AMD_BA_NO_PLAN_REUSE", "1")
+        else:
+            monkeypatch.delenv("VIPE_AMD_BA_NO_PLAN_REUSE", raising=False)
+        g, buf, graph = bench.build_problem(dev(), 12, 384, 512, 3, 0, "hip", seed=7)
+        out = []
+        for it in range(3):
+            if it == 2:
+                buf.disps_sens[5, 0] = buf.disps[5, 0] * 1.05  # frame 5 gets sensor depth before the third call
+            graph.update(t0=1, t1=12, itrs=2)
+            torch.cuda.synchronize()
+            out.append((buf.poses[:12].cpu().numpy().copy(), buf.disps[:12, 0].cpu().numpy().copy()))
+        return out, graph
+
+    a, ga = run(False)
+    b, _ = run(True)
+    assert ga._ba_state.get("key") is not None and ga._ba_state["ws"].numel() > 0
+    for (pa, da), (pb, db) in zip(a, b):
+        # two separate runs differ by the order of float atomics through three fp16 operator applications
+        assert np.abs(pa - pb).max() <= 1e-4 * max(1.0, np.abs(pb).max())
+        assert np.abs(da - db).max() <= 1e-4 * np.abs(db).max()
+    # the third call saw the new sensor depth: frame 5 moved differently than it would have without it
+    assert np.abs(a[2][1][5] - a[1][1][5]).max() > 0

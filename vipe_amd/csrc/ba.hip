@@ -101,9 +101,11 @@ size_t carve(const vipe_ba_params& p, char* base, BAWs* out) {
 
 // ------------------------------------------------------------------------------------------------ plan
 
-__global__ __launch_bounds__(256) void ba_sens_kernel(const float* __restrict__ sens, float* __restrict__ out, int P) {
+__global__ __launch_bounds__(256) void ba_sens_kernel(const float* __restrict__ sens, float* __restrict__ out, int P,
+                                                      int* __restrict__ info) {
   // buffer.py:470-471: frames whose sensor disparity sums to > 0
   const int k = blockIdx.x;
+  if (k == 0 && threadIdx.x == 0) info[2] = 0;  // Cholesky failure count of this call (also when the plan is reused)
   float s = 0.f;
   for (int p = threadIdx.x; p < P; p += blockDim.x) s += sens[(int64_t)k * P + p];
   s = wave_sum(s);
@@ -295,7 +297,7 @@ __device__ __forceinline__ void finish_disp(const BAArgs& a, int k, int p, int P
     if (sv > 0.0f) { C += a.p.alpha; wz -= a.p.alpha * (d - sv); }
     else C += a.eta[(int64_t)a.w.krow[k] * P + p];
   } else {
-    if (flags & 4) {
+    if (a.w.sens_sum[k] > 0.0f) {  // frames with sensor depth (buffer.py:470-471); read per call, not part of the plan
       C += a.p.alpha;
       wz -= a.p.alpha * (d - a.sens[kp]);
     }
@@ -2217,8 +2219,8 @@ VIPE_EXPORT int vipe_dense_ba(const vipe_ba_params* p, float* d_poses, float* d_
   hipStream_t s = as_stream(stream);
   int rc = VIPE_OK;
   if (p->M > 0 && p->n_iters > 0) {
-    ba_sens_kernel<<<a.nF, 256, 0, s>>>(d_disps_sens, a.w.sens_sum, a.P);
-    ba_plan_kernel<<<1, 1024, 0, s>>>(a);
+    ba_sens_kernel<<<a.nF, 256, 0, s>>>(d_disps_sens, a.w.sens_sum, a.P, a.w.info);
+    if (!p->reuse_plan) ba_plan_kernel<<<1, 1024, 0, s>>>(a);
     const int F = p->optimize_intrinsics ? 1 + a.D : 0;
     if (p->camera == VIPE_CAM_PINHOLE) rc = F ? run_iters<VIPE_CAM_PINHOLE, 1>(a, s) : run_iters<VIPE_CAM_PINHOLE, 0>(a, s);
     else rc = F ? run_iters<VIPE_CAM_MEI, 2>(a, s) : run_iters<VIPE_CAM_MEI, 0>(a, s);
@@ -2244,6 +2246,7 @@ vipe_ba_params droid_params(int n_poses, int ht, int wd, int E, int t0, int t1, 
   p.n_poses = n_poses; p.n_views = 1; p.ht = ht; p.wd = wd; p.M = E; p.t0 = t0; p.t1 = t1; p.n_iters = iterations;
   p.pose_damping = lm; p.pose_ep = ep; p.motion_only = motion_only; p.limited_disp = 0; p.optimize_intrinsics = 0;
   p.optimize_rig_rotation = 0; p.camera = VIPE_CAM_PINHOLE; p.alpha = 0.05f; p.weight_scale = 0.001f; p.intr_factor = 1.0f;
+  p.reuse_plan = 0;
   return p;
 }
 }  // namespace
@@ -2286,7 +2289,7 @@ VIPE_EXPORT int vipe_ba(float* d_poses, float* d_disps, const float* d_intrinsic
   a.droid = 1;
   a.dz_out = d_dz;
   if (iterations == 0 || t1 == t0) return VIPE_OK;
-  ba_sens_kernel<<<a.nF, 256, 0, s>>>(d_disps_sens, a.w.sens_sum, a.P);
+  ba_sens_kernel<<<a.nF, 256, 0, s>>>(d_disps_sens, a.w.sens_sum, a.P, a.w.info);
   ba_plan_kernel<<<1, 1024, 0, s>>>(a);
   const int rc = run_iters<VIPE_CAM_PINHOLE, 0>(a, s);
   if (rc != VIPE_OK) return rc;

@@ -1,6 +1,7 @@
 """slam_ext: projective geometry + dense BA (reference: csrc/slam_ext/slam.cpp:31-37)."""
 
 import ctypes
+import os
 
 import torch
 
@@ -71,7 +72,8 @@ def reproject_motion_nhwc(poses, disps, intrinsics, rig, pi, qi, pj, qj, di, tar
 
 def dense_ba(poses, disps, disps_sens, intrinsics, rig, target, weight, disp_damping, pi, qi, pj, qj, di, t0, t1,
              n_iters, pose_damping, pose_ep, motion_only=False, limited_disp=False, optimize_intrinsics=False,
-             optimize_rig_rotation=False, camera="pinhole", alpha=0.001, n_poses=None, want_info=False):
+             optimize_rig_rotation=False, camera="pinhole", alpha=0.001, n_poses=None, want_info=False, state=None,
+             plan_key=None):
     """Live dense BA (GraphBuffer.bundle_adjustment, buffer.py:373-525), IN PLACE on poses / disps / intrinsics.
 
     poses [>=n_poses,7]; disps, disps_sens, disp_damping [>=n_poses*V,ht,wd] (flattened views);
@@ -90,11 +92,25 @@ def dense_ba(poses, disps, disps_sens, intrinsics, rig, target, weight, disp_dam
                  pose_damping=float(pose_damping), pose_ep=float(pose_ep), motion_only=int(motion_only),
                  limited_disp=int(limited_disp), optimize_intrinsics=int(optimize_intrinsics),
                  optimize_rig_rotation=int(optimize_rig_rotation), camera=CAMERA_CODE[camera], alpha=float(alpha),
-                 weight_scale=0.001, intr_factor=8.0)
+                 weight_scale=0.001, intr_factor=8.0, reuse_plan=0)
     L = lib()
     nbytes = L.vipe_dense_ba_workspace_bytes(ctypes.byref(p))
     require(nbytes > 0, "bad BA parameters")
-    ws = _workspace(poses.device, nbytes)
+    if state is None:
+        ws = _workspace(poses.device, nbytes)
+    else:
+        # `state`: a dict owned by ONE caller (a FactorGraph) holding a private workspace.  When that caller vouches, through
+        # `plan_key`, that the index arrays are the ones of its previous call, the plan left in the workspace is reused
+        # (vipe_ba_params.reuse_plan); everything else that shapes the plan is part of the key checked here.
+        ws = state.get("ws")
+        if ws is None or ws.numel() < nbytes or ws.device != poses.device:
+            ws = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=poses.device)
+            state["ws"], state["key"] = ws, None
+        key = None if plan_key is None else (plan_key, ws.data_ptr(), n_poses, V, ht, wd, M, int(t0), int(t1), int(motion_only),
+                                             int(limited_disp), int(optimize_intrinsics), int(optimize_rig_rotation), camera,
+                                             tuple(int(x.data_ptr()) for x in (pi, qi, pj, qj, di)))
+        p.reuse_plan = int(key is not None and state.get("key") == key and not os.environ.get("VIPE_AMD_BA_NO_PLAN_REUSE"))
+        state["key"] = key
     info = torch.zeros(4, dtype=torch.int32, device=poses.device) if want_info else None
     check(L.vipe_dense_ba(ctypes.byref(p), ptr(poses), ptr(disps), ptr(disps_sens), ptr(intrinsics), ptr(rig),
                           ptr(target), ptr(weight), ptr(disp_damping), ptr(_i64(pi)), ptr(_i64(qi)), ptr(_i64(pj)),

@@ -39,6 +39,8 @@ class FactorGraph:
         self.target_inac = torch.zeros([1, 0, ht, wd, 2], device=device, dtype=torch.float)
         self.weight_inac = torch.zeros([1, 0, ht, wd, 2], device=device, dtype=torch.float)
         self._plan = None
+        self._plan_serial = 0   # counts rebuilt edge plans: (serial, kind) identifies the index arrays handed to the BA
+        self._ba_state = {}     # private BA workspace + the key of the plan it holds (slam_ext.dense_ba)
         self._h = None  # host mirror of the integer edge state (ii, jj, age, ii_inac, jj_inac), see host_edges()
 
     def host_edges(self):
@@ -293,6 +295,7 @@ class FactorGraph:
                 dix = torch.from_numpy(dix_h.astype(np.int64)).to(self.device)
                 n_src = int(du_h.shape[0])
             from .update_engine import segment_csr
+            self._plan_serial = getattr(self, "_plan_serial", 0) + 1
             self._plan = dict(pi=pi, qi=qi, di=di, pj=pj, qj=qj, du=du, dix=dix, n_src=n_src,
                               csr=segment_csr(dix, n_src),
                               t0=int(max(1, h["ii"].min() + 1)),
@@ -371,6 +374,7 @@ class FactorGraph:
                 base = int(min(h["ii"].min(), h["jj"].min(), *(h[k][sel_h].min() for k in ("ii_inac", "jj_inac") if sel_h.size)))
                 P[key] = (ii, jj, sel_exp, self._shift_plan(buf.expand_edge_multiview(ii, jj)[:5], base))
             ii, jj, sel_exp, plan = P[key]
+            plan_key = (self._plan_serial, "inac", t0)
             target = torch.cat([self.target_inac.index_select(1, sel_exp), self.target], 1)
             weight = torch.cat([self.weight_inac.index_select(1, sel_exp), self.weight], 1)
         else:
@@ -380,10 +384,11 @@ class FactorGraph:
                 P["ba_plan"] = self._shift_plan((P["pi"], P["qi"], P["di"], P["pj"], P["qj"]),
                                                 int(min(h["ii"].min(), h["jj"].min())))
             plan = P["ba_plan"]
+            plan_key = (self._plan_serial, "act")
         E = target.shape[1]
         buf.bundle_adjustment(target.view(E, -1, 2), weight.view(E, -1, 2), self.damping, ii, jj, t0,
                               t1 if not fixed_motion else t0, itrs, 1e-3, 0.1, motion_only, limited_disp, False, False,
-                              plan=plan)
+                              plan=plan, ba_state=getattr(self, "_ba_state", None), plan_key=plan_key)
         self.age += 1
         if getattr(self, "_h", None) is not None and self._h["age"].shape[0] == self.age.shape[0]:
             self._h["age"] += 1
