@@ -177,7 +177,8 @@ int vipe_reproject_motion_nhwc(const float* d_poses, const float* d_disps, const
  *   pi,qi,pj,qj,di [M] int64.  Pose p is fixed iff it occurs in pi and (p < t0 or p >= t1)
  *   (buffer.py:462-465); t0 == t1 fixes every pose.
  *   d_workspace: vipe_dense_ba_workspace_bytes(...) bytes, contents need not be initialised.
- *   d_info (optional, 4 ints): [n_free_poses, n_free_disp_frames, cholesky_failures, n_regular_unknowns]. */
+ *   d_info (optional, 8 ints): [n_free_poses, n_free_disp_frames, cholesky_failures, n_regular_unknowns,
+ *   band width in 6x6 blocks, 1 if the LDS band solver solved the last iteration, largest source-frame degree, 0]. */
 typedef struct {
   int n_poses;       /* rows of poses; disps has n_poses*n_views frames */
   int n_views;
@@ -198,6 +199,11 @@ typedef struct {
                         call with IDENTICAL index arrays and parameters - skip rebuilding it.  The caller owns that
                         guarantee (same workspace, nothing else ran in it); everything data dependent (sensor-depth
                         frames, damping) is re-read every call. */
+  int path_hint;     /* 0: unknown - every kernel of both accumulate / solve paths is launched and the inapplicable ones
+                        exit at once (the choice depends on the plan, which lives on the device).  A caller that has read
+                        d_info[4..7] of an earlier call with the SAME plan may pass what it learnt so that those launches are
+                        not made: bit 0 source degree <= 6 (matrix-core accumulate), bit 1 degree > 6 (walk + Schur),
+                        bit 2 the LDS band solver takes the system, bit 3 it does not (global-memory Cholesky). */
 } vipe_ba_params;
 
 int64_t vipe_dense_ba_workspace_bytes(const vipe_ba_params* p);

@@ -28,7 +28,7 @@ class BAParams(ctypes.Structure):
         ("pose_damping", ctypes.c_float), ("pose_ep", ctypes.c_float), ("motion_only", ctypes.c_int),
         ("limited_disp", ctypes.c_int), ("optimize_intrinsics", ctypes.c_int),
         ("optimize_rig_rotation", ctypes.c_int), ("camera", ctypes.c_int), ("alpha", ctypes.c_float),
-        ("weight_scale", ctypes.c_float), ("intr_factor", ctypes.c_float), ("reuse_plan", ctypes.c_int),
+        ("weight_scale", ctypes.c_float), ("intr_factor", ctypes.c_float), ("reuse_plan", ctypes.c_int), ("path_hint", ctypes.c_int),
     ]
 
 

@@ -105,7 +105,10 @@ __global__ __launch_bounds__(256) void ba_sens_kernel(const float* __restrict__ 
                                                       int* __restrict__ info) {
   // buffer.py:470-471: frames whose sensor disparity sums to > 0
   const int k = blockIdx.x;
-  if (k == 0 && threadIdx.x == 0) info[2] = 0;  // Cholesky failure count of this call (also when the plan is reused)
+  if (k == 0 && threadIdx.x == 0) {
+    info[2] = 0;  // Cholesky failure count of this call (also when the plan is reused)
+    info[5] = 0;  // "band solver solved": normally reset by that kernel itself, which a path hint may leave out
+  }
   float s = 0.f;
   for (int p = threadIdx.x; p < P; p += blockDim.x) s += sens[(int64_t)k * P + p];
   s = wave_sum(s);
@@ -2166,12 +2169,16 @@ int run_iters(const BAArgs& a, hipStream_t s) {
     hipError_t e1 = hipMemsetAsync(a.w.S, 0, sbytes, s);
     hipError_t e2 = hipMemsetAsync(a.w.Hd, 0, sizeof(double) * nmax, s);
     if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
-    ba_accum_mfma_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, accum_mfma_lds(), s>>>(a);
-    ba_walk_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, walk_lds(), s>>>(a);
-    ba_schur_kernel<F><<<dim3(SC_GRID, a.nF), TILE, 0, s>>>(a);
+    // path_hint (vipe_ba_params): what the caller learnt from an earlier call with this plan; 0 launches everything
+    const int hint = a.force_simple ? 0 : a.p.path_hint;
+    if (!(hint & 2)) ba_accum_mfma_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, accum_mfma_lds(), s>>>(a);
+    if (!(hint & 1)) {
+      ba_walk_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, walk_lds(), s>>>(a);
+      ba_schur_kernel<F><<<dim3(SC_GRID, a.nF), TILE, 0, s>>>(a);
+    }
     if (a.force_simple == 1) ba_accum_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
-    ba_solve_band_kernel<<<1, BAND_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)));
-    ba_solve_kernel<<<1, SOLVE_T, solve_lds, s>>>(a, panel_cap, getenv("VIPE_BA_DEBUG_TIMING") ? (long long*)(a.w.Hd + nmax) : nullptr);
+    if (!(hint & 8)) ba_solve_band_kernel<<<1, BAND_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)));
+    if (!(hint & 4)) ba_solve_kernel<<<1, SOLVE_T, solve_lds, s>>>(a, panel_cap, getenv("VIPE_BA_DEBUG_TIMING") ? (long long*)(a.w.Hd + nmax) : nullptr);
     if (!a.p.motion_only) ba_retract_kernel<F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
   }
   return vipe_launch_status();
@@ -2226,7 +2233,7 @@ VIPE_EXPORT int vipe_dense_ba(const vipe_ba_params* p, float* d_poses, float* d_
     else rc = F ? run_iters<VIPE_CAM_MEI, 2>(a, s) : run_iters<VIPE_CAM_MEI, 0>(a, s);
     if (rc != VIPE_OK) return rc;
     if (d_info) {
-      hipError_t e = hipMemcpyAsync(d_info, a.w.info, 4 * sizeof(int), hipMemcpyDeviceToDevice, s);
+      hipError_t e = hipMemcpyAsync(d_info, a.w.info, 8 * sizeof(int), hipMemcpyDeviceToDevice, s);
       if (e != hipSuccess) return (int)e;
     }
   }
@@ -2246,7 +2253,7 @@ vipe_ba_params droid_params(int n_poses, int ht, int wd, int E, int t0, int t1, 
   p.n_poses = n_poses; p.n_views = 1; p.ht = ht; p.wd = wd; p.M = E; p.t0 = t0; p.t1 = t1; p.n_iters = iterations;
   p.pose_damping = lm; p.pose_ep = ep; p.motion_only = motion_only; p.limited_disp = 0; p.optimize_intrinsics = 0;
   p.optimize_rig_rotation = 0; p.camera = VIPE_CAM_PINHOLE; p.alpha = 0.05f; p.weight_scale = 0.001f; p.intr_factor = 1.0f;
-  p.reuse_plan = 0;
+  p.reuse_plan = 0; p.path_hint = 0;
   return p;
 }
 }  // namespace

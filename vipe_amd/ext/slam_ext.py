@@ -92,10 +92,11 @@ def dense_ba(poses, disps, disps_sens, intrinsics, rig, target, weight, disp_dam
                  pose_damping=float(pose_damping), pose_ep=float(pose_ep), motion_only=int(motion_only),
                  limited_disp=int(limited_disp), optimize_intrinsics=int(optimize_intrinsics),
                  optimize_rig_rotation=int(optimize_rig_rotation), camera=CAMERA_CODE[camera], alpha=float(alpha),
-                 weight_scale=0.001, intr_factor=8.0, reuse_plan=0)
+                 weight_scale=0.001, intr_factor=8.0, reuse_plan=0, path_hint=0)
     L = lib()
     nbytes = L.vipe_dense_ba_workspace_bytes(ctypes.byref(p))
     require(nbytes > 0, "bad BA parameters")
+    key = None
     if state is None:
         ws = _workspace(poses.device, nbytes)
     else:
@@ -111,11 +112,37 @@ def dense_ba(poses, disps, disps_sens, intrinsics, rig, target, weight, disp_dam
                                              tuple(int(x.data_ptr()) for x in (pi, qi, pj, qj, di)))
         p.reuse_plan = int(key is not None and state.get("key") == key and not os.environ.get("VIPE_AMD_BA_NO_PLAN_REUSE"))
         state["key"] = key
-    info = torch.zeros(4, dtype=torch.int32, device=poses.device) if want_info else None
+        p.path_hint = _path_hint(state, key)
+    learn = state is not None and key is not None and p.path_hint == 0 and "pending" not in state and M > 0 and n_iters > 0 \
+        and not torch.cuda.is_current_stream_capturing() and not os.environ.get("VIPE_AMD_BA_NO_PLAN_REUSE")
+    info = torch.zeros(8, dtype=torch.int32, device=poses.device) if (want_info or learn) else None
     check(L.vipe_dense_ba(ctypes.byref(p), ptr(poses), ptr(disps), ptr(disps_sens), ptr(intrinsics), ptr(rig),
                           ptr(target), ptr(weight), ptr(disp_damping), ptr(_i64(pi)), ptr(_i64(qi)), ptr(_i64(pj)),
                           ptr(_i64(qj)), ptr(_i64(di)), ptr(ws), ws.numel(), ptr(info), stream_ptr(poses)), "dense_ba")
+    if learn:  # read the plan's facts back WITHOUT blocking: pinned buffer + event, consulted by a later call
+        host = torch.empty(8, dtype=torch.int32, pin_memory=True)
+        host.copy_(info, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        state["pending"] = (key, host, ev)
     return info
+
+
+def _path_hint(state, key):
+    """vipe_ba_params.path_hint for the plan `key` of this caller, or 0 while nothing has been learnt about it yet."""
+    if key is None or os.environ.get("VIPE_AMD_BA_NO_PLAN_REUSE"):
+        return 0
+    hints = state.setdefault("hints", {})
+    pend = state.get("pending")
+    if pend is not None and pend[2].query():
+        k, host, _ = pend
+        del state["pending"]
+        if len(hints) > 64:
+            hints.clear()
+        degree, solved = int(host[6]), int(host[5])
+        if degree > 0:  # AM_DMAX = 6 in csrc/ba.hip: the matrix-core accumulate kernel covers source degrees up to 6
+            hints[k] = (1 if degree <= 6 else 2) | (4 if solved else 8)
+    return hints.get(key, 0)
 
 
 # ------------------------------------------------------------------ reference-named entry points (slam.cpp:31-37)
