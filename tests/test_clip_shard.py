@@ -133,3 +133,24 @@ def test_corr_pool_slot_bookkeeping_on_host():
     pool = pool[torch.tensor([True, False, True, False, True, False, True])]  # boolean masks work too
     assert [float(x) for x in pool.corr_pyramid[0][:, 0, 0, 0, 0]] == [10, 20, 30, 32]
     assert len(pool._free) == 4 and set(pool._free).isdisjoint(pool._slots_host) and len(set(pool._slots_host)) == 4
+
+
+def test_corr_pool_adopts_a_large_first_block():
+    """A first block at least as large as the pool's default capacity becomes the pool (no copy); later blocks grow it."""
+    import types
+    import numpy as np
+    from vipe_amd.slam.networks import CorrPool
+
+    def block(n, tag):
+        lv = [torch.full((n, 2, 2, 4 >> i, 4 >> i), float(tag), dtype=torch.float16) + torch.arange(n).view(n, 1, 1, 1, 1)
+              for i in range(2)]
+        return types.SimpleNamespace(corr_pyramid=lv)
+
+    b = block(5, 10)
+    pool = CorrPool(num_levels=2, capacity=4).cat(b)
+    assert pool.pool[0].data_ptr() == b.corr_pyramid[0].data_ptr() and pool._free == [] and pool._slots_host == [0, 1, 2, 3, 4]
+    pool.cat(block(2, 20))  # no free slot: the pool grows
+    assert pool.pool[0].shape[0] >= 7 and len(pool) == 7
+    assert [float(x) for x in pool.corr_pyramid[0][:, 0, 0, 0, 0]] == [10, 11, 12, 13, 14, 20, 21]
+    pool = pool[np.array([1, 5])]
+    assert [float(x) for x in pool.corr_pyramid[1][:, 0, 0, 0, 0]] == [11, 20] and len(pool._free) == pool.pool[0].shape[0] - 2

@@ -152,6 +152,13 @@ class CorrPool:
         """append the edges of a CorrBlock (its volumes are copied into free slots)"""
         lv = other.corr_pyramid
         k = lv[0].shape[0]
+        if self.pool is None and k >= self.capacity:
+            # a first block at least as large as the default capacity (a whole graph added at once): its level buffers
+            # BECOME the pool - no second copy of a multi-GB pyramid; later additions grow it like any full pool
+            self.pool = [l.contiguous() for l in lv]
+            self._slots_host = list(range(k))
+            self.slots = torch.arange(k, dtype=torch.int32, device=lv[0].device)
+            return self
         if self.pool is None or len(self._free) < k:
             self._grow(lv, k)
         ids = [self._free.pop(0) for _ in range(k)]
