@@ -2097,6 +2097,15 @@ __global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_c
 template <int F>
 __global__ __launch_bounds__(TILE) void ba_retract_kernel(BAArgs a) {
   const BAWs& w = a.w;
+  {
+    // The reduced system has been solved (this kernel only reads dx): clear S and Hd for the next accumulation here,
+    // spread over the whole grid, instead of two memset launches per Gauss-Newton iteration.
+    const int64_t nthr = (int64_t)gridDim.x * gridDim.y * TILE;
+    const int64_t gid = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * TILE + threadIdx.x;
+    const int64_t ns = (int64_t)w.ld * w.ld;
+    for (int64_t i = gid; i < ns; i += nthr) w.S[i] = 0.0;
+    for (int64_t i = gid; i < (int64_t)w.ld - 1; i += nthr) w.Hd[i] = 0.0;
+  }
   const int k = blockIdx.y;
   const int flags = w.fflags[k];
   if (!(flags & 2)) return;
@@ -2165,10 +2174,16 @@ int run_iters(const BAArgs& a, hipStream_t s) {
   }
   (void)hipFuncSetAttribute((const void*)ba_accum_mfma_kernel<CAM, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_mfma_lds());
   (void)hipFuncSetAttribute((const void*)ba_walk_kernel<CAM, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds());
+  // S / Hd start each accumulation zeroed: by ba_retract_kernel of the previous iteration when it runs (not motion_only),
+  // also across calls when the caller vouches for the workspace (reuse_plan: same key, hence the same motion_only), else
+  // by memsets
+  const bool retract_clears = !a.p.motion_only;
   for (int it = 0; it < a.p.n_iters; ++it) {
-    hipError_t e1 = hipMemsetAsync(a.w.S, 0, sbytes, s);
-    hipError_t e2 = hipMemsetAsync(a.w.Hd, 0, sizeof(double) * nmax, s);
-    if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
+    if (!(retract_clears && (it > 0 || a.p.reuse_plan))) {
+      hipError_t e1 = hipMemsetAsync(a.w.S, 0, sbytes, s);
+      hipError_t e2 = hipMemsetAsync(a.w.Hd, 0, sizeof(double) * nmax, s);
+      if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
+    }
     // path_hint (vipe_ba_params): what the caller learnt from an earlier call with this plan; 0 launches everything
     const int hint = a.force_simple ? 0 : a.p.path_hint;
     if (!(hint & 2)) ba_accum_mfma_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, accum_mfma_lds(), s>>>(a);

@@ -111,7 +111,8 @@ def dense_ba(poses, disps, disps_sens, intrinsics, rig, target, weight, disp_dam
                                              int(limited_disp), int(optimize_intrinsics), int(optimize_rig_rotation), camera,
                                              tuple(int(x.data_ptr()) for x in (pi, qi, pj, qj, di)))
         p.reuse_plan = int(key is not None and state.get("key") == key and not os.environ.get("VIPE_AMD_BA_NO_PLAN_REUSE"))
-        state["key"] = key
+        # a call that launches nothing (no terms / no iterations) leaves the workspace as it found it: it vouches for nothing
+        state["key"] = key if (M > 0 and int(n_iters) > 0) else None
         p.path_hint = _path_hint(state, key)
     learn = state is not None and key is not None and p.path_hint == 0 and "pending" not in state and M > 0 and n_iters > 0 \
         and not torch.cuda.is_current_stream_capturing() and not os.environ.get("VIPE_AMD_BA_NO_PLAN_REUSE")
