@@ -261,19 +261,28 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
 
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; the modulo only matters for rehearsing the multi-rank path on a box with fewer GPUs than ranks
+    # (VIPE_BENCH_DIST_BACKEND=gloo, ranks share the card)
+    device = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(device)
 
+    def init_dist():
+        if world > 1 and not dist.is_initialized():
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            backend = os.environ.get("VIPE_BENCH_DIST_BACKEND", "nccl")  # nccl = RCCL on ROCm
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=device)
+            else:
+                dist.init_process_group(backend)
+
     if args.mode == "video":
+        init_dist()
         video_mode(args, device, world, rank)
         if world > 1:
             dist.destroy_process_group()
         return
     if args.mode == "backend":
+        init_dist()
         backend_mode(args, device, world, rank)
         if world > 1:
             dist.destroy_process_group()
@@ -319,6 +328,9 @@ def main():
         except Exception as e:  # noqa: BLE001 - fall back to eager launches and say so
             cg = None
             launch = f"eager (graph capture failed: {type(e).__name__})"
+    # RCCL comes up only now: problem set-up, warm-up and the graph capture above are rank-local (clip sharding has no
+    # data-path collective), so no communicator thread is alive while a stream is being captured
+    init_dist()
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
