@@ -2,17 +2,23 @@
 
 One "step" = one FactorGraph.update: reproject -> 4-level correlation lookup -> flow-update
 operator (ConvGRU) -> dense bundle adjustment (3 Gauss-Newton iterations) on a synthetic 512x384 clip,
-48 keyframes, E = 276 edges (radius-3 bidirectional graph), inputs resident in HBM.  With --gpus N every
-rank runs its own clip (clip sharding, no data-path collective); the value is the whole-job aggregate.
+48 keyframes, E = 276 edges (radius-3 bidirectional graph), sensor-depth prior on (BASELINE config 3), inputs resident in
+HBM.  With --gpus N every rank runs its own clip (clip sharding, no data-path collective) and the per-clip results are
+exchanged with ONE all_gather (RCCL) at the end; the value is the whole-job aggregate.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # N > 1: starts its own N rank processes
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --mode video --gpus N --frames 300            # BASELINE config 4: one 300-frame clip per GPU
 """
 
 import argparse
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -23,20 +29,46 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP16_TFLOPS = 2500.0  # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0
+DTYPE = "f16 (correlation, GRU; fp32 accumulate) + f32 geometry/BA (fp64 reduced system)"
 
 
-def build_problem(device, n_kf, height, width, radius, extra_edges, conv_backend, seed=1234):
+# ---------------------------------------------------------------------------------------------- launching N ranks
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without an external launcher: start N fresh rank processes (one per GPU) through
+    torch.distributed.run and relay their output.  Runs BEFORE this process has made any GPU call (importing torch and
+    counting devices do not initialise the runtime); the parent never touches the GPU, it only waits."""
+    plumbing = "plumbing" in sys.argv  # --mode plumbing: gloo ranks on the CPU
+    backend = "gloo" if plumbing else os.environ.get("VIPE_BENCH_DIST_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < n:
+        sys.stderr.write(f"bench.py: --gpus {n} needs {n} GPUs for RCCL, this node shows {have} (set "
+                         f"VIPE_BENCH_DIST_BACKEND=gloo to rehearse the multi-rank path with ranks sharing a card)\n")
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------------------------- the workload
+def build_problem(device, n_kf, height, width, radius, extra_edges, seed=1234, depth_prior=True):
     from vipe_amd.slam.buffer import GraphBuffer
     from vipe_amd.slam.factor_graph import FactorGraph
     from vipe_amd.slam.networks import UpdateModule
     from vipe_amd.synth import make_graph
 
-    os.environ["VIPE_AMD_CONV"] = conv_backend
-    g = make_graph(n=n_kf, height=height, width=width, radius=radius, extra_edges=extra_edges, seed=seed)
+    g = make_graph(n=n_kf, height=height, width=width, radius=radius, extra_edges=extra_edges, seed=seed,
+                   depth_prior=depth_prior)
     buf = GraphBuffer(height, width, n_views=1, buffer_size=max(64, n_kf), device=device)
     buf.n_frames = n_kf
     buf.poses[:n_kf] = torch.from_numpy(g.poses).to(device)
     buf.disps[:n_kf, 0] = torch.from_numpy(g.disps).to(device)
+    buf.disps_sens[:n_kf, 0] = torch.from_numpy(g.disps_sens).to(device)  # config 3: "depth_align on"
     buf.intrinsics[:] = torch.from_numpy(g.intrinsics).to(device)
     gen = torch.Generator(device="cpu").manual_seed(seed)
     ht, wd = g.ht, g.wd
@@ -53,53 +85,232 @@ def build_problem(device, n_kf, height, width, radius, extra_edges, conv_backend
     return g, buf, graph
 
 
-def conv_flops(E, ht, wd, cin, cout, k):
-    return 2.0 * E * ht * wd * cin * cout * k * k
-
-
-def cpu_baseline(seconds_budget=20.0):
-    """Oracle (CPU restatement, 'port') of corr lookup + dense BA on a bounded sub-graph, 1 thread."""
-    from threadpoolctl import threadpool_limits
-
-    from oracle import ba as oba
-    from oracle import corr as ocorr
-    from oracle import se3 as ose3
+def cpu_baseline(n_sub=8):
+    """the PyTorch-CPU corr + BA path (oracle/torch_cpu.py: correlation volume + 4-level pyramid +
+    7x7 bilinear lookup, then the 3-iteration dense Schur BA; GRU excluded), timed on this box's host cores on a BOUNDED
+    sample of the workload - an n_sub-keyframe sub-graph of the same 48x64 synthetic clip - and scaled per edge to
+    E = 276.  All threads: 1 warm-up + median of 5; then one pass with 1 thread."""
+    from oracle import torch_cpu as tc
     from vipe_amd.synth import make_graph
 
-    n_sub = 32
-    g = make_graph(n=n_sub, height=384, width=512, radius=3, seed=1234)
+    g = make_graph(n=n_sub, height=384, width=512, radius=3, seed=1234, depth_prior=True)
     E = len(g.ii)
-    rng = np.random.default_rng(0)
-    # one pyramid for all sample edges (random fp16 volume: the lookup cost does not depend on the values)
-    levels = [np.broadcast_to(rng.normal(0, 1, (1, g.ht, g.wd, g.ht >> i, g.wd >> i)).astype(np.float16),
-                              (E, g.ht, g.wd, g.ht >> i, g.wd >> i)) for i in range(4)]
-    coords = np.stack(np.meshgrid(np.arange(g.wd), np.arange(g.ht)), -1).astype(np.float32)[None, None].repeat(E, 1)
-    coords = coords + rng.normal(0, 2, coords.shape).astype(np.float32)
-    with threadpool_limits(limits=1):
-        torch.set_num_threads(1)
+    T = torch.from_numpy
+    gen = torch.Generator().manual_seed(1234)
+    fm = torch.randn(n_sub, 128, g.ht, g.wd, generator=gen).half().float()
+    ii, jj = T(g.ii), T(g.jj)
+    tgt = T(g.target)
+    coords = tgt + 0.5 * torch.randn(tgt.shape, generator=gen)
+    ba_in = (T(g.poses), T(g.disps), T(g.disps_sens), T(g.intrinsics), tgt.reshape(E, -1, 2),
+             T(g.weight).reshape(E, -1, 2), T(g.eta), ii, jj, 1, n_sub, 3, 1e-3, 0.1)
+
+    def one_pass():
         t0 = time.perf_counter()
-        ocorr.corr_lookup(levels, coords, 3)
-        t_corr = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        oba.bundle_adjustment(g.poses, g.disps[:, None], g.disps_sens[:, None], g.intrinsics, ose3.se3_identity(1),
-                              g.target.reshape(E, -1, 2), g.weight.reshape(E, -1, 2), g.eta[:, None], g.ii, g.jj, t0=1,
-                              t1=n_sub, n_iters=3, pose_damping=1e-3, pose_ep=0.1, dtype=np.float32)
-        t_ba = time.perf_counter() - t0
-    per_edge = (t_corr + t_ba) / E
+        pyr = tc.corr_pyramid(fm[ii], fm[jj])
+        t1 = time.perf_counter()
+        tc.corr_lookup(pyr, coords)
+        t2 = time.perf_counter()
+        tc.bundle_adjustment(*ba_in)
+        return t1 - t0, t2 - t1, time.perf_counter() - t2
+
+    cores = os.cpu_count() or 1
+    keep = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    one_pass()
+    runs = sorted((one_pass() for _ in range(5)), key=sum)
+    b, l, a = runs[len(runs) // 2]
+    torch.set_num_threads(1)
+    b1, l1, a1 = one_pass()
+    torch.set_num_threads(keep)
+    scale = 276.0 / E
     return {
-        "value": 1.0 / (per_edge * 276), "unit": "iters/s", "cores": 1, "kind": "port",
-        "sample": f"oracle corr lookup + 3-iteration dense BA (GRU excluded) on a {n_sub}-keyframe / {E}-edge "
-                  f"48x64 sub-graph ({t_corr:.1f}s + {t_ba:.1f}s), scaled per edge to E=276",
+        "value": 1.0 / ((b + l + a) * scale), "unit": "iters/s", "cores": cores, "kind": "port",
+        "value_1_thread": 1.0 / ((b1 + l1 + a1) * scale),
+        "value_without_volume_build": 1.0 / ((l + a) * scale),
+        "seconds_per_pass_on_sample": {"volume+pyramid build": b, "lookup": l, "dense BA (3 GN iterations)": a},
+        "sample": f"PyTorch-CPU (fp32) correlation volume + pyramid + 7x7x4 lookup + 3-iteration dense Schur BA, GRU "
+                  f"excluded, on a {n_sub}-keyframe / {E}-edge 48x64 sub-graph of the bench clip (the full E=276 pass "
+                  f"takes ~20 s per repetition on 8 cores), scaled per edge to E=276; {cores} threads: 1 warm-up + "
+                  f"median of 5; 1 thread: one pass",
     }
 
 
-def backend_mode(args, device, world, rank):
+# ---------------------------------------------------------------------------------------------- distributed plumbing
+class Dist:
+    """One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the launcher).  RCCL carries two barriers, the MAX of
+    the elapsed time and the one all_gather of the per-clip results; nothing during compute."""
+
+    def __init__(self, use_gpu=True):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if not use_gpu:  # --mode plumbing
+            self.device = torch.device("cpu")
+            return
+        # the modulo only matters for rehearsing the multi-rank path on a box with fewer GPUs than ranks
+        # (VIPE_BENCH_DIST_BACKEND=gloo, ranks share the card)
+        self.device = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
+        torch.cuda.set_device(self.device)
+
+    def init(self):
+        if self.world > 1 and not self.dist.is_initialized():
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            backend = os.environ.get("VIPE_BENCH_DIST_BACKEND", "nccl")  # nccl = RCCL on ROCm
+            if backend == "nccl":
+                self.dist.init_process_group("nccl", device_id=self.device)
+            else:
+                self.dist.init_process_group(backend)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max_over_ranks(self, seconds):
+        if self.world == 1:
+            return seconds
+        from vipe_amd.driver.clip_shard import exchange_device
+        tt = torch.tensor([seconds], device=exchange_device(), dtype=torch.float64)
+        self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def n_ranks_seen(self):
+        return self.dist.get_world_size() if self.dist.is_initialized() else 1
+
+    def close(self):
+        if self.world > 1 and self.dist.is_initialized():
+            self.dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------- video clips
+def make_clip_runner(device, features=False):
+    """-> run_clip(seed, n_frames, with_backend) -> dict.  One DroidNet (random-init weights, no checkpoint offline) is
+    shared by all clips of this rank; every clip gets a fresh buffer / frontend (per-clip isolation, run.py:17-26)."""
+    from vipe_amd.slam.buffer import GraphBuffer
+    from vipe_amd.slam.frontend import FrontendArgs, SLAMFrontend
+    from vipe_amd.slam.motion_filter import DroidNet, MotionFilter
+
+    torch.manual_seed(0)
+    dn = DroidNet()
+    um = dn.update
+
+    def run_clip(seed, n_frames, with_backend=False):
+        buf = GraphBuffer(384, 512, buffer_size=n_frames + 16, device=device)
+        buf.intrinsics[:] = torch.tensor([460.8, 460.8, 256.0, 192.0], device=device)
+        # keyframe_thresh = 0: every synthetic frame stays a keyframe (random-weight flow would otherwise make the
+        # distance test drop about half of them and the window would hold ~16 instead of <= 48 edges)
+        fe = SLAMFrontend(um, buf, FrontendArgs(keyframe_thresh=0.0), device)
+        gen = torch.Generator(device="cpu").manual_seed(99 + seed)
+        pool_d = (1.0 / (1.0 + 4.0 * torch.rand(32, 48, 64, generator=gen))).to(device)
+        if features:  # legacy variant: seeded feature maps instead of RGB frames (motion filter + encoders skipped)
+            pool_f = torch.randn(32, 128, 48, 64, generator=gen).half().to(device)
+            pool_n = torch.randn(32, 128, 48, 64, generator=gen).tanh().half().to(device)
+            pool_i = torch.randn(32, 128, 48, 64, generator=gen).relu().half().to(device)
+        else:
+            # decoded RGB frames resident in HBM before the timed region (decode / resize are host work outside the
+            # path); every frame goes through the motion filter: feature encoder, one flow-update application against
+            # the last keyframe, context encoder (thresh 0: every frame becomes a keyframe)
+            pool_img = torch.rand(32, 1, 3, 384, 512, generator=gen).to(device)
+            mf = MotionFilter(dn, thresh=0.0, device=device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_frames):
+            t = buf.n_frames
+            if features:
+                buf.fmaps[t, 0], buf.nets[t, 0], buf.inps[t, 0] = pool_f[t % 32], pool_n[t % 32], pool_i[t % 32]
+            else:
+                keep = mf.check(pool_img[t % 32], None)
+                assert keep, "threshold 0 keeps every frame"
+                buf.fmaps[t], buf.nets[t], buf.inps[t] = mf.f_fmap, mf.f_net, mf.f_inp
+            if t < fe.args.warmup:  # until the frontend owns the poses: smooth trajectory along x
+                buf.poses[t, 0] = 0.05 * t
+                buf.disps[t, 0] = pool_d[t % 32]
+            buf.n_frames += 1
+            fe.run()
+        torch.cuda.synchronize()
+        t_fe = time.perf_counter() - t0
+        backend_edges = None
+        if with_backend:  # system.py:272-275: global BA over all keyframes, twice (fresh graph each time)
+            from vipe_amd.slam.backend import BackendArgs, SLAMBackend
+            be = SLAMBackend(um, buf, BackendArgs(), device)
+            be.run(7)
+            gb = be.run(BackendArgs().backend_iters, update_depth=False)
+            backend_edges = int(gb.ii.numel())
+            torch.cuda.synchronize()
+        n = buf.n_frames
+        finite = bool(torch.isfinite(buf.poses[:n]).all() and torch.isfinite(buf.disps[:n]).all())
+        return {"poses": buf.poses[:n].clone(), "intrinsics": buf.intrinsics[0, :4].clone(), "frames": n_frames,
+                "keyframes": int(n), "frontend_seconds": t_fe, "seconds": time.perf_counter() - t0, "finite": finite,
+                "update_iterations": fe.n_updates, "edges_final": int(fe.graph.ii.numel()),
+                "backend_edges": backend_edges}
+
+    return run_clip
+
+
+def video_mode(args, D):
+    """BASELINE config 4 / the frames/s figure of SURVEY 8(d): `--clips` (default: one per rank) independent synthetic
+    512x384 clips of `--frames` frames, clip i on rank i mod world (clip_shard.run_sharded), every frame a keyframe:
+    per frame = motion filter on the RGB frame (feature encoder, one flow-update application against the last keyframe,
+    context encoder), proximity-edge proposal, correlation pyramid + gate-context build for the new edges, 4 (+2) update
+    iterations over the <= 48-edge window incl. the dense BA with inactive edges; ONE all_gather of the padded
+    trajectories at the end (RCCL), rank 0 writes the pose / intrinsics artifacts."""
+    from vipe_amd.driver import artifacts
+    from vipe_amd.driver.clip_shard import ClipResult, run_sharded
+
+    dev, world, rank = D.device, D.world, D.rank
+    D.init()
+    run_clip = make_clip_runner(dev, features=args.video_features)
+    run_clip(seed=10_000 + rank, n_frames=24)  # untimed warm-up clip: code objects, workspaces, allocator pools
+    n_clips = args.clips or world
+    stats = []
+
+    def process(cid):
+        r = run_clip(seed=cid, n_frames=args.frames, with_backend=args.with_backend)
+        stats.append(r)
+        return ClipResult(cid, r["poses"], r["intrinsics"], ok=r["finite"])
+
+    torch.cuda.synchronize()
+    D.barrier()
+    t0 = time.perf_counter()
+    results = run_sharded(n_clips, process, f_max=args.frames + 16)
+    t_gather_end = time.perf_counter()
+    torch.cuda.synchronize()
+    D.barrier()
+    dt = D.max_over_ranks(time.perf_counter() - t0)
+    if rank == 0:
+        out_dir = args.out_dir or tempfile.mkdtemp(prefix="vipe_amd_artifacts_")
+        written = artifacts.save_clip_results(out_dir, results)
+        if not args.out_dir:
+            shutil.rmtree(out_dir, ignore_errors=True)
+        mine = stats[0] if stats else {}
+        frames = n_clips * args.frames
+        print(json.dumps({
+            "metric": "frames/s, synthetic 512x384xN video clips through the keyframe frontend"
+                      + (" + global BA" if args.with_backend else "") + " (every frame a keyframe)",
+            "value": frames / dt, "unit": "frames/s", "n_gpus": D.n_ranks_seen(), "steps": frames, "warmup": 24,
+            "ms_per_step": 1e3 * dt / max(1, args.frames * ((n_clips + world - 1) // world)),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": DTYPE, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[3]-shaped: {n_clips} independent {args.frames}-frame 512x384 clips, "
+                                   f"clip-sharded over {world} rank(s), frontend window <= 48 edges, 4+2 update "
+                                   f"iterations per keyframe, one all_gather of the results, artifacts by rank 0",
+                       "clips_ok": sum(r.ok for r in results), "clips": len(results), "artifacts_written": len(written),
+                       "gather_backend": (D.dist.get_backend() if D.dist.is_initialized() else "none (1 rank)"),
+                       "rank0_clip": {k: mine.get(k) for k in ("frontend_seconds", "seconds", "update_iterations",
+                                                               "keyframes", "edges_final", "backend_edges", "finite")},
+                       "rank0_seconds_to_gather_end": t_gather_end - t0,
+                       "input": "feature maps (encoders skipped)" if args.video_features else
+                                "RGB frames: motion filter + feature / context encoders in the timed region"}}))
+    D.close()
+
+
+def backend_mode(args, D):
     """Secondary figure: hot loop B of SURVEY 3.4 - `FactorGraph.update_batch(itrs=2, steps=1)` (reproject, correlation
     volume build + lookup, flow-update operator over all E = 276 edges, one global BA with 2 GN iterations) on the
     headline graph, one clip per GPU."""
-    import torch.distributed as dist
-
-    g, buf, graph = build_problem(device, args.keyframes, 384, 512, 3, args.extra_edges, args.conv, seed=1234 + rank)
+    D.init()
+    g, buf, graph = build_problem(D.device, args.keyframes, 384, 512, 3, args.extra_edges, seed=1234 + D.rank)
 
     def step():
         graph.update_batch(itrs=2, steps=1, optimize_intrinsics=False, optimize_rig_rotation=False)
@@ -107,189 +318,114 @@ def backend_mode(args, device, world, rank):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    D.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    if rank == 0:
+    D.barrier()
+    dt = D.max_over_ranks(time.perf_counter() - t0)
+    if D.rank == 0:
         print(json.dumps({
-            "metric": "backend update_batch calls/s, 512x384 48-KF graph", "value": world * args.steps / dt,
-            "unit": "calls/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "backend update_batch calls/s, 512x384 48-KF graph", "value": D.world * args.steps / dt,
+            "unit": "calls/s", "n_gpus": D.n_ranks_seen(), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16 (correlation, GRU) + f32 geometry/BA", "data": "synthetic",
+            "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": f"update_batch(itrs=2, steps=1), E={int(graph.ii.numel())} edges, "
                                    f"{args.keyframes} keyframes, one clip per GPU"}}))
+    D.close()
 
 
-def video_mode(args, device, world, rank):
-    """Secondary figure of SURVEY 8(d): frames/s of the keyframe frontend (frontend.py:78-167 mirror) on a synthetic
-    512x384xN "video" in which every frame is a keyframe: per frame = motion filter on the RGB frame (feature encoder,
-    one flow-update application against the last keyframe, context encoder), proximity-edge proposal (frame_distance kernel),
-    correlation volume + pyramid + gate-context build for the new edges, 4 (+2) update iterations over the <= 48-edge
-    window incl. the dense BA with inactive edges.  Frames are seeded uniform RGB images resident in HBM
-    (`--video-features`: seeded N(0,1) feature maps instead, encoders skipped), poses follow a smooth seeded trajectory (constant-velocity initialisation, then the BA moves
-    them), random-init operator weights."""
-    import torch.distributed as dist
+def plumbing_mode(args, D):
+    """The N > 1 plumbing without a GPU (CPU rehearsal of BASELINE config 4's control flow, used by tests/): rank
+    processes started by `spawn_ranks`, a gloo process group, `run_sharded` over `--clips` fake clips (seeded
+    trajectories, no SLAM), the one all_gather, artifacts by rank 0, one JSON line.  Nothing of the hot path runs here."""
+    from vipe_amd.driver import artifacts
+    from vipe_amd.driver.clip_shard import ClipResult, run_sharded
 
-    from vipe_amd.slam.buffer import GraphBuffer
-    from vipe_amd.slam.frontend import FrontendArgs, SLAMFrontend
-    from vipe_amd.slam.motion_filter import DroidNet, MotionFilter
+    os.environ.setdefault("VIPE_BENCH_DIST_BACKEND", "gloo")
+    D.init()
+    n_clips = args.clips or D.world
 
-    N = args.frames
-    torch.manual_seed(1234 + rank)
-    buf = GraphBuffer(384, 512, buffer_size=N + 16, device=device)
-    buf.intrinsics[:] = torch.tensor([460.8, 460.8, 256.0, 192.0], device=device)
-    torch.manual_seed(0)
-    dn = DroidNet()  # fnet + cnet + update operator, random-init weights (no checkpoint offline)
-    um = dn.update
-    # keyframe_thresh = 0: every synthetic frame stays a keyframe (random-weight flow would otherwise make the
-    # distance test drop about half of them and the window would hold ~16 instead of <= 48 edges)
-    fe = SLAMFrontend(um, buf, FrontendArgs(keyframe_thresh=0.0), device)
-    gen = torch.Generator(device="cpu").manual_seed(99 + rank)
-    pool_d = (1.0 / (1.0 + 4.0 * torch.rand(32, 48, 64, generator=gen))).to(device)
-    if args.video_features:
-        # legacy variant: the "decoded + encoded" frames are a pool of seeded feature maps resident in HBM
-        pool_f = torch.randn(32, 128, 48, 64, generator=gen).half().to(device)
-        pool_n = torch.randn(32, 128, 48, 64, generator=gen).tanh().half().to(device)
-        pool_i = torch.randn(32, 128, 48, 64, generator=gen).relu().half().to(device)
-    else:
-        # decoded RGB frames resident in HBM before the timed region (decode / resize are host work outside the path);
-        # every frame goes through the motion filter: feature encoder, one flow-update application against the last
-        # keyframe, context encoder (thresh 0: every frame becomes a keyframe)
-        pool_img = torch.rand(32, 1, 3, 384, 512, generator=gen).to(device)
-        mf = MotionFilter(dn, thresh=0.0, device=device)
+    def process(cid):
+        gen = torch.Generator().manual_seed(cid)
+        poses = torch.zeros(args.frames, 7)
+        poses[:, :3] = torch.randn(args.frames, 3, generator=gen).cumsum(0) * 0.01
+        poses[:, 6] = 1.0
+        return ClipResult(cid, poses, torch.tensor([460.8, 460.8, 256.0, 192.0]))
 
-    def feed():
-        t = buf.n_frames
-        if args.video_features:
-            buf.fmaps[t, 0], buf.nets[t, 0], buf.inps[t, 0] = pool_f[t % 32], pool_n[t % 32], pool_i[t % 32]
-        else:
-            keep = mf.check(pool_img[t % 32], None)
-            assert keep, "threshold 0 keeps every frame"
-            buf.fmaps[t], buf.nets[t], buf.inps[t] = mf.f_fmap, mf.f_net, mf.f_inp
-        if t < fe.args.warmup:  # until the frontend owns the poses: smooth trajectory along x
-            buf.poses[t, 0] = 0.05 * t
-            buf.disps[t, 0] = pool_d[t % 32]
-        buf.n_frames += 1
-        fe.run()
-
-    fed = 0
-    while not fe.is_initialized:  # warm-up: initialisation (8 keyframes, 8 update iterations), untimed
-        feed()
-        fed += 1
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    D.barrier()
     t0 = time.perf_counter()
-    u0 = fe.n_updates
-    for _ in range(N - fed):
-        feed()
-    backend_edges = None
-    if args.with_backend:  # system.py:272-275: global BA over all keyframes, twice (fresh graph each time)
-        from vipe_amd.slam.backend import BackendArgs, SLAMBackend
-        be = SLAMBackend(um, buf, BackendArgs(), device)
+    results = run_sharded(n_clips, process, f_max=args.frames)
+    D.barrier()
+    dt = D.max_over_ranks(time.perf_counter() - t0)
+    if D.rank == 0:
+        out_dir = args.out_dir or tempfile.mkdtemp(prefix="vipe_amd_artifacts_")
+        written = artifacts.save_clip_results(out_dir, results)
+        if not args.out_dir:
+            shutil.rmtree(out_dir, ignore_errors=True)
+        print(json.dumps({"metric": "plumbing only (no GPU work)", "value": n_clips * args.frames / dt, "unit": "frames/s",
+                          "n_gpus": D.n_ranks_seen(), "steps": n_clips * args.frames, "warmup": 0, "data": "synthetic",
+                          "config": {"workload": "launch + gloo process group + result gather + artifacts",
+                                     "clips": len(results), "artifacts_written": len(written),
+                                     "clip_ids": [r.clip_id for r in results]}}))
+    D.close()
+
+
+# ---------------------------------------------------------------------------------------------- secondary figures
+def secondary_figures(args, device, graph, step):
+    """Figures north_star asks to be reported next to the headline, measured in the same driver-run process AFTER (and
+    outside) the timed headline region, N = 1 only.  Each is a plain eager-launch timing."""
+    out = {}
+
+    def timed(fn, n):
+        fn()
         torch.cuda.synchronize()
-        t_fe = time.perf_counter() - t0
-        be.run(7)
-        gb = be.run(BackendArgs().backend_iters, update_depth=False)
-        backend_edges = int(gb.ii.numel())
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    finite = bool(torch.isfinite(buf.poses[: buf.n_frames]).all() and torch.isfinite(buf.disps[: buf.n_frames]).all())
-    if rank == 0:
-        print(json.dumps({
-            "metric": "frames/s, keyframe frontend on a synthetic 512x384xN video (every frame a keyframe)",
-            "value": world * (N - fed) / dt, "unit": "frames/s", "n_gpus": world, "steps": N - fed, "warmup": fed,
-            "ms_per_step": 1e3 * dt / (N - fed), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16 (correlation, GRU) + f32 geometry/BA", "data": "synthetic",
-            "config": {"workload": f"{N} synthetic keyframes per clip, frontend window <= 48 edges, 4+2 update iterations "
-                                   f"per keyframe, one clip per GPU", "update_iterations": fe.n_updates - u0,
-                       "keyframes_kept": int(buf.n_frames), "edges_final": int(fe.graph.ii.numel()),
-                       "global_ba": None if backend_edges is None else
-                       {"passes": "backend.run(7) + backend.run(24), 8 GN iterations per step", "edges": backend_edges,
-                        "frontend_seconds": t_fe, "backend_seconds": dt - t_fe},
-                       "input": "feature maps (encoders skipped)" if args.video_features else
-                                "RGB frames: motion filter + feature / context encoders in the timed region",
-                       "state_finite": finite}}))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return n / (time.perf_counter() - t0)
+
+    # (1) the same step with ALL of the operator's work inside the iteration: the context-feature part of the GRU gates
+    # recomputed every iteration (as the reference does) instead of once per edge at add_factors
+    if getattr(graph, "pgate", None) is not None:
+        keep, graph.pgate = graph.pgate, None
+        out["value_all_gate_work_per_iteration"] = timed(step, 6)
+        graph.pgate = keep
+    # (2) E = 768 stress (backend cap 16 t): radius-3 graph + 492 seeded long-range edges
+    try:
+        _, _, g768 = build_problem(device, args.keyframes, 384, 512, 3, 492, seed=4321)
+        out["value_E768"] = timed(lambda: g768.update(t0=1, t1=args.keyframes, itrs=3), 5)
+        out["E768_edges"] = int(g768.ii.numel())
+        del g768
+        torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001 - a secondary figure must not take the headline down with it
+        out["value_E768"] = f"failed: {type(e).__name__}: {e}"
+    # (3) synthetic video, 200 frames from RGB: keyframe frontend, then the two global-BA passes of SLAMSystem.run
+    try:
+        run_clip = make_clip_runner(device)
+        run_clip(seed=10_000, n_frames=24)
+        r = run_clip(seed=0, n_frames=args.frames, with_backend=True)
+        out["frames_per_s"] = {
+            "frontend_only": r["frames"] / r["frontend_seconds"], "with_global_ba": r["frames"] / r["seconds"],
+            "frames": r["frames"], "update_iterations": r["update_iterations"], "backend_edges": r["backend_edges"],
+            "state_finite": r["finite"],
+            "what": "one synthetic 512x384 clip from RGB frames resident in HBM, every frame a keyframe: motion filter + "
+                    "encoders + proximity edges + 4+2 update iterations per keyframe (whole clip incl. the 8-keyframe "
+                    "initialisation); with_global_ba adds backend.run(7) + backend.run(24)"}
+    except Exception as e:  # noqa: BLE001
+        out["frames_per_s"] = f"failed: {type(e).__name__}: {e}"
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--keyframes", type=int, default=48)
-    ap.add_argument("--extra-edges", type=int, default=0, help="seeded long-range edges on top of the radius-3 graph")
-    ap.add_argument("--conv", default=os.environ.get("VIPE_AMD_CONV", "hip"), choices=["hip", "miopen"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--prof-steps", type=int, default=2)
-    ap.add_argument("--mode", default="update", choices=["update", "video", "backend"],
-                    help="update: the headline metric (update iterations/s on the 48-keyframe graph); video: frames/s "
-                         "of the keyframe frontend on a synthetic video; backend: FactorGraph.update_batch calls/s "
-                         "(hot loop B: operator over all edges + 2 GN iterations of global BA) on the same graph")
-    ap.add_argument("--frames", type=int, default=200)
-    ap.add_argument("--no-hipgraph", action="store_true",
-                    help="update mode: time eager launches instead of replaying the captured two-step HIP graph")
-    ap.add_argument("--with-backend", action="store_true",
-                    help="video mode: after the frontend pass also run the two global-BA passes of SLAMSystem.run "
-                         "(backend.run(7), backend.run(24): system.py:272-275) inside the timed region")
-    ap.add_argument("--video-features", action="store_true",
-                    help="video mode: feed seeded feature maps instead of RGB frames (skips motion filter + encoders)")
-    ap.add_argument("--also-without-gate-hoist", action="store_true",
-                    help="additionally time the step with the context part of the GRU gates recomputed every iteration "
-                         "(value_all_gate_work_per_iteration); off by default so that every launch of the roofline "
-                         "kernel in the default command is of the same population as the event-timed ones")
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------- headline
+def update_mode(args, D):
+    from vipe_amd.driver.clip_shard import ClipResult, gather_results
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch.distributed as dist
-
-    # one rank per GPU; the modulo only matters for rehearsing the multi-rank path on a box with fewer GPUs than ranks
-    # (VIPE_BENCH_DIST_BACKEND=gloo, ranks share the card)
-    device = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
-    torch.cuda.set_device(device)
-
-    def init_dist():
-        if world > 1 and not dist.is_initialized():
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            backend = os.environ.get("VIPE_BENCH_DIST_BACKEND", "nccl")  # nccl = RCCL on ROCm
-            if backend == "nccl":
-                dist.init_process_group("nccl", device_id=device)
-            else:
-                dist.init_process_group(backend)
-
-    if args.mode == "video":
-        init_dist()
-        video_mode(args, device, world, rank)
-        if world > 1:
-            dist.destroy_process_group()
-        return
-    if args.mode == "backend":
-        init_dist()
-        backend_mode(args, device, world, rank)
-        if world > 1:
-            dist.destroy_process_group()
-        return
-
+    device, world, rank = D.device, D.world, D.rank
     # clip sharding: rank r owns clip r (seed differs per rank), no exchange during compute
-    g, buf, graph = build_problem(device, args.keyframes, 384, 512, 3, args.extra_edges, args.conv, seed=1234 + rank)
+    g, buf, graph = build_problem(device, args.keyframes, 384, 512, 3, args.extra_edges, seed=1234 + rank)
     E = int(graph.ii.numel())
 
     def step():
@@ -298,15 +434,12 @@ def main():
     for _ in range(args.warmup):
         step()
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
     # The update iteration has no host read-back and no shape that changes from step to step, so TWO consecutive steps
-    # (the hidden state ping-pongs between two buffers) are captured once into a HIP graph and the timed region replays
-    # it: the same kernels on the same stream, minus the ~45 Python / ctypes launches per step - which keeps the figure
-    # independent of host jitter (eight ranks share one host's cores in the multi-GPU run; back-to-back runs on one box
-    # lost up to 15 % to slow launch loops with identical kernel times).  `--no-hipgraph` times eager launches.
+    # (the hidden state ping-pongs between two buffers; targets / weights / poses / disparities are updated in place, so
+    # every replay continues from the state the previous one left) are captured once into a HIP graph and the timed
+    # region replays it: the same kernels on the same stream, minus the ~45 Python / ctypes launches per step - which
+    # keeps the figure independent of host jitter (eight ranks share one host's cores in the multi-GPU run).
+    # `--no-hipgraph` times eager launches.
     launch, cg = "eager", None
     if not args.no_hipgraph and args.steps >= 2:
         try:
@@ -330,9 +463,9 @@ def main():
             launch = f"eager (graph capture failed: {type(e).__name__})"
     # RCCL comes up only now: problem set-up, warm-up and the graph capture above are rank-local (clip sharding has no
     # data-path collective), so no communicator thread is alive while a stream is being captured
-    init_dist()
+    D.init()
     torch.cuda.synchronize()
-    barrier()
+    D.barrier()
     t0 = time.perf_counter()
     if cg is not None:
         for _ in range(args.steps // 2):
@@ -343,30 +476,17 @@ def main():
         for _ in range(args.steps):
             step()
     torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    # ---- the same step with ALL of the operator's work inside the iteration: by default the part of the GRU gate
-    # convolutions that depends only on the per-edge context features is computed once per edge at add_factors (like
-    # the correlation volume) and enters the gates as the initial accumulator value; this second figure recomputes it
-    # every iteration, as the reference does
-    value_no_hoist = None
-    if args.also_without_gate_hoist and world == 1 and getattr(graph, "pgate", None) is not None:
-        keep = graph.pgate
-        graph.pgate = None
-        nb = max(3, args.steps // 4)
-        step()
-        torch.cuda.synchronize()
-        tb = time.perf_counter()
-        for _ in range(nb):
-            step()
-        torch.cuda.synchronize()
-        value_no_hoist = nb / (time.perf_counter() - tb)
-        graph.pgate = keep
+    t_steps = time.perf_counter() - t0
+    # the job's one exchange: every rank's clip result (trajectory + intrinsics, ~1.4 KB here) in one all_gather
+    mine = ClipResult(rank, buf.poses[:args.keyframes], buf.intrinsics[0, :4], ok=True, seconds=t_steps)
+    results = gather_results([mine], n_clips=world, f_max=args.keyframes)
+    gather_ms = 1e3 * (time.perf_counter() - t0 - t_steps)
+    torch.cuda.synchronize()
+    D.barrier()
+    dt = D.max_over_ranks(time.perf_counter() - t0)
+    finite = bool(torch.isfinite(buf.poses[:args.keyframes]).all() and torch.isfinite(buf.disps[:args.keyframes]).all()
+                  and torch.isfinite(graph.target).all())
+    n_seen = D.n_ranks_seen()
 
     # ---- roofline of the dominant kernel: conv_halo32_kernel<128, 3, true> (every 3x3 convolution of the
     # flow-update operator with >= 128 output channels: corr2, z|r, q, delta0|weight0|agg1, agg2 - 5 launches per
@@ -374,77 +494,120 @@ def main():
     # the launch stream; achieved = (algorithmic flops of those launches) / (their summed duration).
     eng = graph.update_op.engine(device)
     rec = []
-    achieved = gate_ms = float("nan")
-    flops_per_launch = 0.0
-    if eng.backend == "hip":
-        orig = eng._conv
+    orig = eng._conv
 
-        def timed(pk, x0, x0_coff, B, H, W, *a, **k):
-            cin = k.get("cin") or pk.cin
-            if pk.cout > 64 and pk.kh == 3:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                orig(pk, x0, x0_coff, B, H, W, *a, **k)
-                e1.record()
-                rec.append((e0, e1, 2.0 * B * H * W * cin * pk.cout * pk.kh * pk.kw))
-            else:
-                orig(pk, x0, x0_coff, B, H, W, *a, **k)
+    def timed_conv(pk, x0, x0_coff, B, H, W, *a, **k):
+        cin = k.get("cin") or pk.cin
+        if pk.cout > 64 and pk.kh == 3:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(pk, x0, x0_coff, B, H, W, *a, **k)
+            e1.record()
+            rec.append((e0, e1, 2.0 * B * H * W * cin * pk.cout * pk.kh * pk.kw))
+        else:
+            orig(pk, x0, x0_coff, B, H, W, *a, **k)
 
-        eng._conv = timed
-        for _ in range(args.prof_steps):
-            step()
-        torch.cuda.synchronize()
-        eng._conv = orig
-        tot_ms = sum(a.elapsed_time(b) for a, b, _ in rec) or float("nan")
-        tot_fl = sum(f for _, _, f in rec)
-        gate_ms = tot_ms / max(1, len(rec))
-        flops_per_launch = tot_fl / max(1, len(rec))
-        achieved = tot_fl / (tot_ms * 1e-3) / 1e12
+    eng._conv = timed_conv
+    for _ in range(args.prof_steps):
+        step()
+    torch.cuda.synchronize()
+    eng._conv = orig
+    tot_ms = sum(a.elapsed_time(b) for a, b, _ in rec) or float("nan")
+    tot_fl = sum(f for _, _, f in rec)
+    gate_ms = tot_ms / max(1, len(rec))
+    flops_per_launch = tot_fl / max(1, len(rec))
+    achieved = tot_fl / (tot_ms * 1e-3) / 1e12
 
-    # HBM traffic of the dominant kernel per launch, from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-    # profiles/r01_summary.json; counters cannot be collected from inside the timed process)
-    traffic = None
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_summary.json")))["void conv_halo32_kernel<128, 3, true>"]
-        traffic = (prof["hbm_read_MB_per_launch"] + prof["hbm_write_MB_per_launch"]) * 1e6
-    except Exception:  # noqa: BLE001
-        pass
+    # HBM traffic of the dominant kernel per launch: FETCH_SIZE x2 + WRITE_SIZE from the builder's own rocprofv3 --pmc
+    # passes of this command (profiles/rNN_summary.json, committed) - counters cannot be collected from inside the
+    # timed process, so this is NOT a measurement of this run
+    traffic, traffic_src = None, None
+    for name in ("r02_summary.json", "r01_summary.json"):
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", name)))["void conv_halo32_kernel<128, 3, true>"]
+            traffic = (prof["hbm_read_MB_per_launch"] + prof["hbm_write_MB_per_launch"]) * 1e6
+            traffic_src = f"profiles/{name}: builder-side rocprofv3 --pmc passes of this command, not this run"
+            break
+        except Exception:  # noqa: BLE001
+            pass
 
     if rank == 0:
         out = {
             "metric": "dense-BA+flow update iters/s, 512x384 48-KF graph",
             "value": world * args.steps / dt,
             "unit": "iters/s",
-            "n_gpus": world,
+            "n_gpus": n_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16 (correlation, GRU; fp32 accumulate) + f32 geometry/BA (fp64 reduced system)",
+            "dtype": DTYPE,
             "data": "synthetic",
-            "config": {"workload": f"configs[2]-shaped: 512x384, {args.keyframes}-keyframe factor graph, E={E} edges "
-                                   f"(radius-3 bidirectional), 3 GN iterations per update, one clip per GPU",
-                       "conv_backend": args.conv, "parallelism": f"clip-sharded x{world}", "launch": launch,
+            "config": {"workload": f"configs[2]: 512x384, {args.keyframes}-keyframe factor graph, E={E} edges "
+                                   f"(radius-3 bidirectional), depth_align on (sensor-depth prior on every keyframe), "
+                                   f"3 GN iterations per update, one clip per GPU",
+                       "parallelism": f"clip-sharded x{world}", "launch": launch,
+                       "result_gather": {"clips": len(results), "ms": gather_ms, "inside_timed_region": True,
+                                         "backend": D.dist.get_backend() if D.dist.is_initialized() else "none (1 rank)"},
+                       "state_finite": finite,
                        "gate_context": "context-feature part of the GRU gates computed once per edge (at add_factors, "
                                        "like the correlation volume), not per iteration"
                                        if getattr(graph, "pgate", None) is not None else "recomputed every iteration"},
-            "value_all_gate_work_per_iteration": value_no_hoist,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP16_TFLOPS, "traffic": traffic,
+                         "frac": achieved / PEAK_FP16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "conv_halo32_kernel<128, 3, true> (NHWC fp16 implicit-GEMM 3x3 conv on MFMA 16x16x32, "
                                    "all launches with Cout >= 128 of the flow-update operator)",
                          "avg_launch_ms": gate_ms, "flops_per_launch": flops_per_launch,
                          "launches_per_step": len(rec) // max(1, args.prof_steps)},
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
-        else:
-            out["cpu_baseline"] = None
+        if world == 1 and not args.no_secondary:
+            out.update(secondary_figures(args, device, graph, step))
+        out["cpu_baseline"] = cpu_baseline() if (world == 1 and not args.no_cpu_baseline) else None
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    D.close()
+    if not finite:
+        sys.exit(3)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--keyframes", type=int, default=48)
+    ap.add_argument("--extra-edges", type=int, default=0, help="seeded long-range edges on top of the radius-3 graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="update mode: skip the secondary figures (all-gate-work it/s, E=768 it/s, video frames/s)")
+    ap.add_argument("--prof-steps", type=int, default=2)
+    ap.add_argument("--mode", default="update", choices=["update", "video", "backend", "plumbing"],
+                    help="update: the headline metric (update iterations/s on the 48-keyframe graph); video: frames/s "
+                         "of independent synthetic clips through the keyframe frontend, clip-sharded over the ranks "
+                         "(BASELINE config 4); backend: FactorGraph.update_batch calls/s (hot loop B) on the same graph")
+    ap.add_argument("--frames", type=int, default=200, help="frames per synthetic clip")
+    ap.add_argument("--clips", type=int, default=0, help="video mode: number of clips (default: one per rank)")
+    ap.add_argument("--out-dir", default=None, help="video mode: keep rank 0's pose / intrinsics artifacts here")
+    ap.add_argument("--no-hipgraph", action="store_true",
+                    help="update mode: time eager launches instead of replaying the captured two-step HIP graph")
+    ap.add_argument("--with-backend", action="store_true",
+                    help="video mode: after the frontend pass also run the two global-BA passes of SLAMSystem.run "
+                         "(backend.run(7), backend.run(24): system.py:272-275) inside the timed region")
+    ap.add_argument("--video-features", action="store_true",
+                    help="video mode: feed seeded feature maps instead of RGB frames (skips motion filter + encoders)")
+    args = ap.parse_args()
+
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        sys.exit(spawn_ranks(args.gpus))  # nothing above touched the GPU
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks\n")
+        sys.exit(2)
+
+    D = Dist(use_gpu=args.mode != "plumbing")
+    {"update": update_mode, "video": video_mode, "backend": backend_mode, "plumbing": plumbing_mode}[args.mode](args, D)
 
 
 if __name__ == "__main__":

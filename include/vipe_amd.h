@@ -251,6 +251,12 @@ int vipe_iproj(const float* d_poses, const float* d_disps, const float* d_intrin
 int vipe_scatter(const void* d_src, const int64_t* d_index, void* d_out, int64_t* d_arg_out, int64_t outer,
                  int64_t src_dim, int64_t inner, int64_t out_dim, int reduce, int dtype, void* stream);
 
+/* The same reductions over HOST memory (float32 / float64), for CPU tensors handed to the Python-level scatter API
+ * (vipe/ext/scatter.py:24-63 accepts them through torch.scatter_add_).  Sequential and deterministic; min / max ties
+ * resolve to the last source row.  Index values are range-checked (VIPE_EINVAL). */
+int vipe_scatter_host(const void* h_src, const int64_t* h_index, void* h_out, int64_t* h_arg_out, int64_t outer,
+                      int64_t src_dim, int64_t inner, int64_t out_dim, int reduce, int dtype);
+
 /* [fused] segmented mean of per-edge feature maps onto source nodes (GraphAgg, droid_net.py:420-421):
  * src [E,inner] f16, ix [E] int64 sorted or not, out [n_out,inner] f16 = mean over edges with ix == k. */
 int vipe_scatter_mean_rows_f16(const void* d_src, const int64_t* d_ix, void* d_out, int E, int n_out, int64_t inner,

@@ -40,6 +40,54 @@ def _worker(rank, world, port, n_clips, q):
     dist.destroy_process_group()
 
 
+def _worker_edge(rank, world, port, q):
+    """3 clips on 4 ranks: rank 3's shard is empty; clip 0 (rank 0's FIRST clip) fails; clip 2 is longer than f_max."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def process(cid):
+        if cid == 0:
+            raise RuntimeError("decoder failed")
+        poses = torch.zeros(4 if cid == 1 else 9, 7)
+        poses[:, 6] = 1
+        return ClipResult(cid, poses, torch.tensor([1.0, 2.0, 3.0, 4.0]))
+
+    res = run_sharded(3, process, f_max=6, strict=False)
+    strict_raises = False
+    try:
+        run_sharded(3, process, f_max=6, strict=True)
+    except ValueError:
+        strict_raises = True
+    q.put((rank, [(r.clip_id, r.ok, tuple(r.poses.shape), r.truncated) for r in res], strict_raises))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_with_empty_shard_failed_first_clip_and_overlong_trajectory():
+    """the exchange device comes from the process group, not from the results, so a rank that holds no
+    tensor at all (empty shard / failed first clip) still enters the collective; F > f_max is flagged, never silent."""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_edge, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, got, strict_raises in outs:
+        assert got == [(0, False, (0, 7), False), (1, True, (4, 7), False), (2, True, (6, 7), True)]
+        assert strict_raises, "strict mode must raise on every rank after the exchange"
+
+
+def test_exchange_device_without_process_group_is_cpu():
+    from vipe_amd.driver.clip_shard import exchange_device
+    assert exchange_device() == torch.device("cpu")
+
+
 def test_shard_assignment_is_a_partition():
     for n, w in [(8, 8), (5, 2), (1, 4), (0, 3), (17, 8)]:
         parts = [shard_clips(n, r, w) for r in range(w)]
@@ -154,3 +202,28 @@ def test_corr_pool_adopts_a_large_first_block():
     assert [float(x) for x in pool.corr_pyramid[0][:, 0, 0, 0, 0]] == [10, 11, 12, 13, 14, 20, 21]
     pool = pool[np.array([1, 5])]
     assert [float(x) for x in pool.corr_pyramid[1][:, 0, 0, 0, 0]] == [11, 20] and len(pool._free) == pool.pool[0].shape[0] - 2
+
+
+def test_bench_gpus_flag_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` (no external launcher) must start two rank processes, run the
+    result gather and print ONE line with n_gpus = 2.  `--mode plumbing` is the launch / process-group / gather /
+    artifact control flow of the video mode with fake clips, so it runs without a GPU (gloo)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mode", "plumbing", "--clips", "5",
+                        "--frames", "12", "--out-dir", str(tmp_path / "art")], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["clip_ids"] == [0, 1, 2, 3, 4] and out["config"]["artifacts_written"] == 5
+    assert sorted(os.listdir(tmp_path / "art" / "pose")) == [f"clip_{i:05d}.npz" for i in range(5)]
+    # a launcher / flag mismatch is an error, not a silent single-rank run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mode", "plumbing"],
+                       capture_output=True, text=True, env=env2, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr

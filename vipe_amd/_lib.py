@@ -85,7 +85,14 @@ class VipeError(RuntimeError):
     pass
 
 
+_RESTORE_DEVICE = None  # set by stream_ptr() when it had to switch devices for one call, undone by check()
+
+
 def check(code, what):
+    global _RESTORE_DEVICE
+    if _RESTORE_DEVICE is not None:
+        torch.cuda.set_device(_RESTORE_DEVICE)
+        _RESTORE_DEVICE = None
     if code == 0:
         return
     names = {-1: "VIPE_EINVAL (bad argument)", -2: "VIPE_ENOSPACE (workspace too small)",
@@ -96,8 +103,18 @@ def check(code, what):
 
 
 def stream_ptr(t=None):
-    """hipStream_t of torch's current stream on the tensor's device."""
+    """hipStream_t of torch's current stream on the tensor's device.  Every entry point is called as
+    `check(lib().vipe_x(..., stream_ptr(t)), "x")`: if `t` lives on another device than the current one, that device is
+    made current for the duration of the call (kernel launches and function attributes go to the CURRENT device) and
+    `check` switches back - the device guard of the reference's bindings (correlation_sampler.cpp:44-58)."""
+    global _RESTORE_DEVICE
     dev = t.device if t is not None else None
+    if dev is not None and dev.type == "cuda" and dev.index is not None:
+        cur = torch.cuda.current_device()
+        if cur != dev.index:
+            if _RESTORE_DEVICE is None:
+                _RESTORE_DEVICE = cur
+            torch.cuda.set_device(dev)
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 

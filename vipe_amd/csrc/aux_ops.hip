@@ -321,6 +321,40 @@ VIPE_EXPORT int vipe_scatter(const void* d_src, const int64_t* d_index, void* d_
   return VIPE_EINVAL;
 }
 
+// Host-memory twin of vipe_scatter for CPU tensors (the reference's Python-level scatter_add / scatter_mean accept
+// them, vipe/ext/scatter.py:24-63): the same combine rules in a sequential loop (deterministic; ties of min / max
+// resolve to the LAST source row, as the device kernel's second pass does).
+namespace {
+template <typename T>
+void scatter_host(const T* src, const int64_t* index, T* out, int64_t* arg, int64_t outer, int64_t E, int64_t K, int64_t N,
+                  int reduce) {
+  for (int64_t b = 0; b < outer; ++b)
+    for (int64_t e = 0; e < E; ++e)
+      for (int64_t k = 0; k < K; ++k) {
+        const int64_t i = (b * E + e) * K + k;
+        const int64_t o = b * N * K + index[i] * K + k;
+        const T v = src[i], cur = out[o];
+        if (reduce == 0 || reduce == 2) out[o] = cur + v;
+        else if (reduce == 1) out[o] = cur * v;
+        else if (reduce == 3) { if (v <= cur) { out[o] = v; arg[o] = e; } }
+        else { if (v >= cur) { out[o] = v; arg[o] = e; } }
+      }
+}
+}  // namespace
+
+VIPE_EXPORT int vipe_scatter_host(const void* h_src, const int64_t* h_index, void* h_out, int64_t* h_arg_out, int64_t outer,
+                                  int64_t src_dim, int64_t inner, int64_t out_dim, int reduce, int dtype) {
+  VIPE_CHECK_ARG(outer >= 0 && src_dim >= 0 && inner >= 0 && out_dim >= 0 && reduce >= 0 && reduce <= 4);
+  if (outer * src_dim * inner == 0) return VIPE_OK;
+  VIPE_CHECK_ARG(h_src && h_index && h_out && (reduce < 3 || h_arg_out));
+  for (int64_t i = 0; i < outer * src_dim * inner; ++i) VIPE_CHECK_ARG(h_index[i] >= 0 && h_index[i] < out_dim);
+  switch (dtype) {
+    case VIPE_F32: scatter_host<float>((const float*)h_src, h_index, (float*)h_out, h_arg_out, outer, src_dim, inner, out_dim, reduce); return VIPE_OK;
+    case VIPE_F64: scatter_host<double>((const double*)h_src, h_index, (double*)h_out, h_arg_out, outer, src_dim, inner, out_dim, reduce); return VIPE_OK;
+  }
+  return VIPE_EINVAL;
+}
+
 VIPE_EXPORT int vipe_segment_mean_nhwc_f16(const void* d_src, int src_ctot, int src_coff, const int* d_order,
                                            const int* d_rowptr, void* d_out, int n_out, int64_t rows_per_item, int C,
                                            void* stream) {

@@ -34,7 +34,7 @@ struct BAWs {
   int* order;       // [M] term ids sorted by source frame (stable)
   int* pose_slot;   // [nP] slot in the reduced system or -1
   int* slot_pose;   // [nP] inverse map
-  int* fflags;      // [nF] bit0 source, bit1 disparity free, bit2 sensor prior
+  int* fflags;      // [nF] bit0 source, bit1 disparity free (the sensor-prior test is NOT part of the plan: finish_disp reads sens_sum, refreshed every call)
   int* scratch;     // [2*nP + nF]
   int* info;        // [8] n_free, n_free_disp, chol_fail, n_unknowns
   float* sens_sum;  // [nF]
@@ -177,7 +177,6 @@ __global__ __launch_bounds__(1024) void ba_plan_kernel(BAArgs a) {
     } else {
       bool dfree = f && !p.motion_only && !(p.limited_disp && (pose < p.t0 || pose >= p.t1));  // buffer.py:490-493
       if (dfree) { f |= 2; ++nfd_local; }
-      if (dfree && a.w.sens_sum[k] > 0.0f) f |= 4;
     }
     a.w.fflags[k] = f;
   }
@@ -2166,11 +2165,10 @@ int run_iters(const BAArgs& a, hipStream_t s) {
   panel_cap = (panel_cap + 3) & ~3;
   const size_t solve_lds = fixed + (size_t)NB * panel_cap * sizeof(double);
   const size_t band_lds = 158 * 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_set{0};  // bit d: set on device d
+  if (vipe_first_on_device(attr_set)) {
     (void)hipFuncSetAttribute((const void*)ba_solve_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   (void)hipFuncSetAttribute((const void*)ba_accum_mfma_kernel<CAM, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_mfma_lds());
   (void)hipFuncSetAttribute((const void*)ba_walk_kernel<CAM, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds());

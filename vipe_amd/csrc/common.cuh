@@ -4,6 +4,8 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/vipe_amd.h"
 
 #define VIPE_EXPORT extern "C" __attribute__((visibility("default")))
@@ -16,6 +18,15 @@
 static inline int vipe_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? VIPE_OK : (int)e;
+}
+
+// true exactly once per (call site, device): hipFuncSetAttribute is a per-device setting, and a process may drive
+// several devices (one process per GPU is the deployment model, but the library must not depend on it)
+static inline bool vipe_first_on_device(std::atomic<uint64_t>& seen) {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  const uint64_t bit = 1ull << (d & 63);
+  return !(seen.fetch_or(bit) & bit);
 }
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }

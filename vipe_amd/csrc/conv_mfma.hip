@@ -1205,12 +1205,11 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
   if (M == 0) return VIPE_OK;
   const bool small = a.Cin == 4;
   const int gx = (int)((M + BNP - 1) / BNP);
-  static bool attr = false;
-  if (!attr) {
+  static std::atomic<uint64_t> attr{0};  // bit d: set on device d
+  if (vipe_first_on_device(attr)) {
     (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<128, 2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<128, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)conv_mfma_glds_kernel<128, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    attr = true;
   }
   const bool glds = !small && a.KH * a.KW <= 32 && getenv("VIPE_AMD_CONV_REGSTAGE") == nullptr;
   const bool halo = glds && a.W % HALO_TW == 0 && a.H % HALO_TH == 0 && a.KH == a.KW && (a.KH == 1 || a.KH == 3) &&
@@ -1224,35 +1223,32 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
   if (a.epi == EPI_GLO && a.KH == 1 && a.KW == 1 && a.Cin == 128 && a.Cout == 128 && cp == 128 && a.split >= a.Cin &&
       (a.H * a.W) % 256 == 0 && a.x0_ctot % 8 == 0 && a.x0_coff % 8 == 0 && a.net == a.x0 && a.net_ctot == a.x0_ctot &&
       a.net_coff == a.x0_coff && a.extra == nullptr && getenv("VIPE_AMD_CONV_NOGLO") == nullptr) {
-    static bool gattr = false;
-    if (!gattr) {
+    static std::atomic<uint64_t> gattr{0};  // bit d: set on device d
+    if (vipe_first_on_device(gattr)) {
       (void)hipFuncSetAttribute((const void*)conv1x1_glo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GLO_LDS);
-      gattr = true;
     }
     conv1x1_glo_kernel<<<dim3((unsigned)(M / 256)), 512, GLO_LDS, s>>>(a);
     return vipe_launch_status();
   }
   if (halo && a.KH == 3 && a.Cout <= 16 && cp == 32 && (a.split >= a.Cin || a.split % H32_BK == 0) &&
       (a.epi == EPI_HEADS || a.epi == EPI_ETA || a.epi == EPI_PLAIN) && getenv("VIPE_AMD_CONV_NONARROW") == nullptr) {
-    static bool nattr = false;
-    if (!nattr) {
+    static std::atomic<uint64_t> nattr{0};  // bit d: set on device d
+    if (vipe_first_on_device(nattr)) {
       (void)hipFuncSetAttribute((const void*)conv_halo32_narrow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRW_LDS);
-      nattr = true;
     }
     conv_halo32_narrow_kernel<<<dim3((int)(M / (HALO_TH * HALO_TW))), 512, NRW_LDS, s>>>(a);
     return vipe_launch_status();
   }
   if (halo && (a.split >= a.Cin || a.split % H32_BK == 0)) {
-    static bool h32attr = false;
+    static std::atomic<uint64_t> h32attr{0};  // bit d: set on device d
     const int bmc = cp >= 128 ? 128 : cp;
-    if (!h32attr) {
+    if (vipe_first_on_device(h32attr)) {
       (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<128, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(128));
       (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<64, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(64));
       (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<32, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(32));
       (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<128, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(128));
       (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<64, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(64));
       (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<32, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(32));
-      h32attr = true;
     }
     const int gy = cp >= 128 ? cp / 128 : 1;
     const int tiles = (int)(M / (HALO_TH * HALO_TW));
@@ -1260,11 +1256,10 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
     const size_t lds = halo32_lds_bytes(bmc);
     static const bool m32 = getenv("VIPE_AMD_CONV_MFMA32") != nullptr;  // A/B: 32x32x16 fragments
     if (m32) {
-      static bool a32 = false;
-      if (!a32) {
+      static std::atomic<uint64_t> a32{0};  // bit d: set on device d
+      if (vipe_first_on_device(a32)) {
         (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<128, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(128));
         (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<128, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(128));
-        a32 = true;
       }
     }
     if (a.KH == 3) {
@@ -1282,10 +1277,9 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
   }
   if (small && a.KH == 7 && a.KW == 7 && a.W % HALO_TW == 0 && a.H % HALO_TH == 0 && cp % 128 == 0 && kp == 256 &&
       a.epi == EPI_PLAIN && a.extra == nullptr && getenv("VIPE_AMD_CONV_NO7X7") == nullptr) {
-    static bool a7 = false;
-    if (!a7) {
+    static std::atomic<uint64_t> a7{0};  // bit d: set on device d
+    if (vipe_first_on_device(a7)) {
       (void)hipFuncSetAttribute((const void*)conv7x7_c4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C7_LDS);
-      a7 = true;
     }
     const int gy = cp / 128;
     conv7x7_c4_kernel<<<dim3((int)(M / (HALO_TH * HALO_TW)) * gy), 512, C7_LDS, s>>>(a, gy);

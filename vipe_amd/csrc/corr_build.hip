@@ -210,10 +210,9 @@ VIPE_EXPORT int vipe_corr_pyramid_build(const void* d_fmap1, const void* d_fmap2
   a.f2 = (const half_t*)d_fmap2;
   for (int i = 0; i < 4; ++i) a.lv[i] = i < num_levels ? (half_t*)h_levels[i] : nullptr;
   a.B = B; a.h = h; a.w = w; a.nlev = num_levels;
-  static bool attr = false;
-  if (!attr) {
+  static std::atomic<uint64_t> attr{0};  // bit d: set on device d
+  if (vipe_first_on_device(attr)) {
     (void)hipFuncSetAttribute((const void*)corr_pyramid_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS);
-    attr = true;
   }
   corr_pyramid_build_kernel<<<dim3((unsigned)((int64_t)B * h * w / PB_M)), 512, PB_LDS, as_stream(stream)>>>(a);
   return vipe_launch_status();

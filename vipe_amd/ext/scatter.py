@@ -1,58 +1,25 @@
-"""Python-level scatter API (reference: vipe/ext/scatter.py:24-110).
+"""Python-level scatter API (what `vipe.slam` / `vipe.priors` host code imports from `vipe.ext.scatter`:
+scatter_add / scatter_sum / scatter_mean / scatter_mul / scatter_min / scatter_max / scatter, vipe/ext/scatter.py:24-110).
 
-As in the reference, scatter_add / scatter_mean go through torch.Tensor.scatter_add_ (vipe/ext/scatter.py:24-53,
-56-63) - they never reach the native module; scatter_mul/min/max do."""
-
-import torch
+Every reduction - sum and mean included, which the reference sends through `Tensor.scatter_add_` - runs in the library's
+own scatter kernel via `scatter_ext` (autograd-aware): GraphAgg's scatter_mean (droid_net.py:420-421) is a factor-graph
+scatter-add, one of the operators this backend exists to provide."""
 
 from . import scatter_ext
 
-
-def _broadcast(src, other, dim):
-    if dim < 0:
-        dim = other.dim() + dim
-    if src.dim() == 1:
-        for _ in range(dim):
-            src = src.unsqueeze(0)
-    for _ in range(src.dim(), other.dim()):
-        src = src.unsqueeze(-1)
-    return src.expand(other.size())
+_OPS = {"sum": scatter_ext.scatter_sum, "add": scatter_ext.scatter_sum, "mul": scatter_ext.scatter_mul,
+        "mean": scatter_ext.scatter_mean}
 
 
 def scatter_sum(src, index, dim=-1, out=None, dim_size=None):
-    index = _broadcast(index, src, dim)
-    if out is None:
-        size = list(src.size())
-        if dim_size is not None:
-            size[dim] = dim_size
-        elif index.numel() == 0:
-            size[dim] = 0
-        else:
-            size[dim] = int(index.max()) + 1
-        out = torch.zeros(size, dtype=src.dtype, device=src.device)
-    return out.scatter_add_(dim, index, src)
+    return scatter_ext.scatter_sum(src, index, dim, out, dim_size)
 
 
 scatter_add = scatter_sum
 
 
 def scatter_mean(src, index, dim=-1, out=None, dim_size=None):
-    out = scatter_sum(src, index, dim, out, dim_size)
-    dim_size = out.size(dim)
-    index_dim = dim
-    if index_dim < 0:
-        index_dim = index_dim + src.dim()
-    if index.dim() <= index_dim:
-        index_dim = index.dim() - 1
-    ones = torch.ones(index.size(), dtype=src.dtype, device=src.device)
-    count = scatter_sum(ones, index, index_dim, None, dim_size)
-    count[count < 1] = 1
-    count = _broadcast(count, out, dim)
-    if out.is_floating_point():
-        out.true_divide_(count)
-    else:
-        out.div_(count, rounding_mode="floor")
-    return out
+    return scatter_ext.scatter_mean(src, index, dim, out, dim_size)
 
 
 def scatter_mul(src, index, dim=-1, out=None, dim_size=None):
@@ -68,14 +35,9 @@ def scatter_max(src, index, dim=-1, out=None, dim_size=None):
 
 
 def scatter(src, index, dim=-1, out=None, dim_size=None, reduce="sum"):
-    if reduce in ("sum", "add"):
-        return scatter_sum(src, index, dim, out, dim_size)
-    if reduce == "mul":
-        return scatter_mul(src, index, dim, out, dim_size)
-    if reduce == "mean":
-        return scatter_mean(src, index, dim, out, dim_size)
-    if reduce == "min":
-        return scatter_min(src, index, dim, out, dim_size)[0]
-    if reduce == "max":
-        return scatter_max(src, index, dim, out, dim_size)[0]
-    raise ValueError(reduce)
+    """One entry point for all reductions; min / max return the values only (vipe/ext/scatter.py:200-203)."""
+    if reduce in _OPS:
+        return _OPS[reduce](src, index, dim, out, dim_size)
+    if reduce in ("min", "max"):
+        return getattr(scatter_ext, "scatter_" + reduce)(src, index, dim, out, dim_size)[0]
+    raise ValueError(f"unknown reduction {reduce!r}")

@@ -135,7 +135,9 @@ def _path_hint(state, key):
         return 0
     hints = state.setdefault("hints", {})
     pend = state.get("pending")
-    if pend is not None and pend[2].query():
+    # no event query while a stream is being captured (a query of an event recorded outside the capture is legal in
+    # relaxed mode only): the hint simply stays unknown for this call
+    if pend is not None and not torch.cuda.is_current_stream_capturing() and pend[2].query():
         k, host, _ = pend
         del state["pending"]
         if len(hints) > 64:

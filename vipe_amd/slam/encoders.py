@@ -93,6 +93,9 @@ class BasicEncoder(nn.Module):
         """x4 [n,H,W,4] fp16 normalised image (vipe_enc_prep) -> [n,output_dim,H/8,W/8] fp16 (NCHW)."""
         require(x4.is_cuda and x4.dtype == torch.float16 and x4.is_contiguous() and x4.shape[-1] == 4,
                 "BasicEncoder runs on the HIP device over a normalised NHWC4 fp16 image")
+        if x4.device.index is not None and x4.device.index != torch.cuda.current_device():
+            with torch.cuda.device(x4.device):  # the launches below share one stream handle: make its device current
+                return self.forward_x4(x4, tanh_split)
         P = self._pack(x4.device)
         st = stream_ptr(x4)
         n, H, W, _ = x4.shape

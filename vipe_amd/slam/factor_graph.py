@@ -99,7 +99,7 @@ class FactorGraph:
             xb[..., 0:128] = self.buffer.inps[pi, qi].permute(0, 2, 3, 1)
             self.xbuf = xb if self.xbuf is None else torch.cat([self.xbuf, xb], 0)
             eng = self.update_op.engine(self.device)
-            if eng.backend == "hip" and eng.supports_gate_split(self.ht, self.wd):
+            if eng.supports_gate_split(self.ht, self.wd):
                 pg = eng.gate_context(xb)
                 self.pgate = pg if self.pgate is None else torch.cat([self.pgate, pg], 0)
         target, _ = self.buffer.reproject_dense_disp(ii, jj)
@@ -341,22 +341,21 @@ class FactorGraph:
                                                        P["pi"], P["qi"], P["pj"], P["qj"], P["di"],
                                                        self.target[0].contiguous(), camera=buf.camera_type)
         eng = self.update_op.engine(self.device)
-        # hip: the lookup is deferred into the correlation encoder's first convolution (one kernel, no [E,h,w,200])
-        corr = self.corr.lookup_deferred(coords1) if eng.backend == "hip" else self.corr.lookup_nhwc(coords1)
-        if eng.backend == "hip":
-            self.net_n, dw, eta, _ = eng.forward_nhwc(self.net_n, self.xbuf, corr, motn, ix=P["dix"], n_src=P["n_src"],
-                                                      net_out=self._net_spare(), csr=P["csr"], pgate=self.pgate)
-            delta, weight = dw[None, ..., 0:2], dw[None, ..., 2:4]
-        else:  # A/B baseline: reference-shaped NCHW call
-            f_net, delta, weight, eta, _ = eng.forward(
-                self.net_n.permute(0, 3, 1, 2)[None], self.xbuf[..., 0:128].permute(0, 3, 1, 2)[None],
-                corr[..., :196].permute(0, 3, 1, 2)[None], motn.permute(0, 3, 1, 2)[None], ix=P["dix"],
-                skip_upmask=True, n_src=P["n_src"])
-            self.net_n = f_net[0].permute(0, 2, 3, 1).contiguous()
-            delta, weight, eta = delta.float(), weight.float(), eta[0]
-        # factor_graph.py:272 (`weight[:, masks[pi, qi]] = 0`) without the host sync of a boolean-mask assignment
-        self.weight = weight.masked_fill(buf.masks[P["pi"], P["qi"]][None, ..., None], 0.0)
-        self.target = coords1[None] + delta
+        # the lookup is deferred into the correlation encoder's first convolution (one kernel, no [E,h,w,200] tensor)
+        corr = self.corr.lookup_deferred(coords1)
+        self.net_n, dw, eta, _ = eng.forward_nhwc(self.net_n, self.xbuf, corr, motn, ix=P["dix"], n_src=P["n_src"],
+                                                  net_out=self._net_spare(), csr=P["csr"], pgate=self.pgate)
+        # factor_graph.py:272 (`weight[:, masks[pi, qi]] = 0`) without the host sync of a boolean-mask assignment.
+        # target / weight are rewritten IN PLACE: their addresses only change with the edge set, so a captured HIP graph of
+        # consecutive iterations chains through them (iteration k+1 reads what iteration k wrote) and the steady state
+        # allocates nothing
+        if "mask" not in P:
+            P["mask"] = buf.masks[P["pi"], P["qi"]][None, ..., None]
+        if not self.weight.is_contiguous() or not self.target.is_contiguous():
+            self.weight, self.target = self.weight.contiguous(), self.target.contiguous()
+        torch.add(coords1[None], dw[None, ..., 0:2], out=self.target)
+        self.weight.copy_(dw[None, ..., 2:4])
+        self.weight.masked_fill_(P["mask"], 0.0)
         self.damping[P["du"]] = eta
         if use_inactive:
             # factor_graph.py:296-304.  The selection of inactive edges and its multiview expansion only change with
@@ -406,8 +405,7 @@ class FactorGraph:
         # 288 GB of HBM the per-chunk volume (~33 MB per edge, ~1.5 GB per chunk of 8 source keyframes) is cheap, and
         # building it (one fused kernel, 10 us per edge) + the fused lookup is >10x faster than 49 x 128-channel dot
         # products per pixel and level; AltCorrBlock stays the path for grids the volume kernels do not cover.
-        use_volume = (eng.backend == "hip" and self.wd % 64 == 0 and self.ht % 8 == 0
-                      and os.environ.get("VIPE_AMD_BACKEND_ALTCORR") is None)
+        use_volume = self.wd % 64 == 0 and self.ht % 8 == 0 and os.environ.get("VIPE_AMD_BACKEND_ALTCORR") is None
         corr_op = None if use_volume else AltCorrBlock(buf.flattened_fmaps[None])
         P = self._edge_plan()
         V = buf.n_views
@@ -474,17 +472,9 @@ class FactorGraph:
                     corr_n[..., :196] = corr1[0].permute(0, 2, 3, 1)
                 xb = torch.empty((n, self.ht, self.wd, 320), dtype=torch.half, device=self.device)
                 xb[..., 0:128] = buf.inps[pis, qis].permute(0, 2, 3, 1)
-                if eng.backend == "hip":
-                    net, dw, eta, _ = eng.forward_nhwc(take(self.net_n).contiguous(), xb, corr_n, take(motn).contiguous(),
-                                                       ix=dixs, n_src=int(du_np.shape[0]))
-                    delta, weight = dw[..., 0:2], dw[..., 2:4].clone()
-                else:
-                    f_net, delta, weight, eta, _ = eng.forward(
-                        take(self.net_n).permute(0, 3, 1, 2)[None], xb[..., 0:128].permute(0, 3, 1, 2)[None],
-                        corr1.half(), take(motn).permute(0, 3, 1, 2)[None], ix=dixs, skip_upmask=True,
-                        n_src=int(du_np.shape[0]))
-                    net = f_net[0].permute(0, 2, 3, 1).contiguous()
-                    delta, weight, eta = delta[0].float(), weight[0].float(), eta[0]
+                net, dw, eta, _ = eng.forward_nhwc(take(self.net_n).contiguous(), xb, corr_n, take(motn).contiguous(),
+                                                   ix=dixs, n_src=int(du_np.shape[0]))
+                delta, weight = dw[..., 0:2], dw[..., 2:4].clone()
                 weight = weight.masked_fill(buf.masks[pis, qis].unsqueeze(-1), 0.0)
                 if whole:
                     self.net_n = net if net.data_ptr() != self.net_n.data_ptr() else net.clone()

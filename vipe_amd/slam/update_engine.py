@@ -16,15 +16,14 @@ epilogues:
     delta0|weight0|agg1 (3x3 128->384, relu) -> delta2|weight2 (3x3 256->4)       [HEADS epilogue]
     agg2 (3x3, relu) -> eta (3x3 128->1, 0.01 softplus)                           [ETA epilogue]
 
-Backends: "hip" (default, the kernels above) and "miopen" (torch conv2d, fp16 channels_last) kept as the A/B
-baseline for the hand-written kernels - selected only explicitly or through VIPE_AMD_CONV=miopen.
+There is no other backend: the torch / MIOpen formulation used as the A/B baseline of these kernels lives in
+scratch/miopen_ab.py (diagnostic, not importable from the package).
 """
 
 import ctypes
 import os
 
 import torch
-import torch.nn.functional as F
 
 from .._lib import check, lib, ptr, stream_ptr
 
@@ -59,13 +58,11 @@ def segment_csr(ix, n_src):
 
 
 class UpdateEngine:
-    def __init__(self, module, device, backend=None):
+    def __init__(self, module, device):
         self.device = device
-        self.backend = backend or os.environ.get("VIPE_AMD_CONV", "hip")
         self.m = module
         self._bufs = {}
-        if self.backend == "hip":
-            self._pack_all()
+        self._pack_all()
 
     # ------------------------------------------------------------------ weights
     def _pack_all(self):
@@ -158,7 +155,6 @@ class UpdateEngine:
         motn [E,h,w,4] f16;  ix [E] int64 -> source slot.  Returns (net' [E,h,w,128] f16, dw [E,h,w,4] f32 =
         (delta_x, delta_y, weight_x, weight_y), eta [n_src,h,w] f32 or None, upmask or None)."""
         E, H, W, _ = net.shape
-        assert self.backend == "hip"
         c1 = self._buf("c1", (E, H, W, 128))
         f1 = self._buf("f1", (E, H, W, 128))
         zb = self._buf("z", (E, H, W, 128))
@@ -221,8 +217,6 @@ class UpdateEngine:
     @torch.no_grad()
     def forward(self, net, inp, corr, flow=None, ix=None, skip_upmask=False, n_src=None):
         """Reference signature and return structure (droid_net.py:467-499): NCHW [1,E,C,h,w] in and out."""
-        if self.backend != "hip":
-            return self._forward_miopen(net, inp, corr, flow, ix, skip_upmask, n_src)
         batch, num, ch, ht, wd = net.shape
         E = batch * num
         dev = net.device
@@ -249,56 +243,3 @@ class UpdateEngine:
         if upmask is not None:
             upmask = upmask.permute(0, 3, 1, 2).reshape(batch, n_src, 576, ht, wd)
         return net_out, delta, weight, eta.view(batch, n_src, ht, wd), upmask
-
-    # ------------------------------------------------------------------ A/B baseline
-    def _forward_miopen(self, net, inp, corr, flow, ix, skip_upmask, n_src):
-        m = self.m
-        batch, num, ch, ht, wd = net.shape
-        E = batch * num
-        dev = net.device
-        f16 = torch.float16
-        if not hasattr(self, "_mio"):
-            self._mio = {k: (c.weight.detach().to(dev, f16).contiguous(memory_format=torch.channels_last),
-                             c.bias.detach().to(dev, f16))
-                         for k, c in dict(corr0=m.corr_encoder[0], corr2=m.corr_encoder[2], flow0=m.flow_encoder[0],
-                                          flow2=m.flow_encoder[2], w=m.gru.w, convz=m.gru.convz, convr=m.gru.convr,
-                                          convq=m.gru.convq, zg=m.gru.convz_glo, rg=m.gru.convr_glo, qg=m.gru.convq_glo,
-                                          d0=m.delta[0], d2=m.delta[2], w0=m.weight[0], w2=m.weight[2],
-                                          a1=m.agg.conv1, a2=m.agg.conv2, eta=m.agg.eta[0], up=m.agg.upmask[0]).items()}
-
-        def cv(x, k, pad):
-            w, b = self._mio[k]
-            return F.conv2d(x, w, b, padding=pad)
-
-        def cl(t, c):
-            return t.reshape(E, c, ht, wd).to(f16).contiguous(memory_format=torch.channels_last)
-
-        net_ = cl(net, 128)
-        inp_ = cl(inp, 128)
-        c = F.relu(cv(F.relu(cv(cl(corr, 196), "corr0", 0)), "corr2", 1))
-        fl = cl(flow, 4) if flow is not None else torch.zeros(E, 4, ht, wd, device=dev, dtype=f16)
-        f = F.relu(cv(F.relu(cv(fl, "flow0", 3)), "flow2", 1))
-        x = torch.cat([inp_, c, f], 1)
-        hx = torch.cat([net_, x], 1)
-        glo = (torch.sigmoid(cv(net_, "w", 0)) * net_).mean(dim=(2, 3), keepdim=True)
-        z = torch.sigmoid(cv(hx, "convz", 1) + cv(glo, "zg", 0))
-        r = torch.sigmoid(cv(hx, "convr", 1) + cv(glo, "rg", 0))
-        q = torch.tanh(cv(torch.cat([r * net_, x], 1), "convq", 1) + cv(glo, "qg", 0))
-        net_ = (1 - z) * net_ + z * q
-        delta = cv(F.relu(cv(net_, "d0", 1)), "d2", 1).view(batch, num, -1, ht, wd).permute(0, 1, 3, 4, 2)[..., :2].contiguous()
-        weight = torch.sigmoid(cv(F.relu(cv(net_, "w0", 1)), "w2", 1)).view(batch, num, -1, ht, wd) \
-            .permute(0, 1, 3, 4, 2)[..., :2].contiguous()
-        net_out = net_.view(batch, num, 128, ht, wd)
-        if ix is None:
-            return net_out, delta, weight
-        a = F.relu(cv(net_, "a1", 1))
-        if n_src is None:
-            n_src = int(ix.max().item()) + 1 if ix.numel() else 0
-        ixd = ix.to(dev)
-        acc = torch.zeros((n_src, 128, ht, wd), dtype=torch.float32, device=dev).index_add_(0, ixd, a.float())
-        cnt = torch.zeros(n_src, dtype=torch.float32, device=dev).index_add_(0, ixd, torch.ones(E, device=dev))
-        a = (acc / cnt.clamp(min=1).view(-1, 1, 1, 1)).to(f16).contiguous(memory_format=torch.channels_last)
-        a = F.relu(cv(a, "a2", 1))
-        eta = F.softplus(cv(a, "eta", 1).float()).view(batch, n_src, ht, wd)
-        upmask = None if skip_upmask else cv(a, "up", 0).view(batch, n_src, 576, ht, wd)
-        return net_out, delta, weight, 0.01 * eta, upmask
