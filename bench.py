@@ -32,6 +32,35 @@ PEAK_HBM_GBS = 8000.0
 DTYPE = "f16 (correlation, GRU; fp32 accumulate) + f32 geometry/BA (fp64 reduced system)"
 
 
+_T0 = time.perf_counter()
+
+
+def _log(msg):
+    """progress on stderr (stdout carries the one JSON line): a silent multi-minute run is indistinguishable from a hang"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        sys.stderr.write(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}\n")
+        sys.stderr.flush()
+
+
+def host_cores():
+    """CPU threads this process may actually use: the scheduler affinity mask, capped by the cgroup CPU quota (a GPU box
+    hands each job a share of a many-core host; os.cpu_count() reports the whole host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:  # noqa: BLE001 - cgroup v1 / not readable: the affinity mask stands
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:  # noqa: BLE001
+            pass
+    return n
+
+
 # ---------------------------------------------------------------------------------------------- launching N ranks
 def spawn_ranks(n):
     """`python bench.py --gpus N` without an external launcher: start N fresh rank processes (one per GPU) through
@@ -113,11 +142,13 @@ def cpu_baseline(n_sub=8):
         tc.bundle_adjustment(*ba_in)
         return t1 - t0, t2 - t1, time.perf_counter() - t2
 
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     keep = torch.get_num_threads()
+    _log(f"cpu_baseline: {cores} threads (os.cpu_count() = {os.cpu_count()})")
     torch.set_num_threads(cores)
-    one_pass()
-    runs = sorted((one_pass() for _ in range(5)), key=sum)
+    w = one_pass()
+    _log(f"cpu_baseline: warm-up pass {sum(w):.1f}s")
+    runs = sorted((one_pass() for _ in range(5 if sum(w) < 6 else 2)), key=sum)
     b, l, a = runs[len(runs) // 2]
     torch.set_num_threads(1)
     b1, l1, a1 = one_pass()
@@ -131,7 +162,7 @@ def cpu_baseline(n_sub=8):
         "sample": f"PyTorch-CPU (fp32) correlation volume + pyramid + 7x7x4 lookup + 3-iteration dense Schur BA, GRU "
                   f"excluded, on a {n_sub}-keyframe / {E}-edge 48x64 sub-graph of the bench clip (the full E=276 pass "
                   f"takes ~20 s per repetition on 8 cores), scaled per edge to E=276; {cores} threads: 1 warm-up + "
-                  f"median of 5; 1 thread: one pass",
+                  f"median of {len(runs)}; 1 thread: one pass",
     }
 
 
@@ -393,6 +424,7 @@ def secondary_figures(args, device, graph, step):
         keep, graph.pgate = graph.pgate, None
         out["value_all_gate_work_per_iteration"] = timed(step, 6)
         graph.pgate = keep
+    _log("secondary: all-gate-work done")
     # (2) E = 768 stress (backend cap 16 t): radius-3 graph + 492 seeded long-range edges
     try:
         _, _, g768 = build_problem(device, args.keyframes, 384, 512, 3, 492, seed=4321)
@@ -402,6 +434,7 @@ def secondary_figures(args, device, graph, step):
         torch.cuda.empty_cache()
     except Exception as e:  # noqa: BLE001 - a secondary figure must not take the headline down with it
         out["value_E768"] = f"failed: {type(e).__name__}: {e}"
+    _log("secondary: E768 done")
     # (3) synthetic video, 200 frames from RGB: keyframe frontend, then the two global-BA passes of SLAMSystem.run
     try:
         run_clip = make_clip_runner(device)
@@ -416,6 +449,7 @@ def secondary_figures(args, device, graph, step):
                     "initialisation); with_global_ba adds backend.run(7) + backend.run(24)"}
     except Exception as e:  # noqa: BLE001
         out["frames_per_s"] = f"failed: {type(e).__name__}: {e}"
+    _log("secondary: video done")
     return out
 
 
@@ -431,8 +465,11 @@ def update_mode(args, D):
     def step():
         graph.update(t0=1, t1=args.keyframes, itrs=3)
 
+    _log(f"problem built: E = {E}")
     for _ in range(args.warmup):
         step()
+    torch.cuda.synchronize()
+    _log("warm-up done")
 
     # The update iteration has no host read-back and no shape that changes from step to step, so TWO consecutive steps
     # (the hidden state ping-pongs between two buffers; targets / weights / poses / disparities are updated in place, so
@@ -463,6 +500,7 @@ def update_mode(args, D):
             launch = f"eager (graph capture failed: {type(e).__name__})"
     # RCCL comes up only now: problem set-up, warm-up and the graph capture above are rank-local (clip sharding has no
     # data-path collective), so no communicator thread is alive while a stream is being captured
+    _log(f"launch mode: {launch}")
     D.init()
     torch.cuda.synchronize()
     D.barrier()
@@ -487,6 +525,7 @@ def update_mode(args, D):
     finite = bool(torch.isfinite(buf.poses[:args.keyframes]).all() and torch.isfinite(buf.disps[:args.keyframes]).all()
                   and torch.isfinite(graph.target).all())
     n_seen = D.n_ranks_seen()
+    _log(f"timed region done: {world * args.steps / dt:.1f} it/s")
 
     # ---- roofline of the dominant kernel: conv_halo32_kernel<128, 3, true> (every 3x3 convolution of the
     # flow-update operator with >= 128 output channels: corr2, z|r, q, delta0|weight0|agg1, agg2 - 5 launches per

@@ -32,6 +32,17 @@ extern "C" {
 #define VIPE_ENOSPACE (-2) /* workspace too small */
 #define VIPE_EUNSUPPORTED (-3)
 
+/* storage layout of a correlation pyramid (level i of an edge b, source pixel p1 = y1 * w + x1, target (y, x)):
+ *   REFERENCE  level i = [B][h*w][h>>i][w>>i] for every level - CorrBlock.corr_pyramid, droid_net.py:56-69.
+ *   BLOCKED    levels 0 and 1 regrouped into 64-byte tiles of 4 rows x 8 columns and 16 KiB / 8 KiB runs per 64
+ *              source pixels (levels 2, 3 as REFERENCE); needs C == 128, w % 64 == 0, h % 8 == 0:
+ *                level0[b][p1/64][(x/32)*(h/4) + y/4][p1%64][(x%32)/8][y%4][x%8]
+ *                level1[b][p1/64][(x/16)*(h/8) + y/4][p1%64][(x%16)/8][y%4][x%8]     (x, y level-1 coordinates)
+ *              Same bytes per level as REFERENCE.  The internal layout of pooled pyramids: built by
+ *              vipe_corr_pyramid_build_indexed, read by vipe_corr_lookup_conv1x1. */
+#define VIPE_PYRAMID_REFERENCE 0
+#define VIPE_PYRAMID_BLOCKED 1
+
 #define VIPE_CAM_PINHOLE 0 /* vipe/utils/cameras.py:123 */
 #define VIPE_CAM_MEI 1     /* vipe/utils/cameras.py:220 */
 
@@ -70,16 +81,25 @@ int vipe_corr_pyramid_lookup_nhwc(const void* const* h_levels, const float* d_co
  * d_w_packed / d_bias as produced by vipe_conv_pack_weights for a [Cout, 200, 1, 1] weight (196 + 4 zero inputs).
  * fp16 volume levels, Cout == 128; other configurations return VIPE_EUNSUPPORTED (use lookup_nhwc + conv2d).
  * d_slots (optional, [B] int32): edge b reads slot d_slots[b] of the level buffers (a pool of pyramids with capacity
- * >= B whose edges come and go without compaction, factor_graph.py:147-152,194-196); null: slot b. */
+ * >= B whose edges come and go without compaction, factor_graph.py:147-152,194-196); null: slot b.
+ * layout: VIPE_PYRAMID_REFERENCE or VIPE_PYRAMID_BLOCKED (h1 == h2, w1 == w2 then). */
 int vipe_corr_lookup_conv1x1(const void* const* h_levels, const float* d_coords, const void* d_w_packed,
                              const float* d_bias, void* d_out, int out_ctot, int out_coff, int B, int h1, int w1,
-                             int h2, int w2, int Cout, int act, const int* d_slots, void* stream);
+                             int h2, int w2, int Cout, int act, const int* d_slots, int layout, void* stream);
 
 /* [fused] CorrBlock.corr + pyramid (droid_net.py:56-69,94-102): volume = (f1/4)^T (f2/4) on MFMA (fp16 in,
  * fp32 accumulate, stored as dtype), then 2x2 average pooling of the target dims for levels 1..num_levels-1.
  * fmap1, fmap2 [B,C,h,w] f16; h_levels: host array of num_levels device pointers (outputs). C % 32 == 0. */
 int vipe_corr_pyramid_build(const void* d_fmap1, const void* d_fmap2, void* const* h_levels, int B, int C, int h,
                             int w, int num_levels, void* stream);
+
+/* [fused] the same for the edges of a factor graph, straight from the keyframe buffer into a pooled store
+ * (factor_graph.py:147-152: `CorrBlock(fmaps[ii], fmaps[jj])` then `corr.cat`): edge b correlates frame d_idx1[b]
+ * with frame d_idx2[b] of d_fmaps [n_frames,C,h,w] f16 - the gathered [B,C,h,w] copies never exist - and is written
+ * to slot d_slots[b] of the level buffers (null: slot b) in `layout` (VIPE_PYRAMID_*). */
+int vipe_corr_pyramid_build_indexed(const void* d_fmaps, const int64_t* d_idx1, const int64_t* d_idx2,
+                                    const int* d_slots, void* const* h_levels, int B, int C, int h, int w,
+                                    int num_levels, int layout, void* stream);
 
 /* altcorr_forward: replaces altcorr_cuda_forward, altcorr_kernel.cu:266-290.
  * fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C] dtype (f16/f32); coords [B,N,H1,W1,2] f32; corr [B,N,(2r+1)^2,H1,W1]. */

@@ -183,8 +183,9 @@ def test_corr_pool_slot_bookkeeping_on_host():
     assert len(pool._free) == 4 and set(pool._free).isdisjoint(pool._slots_host) and len(set(pool._slots_host)) == 4
 
 
-def test_corr_pool_adopts_a_large_first_block():
-    """A first block at least as large as the pool's default capacity becomes the pool (no copy); later blocks grow it."""
+def test_corr_pool_first_block_larger_than_default_capacity():
+    """A first block larger than the pool's default capacity sizes the pool to fit; later blocks grow it.  (The
+    product path, `add_edges`, has the build kernel write into the pool's slots directly - no copy to avoid.)"""
     import types
     import numpy as np
     from vipe_amd.slam.networks import CorrPool
@@ -194,15 +195,32 @@ def test_corr_pool_adopts_a_large_first_block():
               for i in range(2)]
         return types.SimpleNamespace(corr_pyramid=lv)
 
-    b = block(5, 10)
-    pool = CorrPool(num_levels=2, capacity=4).cat(b)
-    assert pool.pool[0].data_ptr() == b.corr_pyramid[0].data_ptr() and pool._free == [] and pool._slots_host == [0, 1, 2, 3, 4]
-    pool.cat(block(2, 20))  # no free slot: the pool grows
-    assert pool.pool[0].shape[0] >= 7 and len(pool) == 7
-    assert [float(x) for x in pool.corr_pyramid[0][:, 0, 0, 0, 0]] == [10, 11, 12, 13, 14, 20, 21]
+    pool = CorrPool(num_levels=2, capacity=4).cat(block(5, 10))
+    assert pool.pool[0].shape[0] == 8 and pool._slots_host == [0, 1, 2, 3, 4] and pool._free == [5, 6, 7]
+    pool.cat(block(4, 20))  # one slot short: the pool grows
+    assert pool.pool[0].shape[0] == 16 and len(pool) == 9
+    assert [float(x) for x in pool.corr_pyramid[0][:, 0, 0, 0, 0]] == [10, 11, 12, 13, 14, 20, 21, 22, 23]
     pool = pool[np.array([1, 5])]
     assert [float(x) for x in pool.corr_pyramid[1][:, 0, 0, 0, 0]] == [11, 20] and len(pool._free) == pool.pool[0].shape[0] - 2
 
+
+def test_blocked_pyramid_layout_round_trip():
+    """VIPE_PYRAMID_BLOCKED <-> reference layout converters are inverse permutations, and element (p1, y, x) of the
+    reference tensor sits where include/vipe_amd.h says it does in the blocked one."""
+    from vipe_amd.ext import droid_net_ext as dn
+    from vipe_amd.slam.networks import _to_blocked
+    h, w, n = 8, 64, 2
+    ref = [torch.arange(n * h * w * (h >> i) * (w >> i), dtype=torch.float32).reshape(n, h, w, h >> i, w >> i) for i in range(4)]
+    blk = _to_blocked(ref, h, w)
+    assert [tuple(b.shape) for b in blk] == dn.pyramid_level_shapes(n, h, w, 4, dn.BLOCKED)
+    back = dn.pyramid_to_reference(blk, h, w)
+    assert all(torch.equal(a, b) for a, b in zip(ref, back))
+    for (e, p1, y, x) in [(0, 0, 0, 0), (1, 77, 5, 43), (1, 511, 7, 63), (0, 130, 3, 8)]:
+        assert blk[0][e, p1 // 64, (x // 32) * (h // 4) + y // 4, p1 % 64, (x % 32) // 8, y % 4, x % 8] == \
+            ref[0][e, p1 // w, p1 % w, y, x]
+        y1, x1 = y // 2, x // 2
+        assert blk[1][e, p1 // 64, (x1 // 16) * (h // 8) + y1 // 4, p1 % 64, (x1 % 16) // 8, y1 % 4, x1 % 8] == \
+            ref[1][e, p1 // w, p1 % w, y1, x1]
 
 def test_bench_gpus_flag_spawns_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` (no external launcher) must start two rank processes, run the

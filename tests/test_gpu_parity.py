@@ -618,6 +618,57 @@ def test_factor_graph_update_matches_oracle_composition():
     assert int(graph.age.min()) == 1
 
 
+def test_factor_graph_update_full_size_with_sensor_depth():
+    """BASELINE configs[2] as bench.py runs it: ONE FactorGraph.update at N = 48, E = 276, 48x64, sensor-depth prior on
+    every keyframe ("depth_align on").  (i) the lookup on the DEVICE-built pyramid (through the CorrPool slot
+    indirection) is bit-exact vs the oracle for a sample of edges; (ii) the BA step equals the fp64 oracle BA fed the
+    device's own targets / weights / damping at 1e-4 relative (north_star tolerance); (iii) the energy of those factors
+    decreases; (iv) the sensor prior is live (the result differs from a run without it)."""
+    import bench
+    from vipe_amd.ext import slam_ext
+    n = 48
+    g, buf, graph = bench.build_problem(dev(), n, 384, 512, 3, 0, seed=1234, depth_prior=True)
+    E = len(g.ii)
+    assert E == 276 and float(buf.disps_sens[:n].sum()) > 0
+    poses0, disps0 = buf.poses[:n].cpu().numpy().copy(), buf.disps[:n, 0].cpu().numpy().copy()
+    # (i) lookup, sample of 12 edges spread over the graph
+    z = torch.zeros(E, dtype=torch.long, device=dev())
+    coords1, _ = slam_ext.reproject(buf.poses, buf.flattened_disps, buf.intrinsics, buf.rig, graph.ii, z, graph.jj, z,
+                                    graph.ii)
+    sel = list(range(0, E, 23))
+    out = graph.corr.lookup_nhwc(coords1)  # [E,h,w,200] through the pool's slot vector
+    lv_all = graph.corr.corr_pyramid
+    levels = [lv[sel].cpu().numpy() for lv in lv_all]
+    ref = ocorr.corr_lookup(levels, coords1[sel].cpu().numpy()[None], 3)[0]  # [12,196,h,w]
+    got = out[sel][..., :196].permute(0, 3, 1, 2).cpu().numpy()
+    assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)), "full-size lookup on the device pyramid not bit-exact"
+    del out, lv_all
+    # the update itself
+    graph.update(t0=1, t1=n, itrs=3)
+    torch.cuda.synchronize()
+    tg, wg = graph.target[0].cpu().numpy(), graph.weight[0].cpu().numpy()
+    damping = graph.damping[:n].cpu().numpy()
+    p1, d1 = buf.poses[:n].cpu().numpy(), buf.disps[:n, 0].cpu().numpy()
+    assert np.isfinite(p1).all() and np.isfinite(d1).all() and np.isfinite(tg).all()
+    # (ii) fp64 oracle BA on the device's targets / weights / eta, from the pre-update state
+    rig = ose3.se3_identity(1)
+    kw = dict(t0=1, t1=n, n_iters=3, pose_damping=1e-3, pose_ep=0.1)
+    op, od, _, _ = oba.bundle_adjustment(poses0, disps0[:, None], g.disps_sens[:, None], g.intrinsics, rig,
+                                         tg.reshape(E, -1, 2), wg.reshape(E, -1, 2), damping[:, None], g.ii, g.jj, **kw)
+    assert np.abs(p1 - op).max() <= 1e-4 * max(1.0, np.abs(op).max()), np.abs(p1 - op).max()
+    assert np.abs(d1 - od[:, 0]).max() <= 1e-4 * np.abs(od).max(), np.abs(d1 - od[:, 0]).max()
+    # (iii) energy of the factors the BA was given
+    e0 = oba.energy(poses0, disps0[:, None], g.intrinsics, rig, tg, wg, g.ii, g.jj)
+    e1 = oba.energy(p1, d1[:, None], g.intrinsics, rig, tg, wg, g.ii, g.jj)
+    assert e1 < e0
+    # (iv) same BA without the prior moves the disparities elsewhere
+    pz, dz = T(poses0).clone(), T(disps0).clone()
+    zz = np.zeros_like(g.ii)
+    slam_ext.dense_ba(pz, dz, torch.zeros_like(dz), T(g.intrinsics), T(rig), T(tg.reshape(E, -1, 2)),
+                      T(wg.reshape(E, -1, 2)), T(damping), T(g.ii), T(zz), T(g.jj), T(zz), T(g.ii), 1, n, 3, 1e-3, 0.1)
+    assert np.abs(dz.cpu().numpy() - d1).max() > 10 * 1e-4 * np.abs(od).max()
+
+
 def test_factor_graph_update_batch_runs_and_reduces_energy():
     g, buf, graph, um = _tiny_graph(seed=43)
     n = 5
@@ -1093,6 +1144,59 @@ def test_corr_pool_matches_corr_block_through_add_and_remove():
         assert torch.equal(pool.lookup_nhwc(coords), droid_net_ext.corr_pyramid_lookup_nhwc(ref, coords, 3, 200))
 
 
+def test_blocked_pool_built_from_frame_indices_matches_reference_layout():
+    """The pooled store the update iteration reads: `CorrPool.add_edges` = `vipe_corr_pyramid_build_indexed` writing the
+    BLOCKED layout straight into free slots from (frame i, frame j) index vectors.  Against `CorrBlock(fmaps[i], fmaps[j])`
+    (gathered maps, reference layout): every level BIT-IDENTICAL after conversion (same MFMA accumulation and pooling
+    arithmetic, only the addresses differ), the fused lookup + 1x1 conv kernel BIT-IDENTICAL on both layouts, through
+    additions, removals with slot reuse, pool growth, and a reference-layout block appended with `cat`."""
+    from vipe_amd.ext import droid_net_ext
+    from vipe_amd.slam.networks import CorrBlock, CorrPool
+    from vipe_amd.slam.networks import UpdateModule
+    torch.manual_seed(0)
+    eng = UpdateModule().eval().engine(dev())
+    g = torch.Generator().manual_seed(21)
+    for (h, w, nf) in ((8, 64, 7), (48, 64, 5), (16, 128, 4)):
+        fmaps = torch.randn(nf, 128, h, w, generator=g).half().to(dev())
+        pool = CorrPool(capacity=4)
+        ii = torch.zeros(0, dtype=torch.long)
+        jj = torch.zeros(0, dtype=torch.long)
+        steps = [("add", 3), ("rm", [0, 2]), ("add", 4), ("cat", 2), ("rm", [1, 2, 4, 5, 6]), ("add", 3)]
+        for op, arg in steps:
+            if op in ("add", "cat"):
+                i_new = torch.randint(0, nf, (arg,), generator=g)
+                j_new = torch.randint(0, nf, (arg,), generator=g)
+                if op == "add":
+                    pool.add_edges(fmaps, i_new.to(dev()), j_new.to(dev()))
+                else:
+                    pool.cat(CorrBlock(fmaps[i_new.to(dev())][None], fmaps[j_new.to(dev())][None]))
+                ii, jj = torch.cat([ii, i_new]), torch.cat([jj, j_new])
+            else:
+                keep = np.array(arg)
+                pool = pool[keep]
+                ii, jj = ii[keep], jj[keep]
+            E = ii.shape[0]
+            assert pool.blocked and len(pool) == E and pool.pool[0].dim() == 7
+            ref = CorrBlock(fmaps[ii.to(dev())][None], fmaps[jj.to(dev())][None])
+            for a, b_ in zip(pool.corr_pyramid, ref.corr_pyramid):
+                assert a.shape == b_.shape and torch.equal(a, b_)
+            coords = (torch.rand(E, h, w, 2, generator=g) * torch.tensor([w + 6.0, h + 6.0]) - 3.0).to(dev())
+            hd = pool.lookup_deferred(coords)
+            out_p = torch.zeros(E, h, w, 128, dtype=torch.float16, device=dev())
+            out_r = torch.zeros_like(out_p)
+            droid_net_ext.corr_lookup_conv1x1(hd[1], hd[2], eng.corr0.packed, eng.corr0.bias, out_p, act="relu", slots=hd[3])
+            droid_net_ext.corr_lookup_conv1x1(ref.levels, coords, eng.corr0.packed, eng.corr0.bias, out_r, act="relu")
+            assert torch.equal(out_p, out_r)
+        # CorrBlock.from_buffer (the backend's per-chunk volume): blocked, no slots
+        blk = CorrBlock.from_buffer(fmaps, ii.to(dev()), jj.to(dev()))
+        assert blk.levels[0].dim() == 7
+        hd = blk.lookup_deferred(coords)
+        out_b = torch.zeros_like(out_p)
+        droid_net_ext.corr_lookup_conv1x1(hd[1], hd[2], eng.corr0.packed, eng.corr0.bias, out_b, act="relu")
+        assert torch.equal(out_b, out_r)
+        assert torch.equal(blk(coords[None]), ref(coords[None]))  # reference-API lookup through the converter
+
+
 def test_update_batch_merged_chunks_equal_reference_groups_of_eight(monkeypatch):
     """The reference applies the operator per group of 8 source keyframes (factor_graph.py:337-343); merging the groups
     into one chunk (the default here) must not change anything: GraphAgg only couples edges of the same source frame.
@@ -1202,7 +1306,7 @@ def test_ba_plan_reuse_equals_rebuilding_the_plan(monkeypatch):
             monkeypatch.setenv("VIPE_AMD_BA_NO_PLAN_REUSE", "1")
         else:
             monkeypatch.delenv("VIPE_AMD_BA_NO_PLAN_REUSE", raising=False)
-        g, buf, graph = bench.build_problem(dev(), 12, 384, 512, 3, 0, "hip", seed=7)
+        g, buf, graph = bench.build_problem(dev(), 12, 384, 512, 3, 0, seed=7, depth_prior=False)
         out = []
         for it in range(3):
             if it == 2:

@@ -18,6 +18,17 @@
 // Pooling: the thread that stores columns 8s..8s+7 of both chunk rows of source pixel p1 also produces level-1
 // columns 4s..4s+3, keeps them to form level-2 columns 2s, 2s+1 two chunks later and level-3 column s after eight
 // target rows - no cross-thread traffic after the level-0 tile.
+//
+// Two output layouts (template parameter BLK).  Reference layout: level i = [e][p1][h>>i][w>>i], what CorrBlock exposes;
+// the chunk is 2 target rows x 64 columns and a source pixel's piece of it is 256 contiguous bytes.  BLOCKED layout
+// (the internal layout of the pooled store the update iteration reads, VIPE_PYRAMID_BLOCKED in the header): the chunk
+// is 4 target rows x 32 columns and levels 0 / 1 are stored as
+//     level0[e][p1 / 64][chunk][p1 % 64][tile 0..3][row 0..3][col 0..7]      chunk = (x / 32) * (h / 4) + y / 4
+//     level1[e][p1 / 64][chunk / 2][p1 % 64][tile 0..1][row 0..3][col 0..7]  (level-1 rows 4 (y / 8) .., cols 16 (x / 32) ..)
+// i.e. (a) the 64 x 128 tile a workgroup produces per chunk is ONE contiguous 16 KiB run (8 KiB per two chunks at
+// level 1) instead of 64 pieces 6 KiB apart - DRAM pages are written whole - and (b) a 64-byte sector holds a
+// 4 x 8 patch of a source pixel's slab, so the 8 x 8 lookup window touches 5.2 sectors on average instead of 10
+// (8 rows x 1.25).  Levels 2 / 3 (384 / 96 bytes per source pixel) keep the reference layout.
 #include "common.cuh"
 
 namespace {
@@ -38,8 +49,11 @@ constexpr int PB_STAGE = PB_M * PB_PS * 2;  // 17408: one staged level-0 tile [6
 constexpr int PB_LDS = PB_IMGA + 2 * PB_STAGE;  // f2 chunk image + two stage buffers (the f1 image borrows imgA first)
 
 struct BuildArgs {
-  const half_t* f1;
+  const half_t* f1;      // [*, C, h*w] feature maps: edge e reads map idx1[e] (e itself when idx1 == nullptr)
   const half_t* f2;
+  const int64_t* idx1;
+  const int64_t* idx2;
+  const int* slots;      // edge e is written to slot slots[e] of the level buffers (e itself when nullptr)
   half_t* lv[4];
   int B, h, w, nlev;
 };
@@ -61,6 +75,7 @@ __device__ __forceinline__ half_t pool4(half_t a, half_t b, half_t c, half_t d) 
   return (half_t)((((float)a + (float)b) + (float)c + (float)d) / 4.0f);
 }
 
+template <bool BLK>
 __global__ __launch_bounds__(512) void corr_pyramid_build_kernel(BuildArgs a) {
   extern __shared__ __align__(16) unsigned char lds[];
   unsigned char* imgA = lds;             // f2 chunk  [128 c][128 p2]; before the first chunk: the f1 tile [128 c][64 p1]
@@ -70,8 +85,9 @@ __global__ __launch_bounds__(512) void corr_pyramid_build_kernel(BuildArgs a) {
   const int tiles = P / PB_M;
   const int L = xcd_remap(blockIdx.x, gridDim.x);
   const int e = L / tiles, p1_0 = (L % tiles) * PB_M;
-  const half_t* f1 = a.f1 + (int64_t)e * PB_C * P;
-  const half_t* f2 = a.f2 + (int64_t)e * PB_C * P;
+  const half_t* f1 = a.f1 + (a.idx1 ? a.idx1[e] : (int64_t)e) * PB_C * P;
+  const half_t* f2 = a.f2 + (a.idx2 ? a.idx2[e] : (int64_t)e) * PB_C * P;
+  const int64_t es = a.slots ? a.slots[e] : e;
 
   // ---- f1 tile -> LDS -> registers (B operand: columns = source pixels)
   for (int i = tid; i < PB_C * 8; i += 512) {
@@ -89,24 +105,34 @@ __global__ __launch_bounds__(512) void corr_pyramid_build_kernel(BuildArgs a) {
       bf[j][kk] = tr_frag(imgB, (kk * 32 + g * 4 + q) * PB_PB + (wp * 32 + j * 16 + 4 * pp) * 2, 16 * PB_PB);
   const int a_off = (g * 4 + q) * PB_PA + (wn * 32 + 4 * pp) * 2;
 
-  // ---- chunk walk: (8-row group, 64-column segment, row pair)
+  // ---- chunk walk.  Reference layout: (8-row group, 64-column segment, row pair) of 2 x 64 chunks.  Blocked layout:
+  // 4 x 32 chunks, down the rows of one 32-column strip, then the next strip (vertically adjacent chunks are
+  // consecutive: pairs of them complete the level-1 tiles and the level-3 entries)
   const int csegs = a.w / 64;
-  const int nchunks = (a.h / 2) * csegs;
+  const int nchunks = (a.h / 2) * csegs;  // = (h / 4) * (w / 32)
+  const int rgs = a.h / 4;
   auto chunk_origin = [&](int ch, int& y, int& x0) {
-    const int rp = ch & 3, t = ch >> 2;
-    y = (t / csegs) * 8 + rp * 2;
-    x0 = (t % csegs) * 64;
+    if (BLK) {
+      y = (ch % rgs) * 4;
+      x0 = (ch / rgs) * 32;
+    } else {
+      const int rp = ch & 3, t = ch >> 2;
+      y = (t / csegs) * 8 + rp * 2;
+      x0 = (t % csegs) * 64;
+    }
   };
-  // this thread's 4 sixteen-byte pieces of a chunk: channel rows tid/16 + 32 k, piece tid % 16 (row rr = piece / 8)
+  // this thread's 4 sixteen-byte pieces of a chunk: channel rows tid/16 + 32 k, piece tid % 16 (chunk-local pixels
+  // 8 piece ..: row piece / 8 of a 2 x 64 chunk, row piece / 4 of a 4 x 32 chunk)
   half8 pre[4];
   auto fetch = [&](int ch) {
     int y, x0;
     chunk_origin(ch, y, x0);
     const int pc = tid & 15;
+    const int off = BLK ? (y + (pc >> 2)) * a.w + x0 + (pc & 3) * 8 : (y + (pc >> 3)) * a.w + x0 + (pc & 7) * 8;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int c = (tid >> 4) + 32 * k;
-      pre[k] = *reinterpret_cast<const half8*>(f2 + (int64_t)c * P + (y + (pc >> 3)) * a.w + x0 + (pc & 7) * 8);
+      pre[k] = *reinterpret_cast<const half8*>(f2 + (int64_t)c * P + off);
     }
   };
   auto commit = [&]() {
@@ -116,7 +142,8 @@ __global__ __launch_bounds__(512) void corr_pyramid_build_kernel(BuildArgs a) {
   };
   fetch(0);
   const int sp1 = tid >> 3, sseg = tid & 7;  // output role: source pixel of the tile, 8-column segment
-  const int64_t p1g = (int64_t)e * P + p1_0 + sp1;
+  const int64_t p1g = es * P + p1_0 + sp1;
+  const int64_t eg = es * tiles + (p1_0 / PB_M);  // blocked layout: (slot, group of 64 source pixels)
   half4 l1prev = {0, 0, 0, 0};
   half_t l2prev[2] = {0, 0};
   half_t* stage0 = reinterpret_cast<half_t*>(lds + PB_IMGA);
@@ -127,6 +154,46 @@ __global__ __launch_bounds__(512) void corr_pyramid_build_kernel(BuildArgs a) {
   auto output = [&](int ch, const half_t* stage) {
     int y, x0;
     chunk_origin(ch, y, x0);
+    if (BLK) {
+      // thread = (source pixel, tile 0..3 of the chunk, row pair 0..1 of the tile): 32 contiguous bytes of level 0; the
+      // workgroup's 512 x 32 B are one 16 KiB run
+      const int tile = sseg >> 1, hf = sseg & 1, rg = y >> 2;
+      const half8 r0 = *reinterpret_cast<const half8*>(stage + sp1 * PB_PS + (2 * hf) * 32 + tile * 8);
+      const half8 r1 = *reinterpret_cast<const half8*>(stage + sp1 * PB_PS + (2 * hf + 1) * 32 + tile * 8);
+      half_t* dst = a.lv[0] + ((eg * nchunks + ch) * PB_M + sp1) * 128 + tile * 32 + hf * 16;
+      *reinterpret_cast<half8*>(dst) = r0;
+      *reinterpret_cast<half8*>(dst + 8) = r1;
+      if (a.nlev <= 1) return;
+      half4 l1;  // level-1 row hf of the chunk (rows 2 (rg & 1) + hf of the level-1 tile), columns 4 tile .. + 3
+#pragma unroll
+      for (int k = 0; k < 4; ++k) l1[k] = pool4(r0[2 * k], r0[2 * k + 1], r1[2 * k], r1[2 * k + 1]);
+      if (rg & 1) {  // second chunk of the pair: both level-1 rows of this thread leave together (8 KiB run per workgroup)
+        half_t* d1 = a.lv[1] + ((eg * (nchunks >> 1) + (ch >> 1)) * PB_M + sp1) * 64 + (tile >> 1) * 32 + (tile & 1) * 4;
+        *reinterpret_cast<half4*>(d1 + hf * 8) = l1prev;
+        *reinterpret_cast<half4*>(d1 + (2 + hf) * 8) = l1;
+      }
+      if (a.nlev > 2) {
+        // level 2 pools the two level-1 rows of the chunk: the other row lives in the neighbour lane (sseg ^ 1)
+        uint2 mine = __builtin_bit_cast(uint2, l1), oth;
+        oth.x = __shfl_xor(mine.x, 1, WAVE);
+        oth.y = __shfl_xor(mine.y, 1, WAVE);
+        const half4 lo = hf ? __builtin_bit_cast(half4, oth) : l1, hi = hf ? l1 : __builtin_bit_cast(half4, oth);
+        half_t l2[2];
+        l2[0] = pool4(lo[0], lo[1], hi[0], hi[1]);
+        l2[1] = pool4(lo[2], lo[3], hi[2], hi[3]);
+        if (hf == 0) {
+          half_t* d2 = a.lv[2] + (p1g * (a.h >> 2) + rg) * (a.w >> 2) + (x0 >> 2) + tile * 2;
+          d2[0] = l2[0];
+          d2[1] = l2[1];
+          if (a.nlev > 3 && (rg & 1))
+            a.lv[3][(p1g * (a.h >> 3) + (rg >> 1)) * (a.w >> 3) + (x0 >> 3) + tile] = pool4(l2prev[0], l2prev[1], l2[0], l2[1]);
+        }
+        l2prev[0] = l2[0];
+        l2prev[1] = l2[1];
+      }
+      l1prev = l1;
+      return;
+    }
     // level 0 + level 1: the thread reads columns 8s..8s+7 of both chunk rows once; its two 16-byte stores are parts
     // of two fully covered 128-byte row segments (8 lanes per source pixel and row)
     const half8 r0 = *reinterpret_cast<const half8*>(stage + sp1 * PB_PS + sseg * 8);
@@ -193,29 +260,47 @@ __global__ __launch_bounds__(512) void corr_pyramid_build_kernel(BuildArgs a) {
 
 }  // namespace
 
-extern "C" {
-
-VIPE_EXPORT int vipe_corr_pyramid_build(const void* d_fmap1, const void* d_fmap2, void* const* h_levels, int B, int C,
-                                        int h, int w, int num_levels, void* stream) {
+static int build_impl(const void* d_f1, const void* d_f2, const int64_t* d_idx1, const int64_t* d_idx2, const int* d_slots,
+                      void* const* h_levels, int B, int C, int h, int w, int num_levels, int layout, void* stream) {
   VIPE_CHECK_ARG(h_levels && num_levels >= 1 && num_levels <= 4 && B >= 0 && C > 0 && h > 0 && w > 0);
+  VIPE_CHECK_ARG(layout == VIPE_PYRAMID_REFERENCE || layout == VIPE_PYRAMID_BLOCKED);
   if (B == 0) return VIPE_OK;
-  VIPE_CHECK_ARG(d_fmap1 && d_fmap2);
+  VIPE_CHECK_ARG(d_f1 && d_f2);
   for (int i = 0; i < num_levels; ++i) VIPE_CHECK_ARG(h_levels[i]);
   // tiling of this kernel: 128 channels, 64-column segments, 8-row groups (the DROID feature map at 1/8 of
   // 512 x 384 and multiples); other shapes take the library GEMM + pooling path on the Python side
   if (C != PB_C || w % 64 != 0 || h % 8 != 0) return VIPE_EUNSUPPORTED;
   if ((int64_t)B * h * w / PB_M > 0x7fffffff) return VIPE_EINVAL;
   BuildArgs a;
-  a.f1 = (const half_t*)d_fmap1;
-  a.f2 = (const half_t*)d_fmap2;
+  a.f1 = (const half_t*)d_f1;
+  a.f2 = (const half_t*)d_f2;
+  a.idx1 = d_idx1; a.idx2 = d_idx2; a.slots = d_slots;
   for (int i = 0; i < 4; ++i) a.lv[i] = i < num_levels ? (half_t*)h_levels[i] : nullptr;
   a.B = B; a.h = h; a.w = w; a.nlev = num_levels;
   static std::atomic<uint64_t> attr{0};  // bit d: set on device d
   if (vipe_first_on_device(attr)) {
-    (void)hipFuncSetAttribute((const void*)corr_pyramid_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS);
+    (void)hipFuncSetAttribute((const void*)corr_pyramid_build_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS);
+    (void)hipFuncSetAttribute((const void*)corr_pyramid_build_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS);
   }
-  corr_pyramid_build_kernel<<<dim3((unsigned)((int64_t)B * h * w / PB_M)), 512, PB_LDS, as_stream(stream)>>>(a);
+  const dim3 grid((unsigned)((int64_t)B * h * w / PB_M));
+  if (layout == VIPE_PYRAMID_BLOCKED) corr_pyramid_build_kernel<true><<<grid, 512, PB_LDS, as_stream(stream)>>>(a);
+  else corr_pyramid_build_kernel<false><<<grid, 512, PB_LDS, as_stream(stream)>>>(a);
   return vipe_launch_status();
+}
+
+extern "C" {
+
+VIPE_EXPORT int vipe_corr_pyramid_build(const void* d_fmap1, const void* d_fmap2, void* const* h_levels, int B, int C,
+                                        int h, int w, int num_levels, void* stream) {
+  return build_impl(d_fmap1, d_fmap2, nullptr, nullptr, nullptr, h_levels, B, C, h, w, num_levels, VIPE_PYRAMID_REFERENCE,
+                    stream);
+}
+
+VIPE_EXPORT int vipe_corr_pyramid_build_indexed(const void* d_fmaps, const int64_t* d_idx1, const int64_t* d_idx2,
+                                                const int* d_slots, void* const* h_levels, int B, int C, int h, int w,
+                                                int num_levels, int layout, void* stream) {
+  VIPE_CHECK_ARG(B == 0 || (d_idx1 && d_idx2));
+  return build_impl(d_fmaps, d_fmaps, d_idx1, d_idx2, d_slots, h_levels, B, C, h, w, num_levels, layout, stream);
 }
 
 }  // extern "C"

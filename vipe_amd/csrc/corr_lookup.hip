@@ -343,7 +343,7 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void corr_lookup_conv_kernel(
     LevelPtrs lv, const float* __restrict__ coords, const half_t* __restrict__ wpk, const float* __restrict__ bias,
     half_t* __restrict__ out, int out_ctot, int out_coff, int h1, int w1, int h2, int w2, int B, int cout_pad, int act,
-    const int* __restrict__ slots) {
+    const int* __restrict__ slots, int blocked) {
   constexpr int R = 3, RD = 7, L = 4;
   using A = Acc<half_t>;
   __shared__ __align__(16) half_t stage[32 * LKC_PITCH];
@@ -384,12 +384,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const int bx = (int)floorf(c.x * sc) - R, by = (int)floorf(c.y * sc) - R;
       const int y1 = by + j, c0 = bx >> 3, nchunks = w2l >> 3;
       const bool rowok = (y1 >= 0) & (y1 < h2l);
-      const half_t* slab = reinterpret_cast<const half_t*>(lv.p[l]) + ((int64_t)ns * P + pc) * ((int64_t)h2l * w2l);
-      const uint4v* rowp = reinterpret_cast<const uint4v*>(slab + (int64_t)(rowok ? y1 : 0) * w2l);
       lo[l] = uint4v{0, 0, 0, 0};
       hi[l] = uint4v{0, 0, 0, 0};
-      if (rowok & (c0 >= 0) & (c0 < nchunks)) lo[l] = rowp[c0];
-      if (rowok & (c0 + 1 >= 0) & (c0 + 1 < nchunks)) hi[l] = rowp[c0 + 1];
+      if (blocked && l < 2) {
+        // VIPE_PYRAMID_BLOCKED (include/vipe_amd.h): 16-byte piece (row y1, columns 8 c ..) of source pixel pc lives in
+        // run ((x-strip) * (h2l / 4) + y1 / 4) of the pixel's group of 64, tile c % T, tile row y1 % 4
+        const int T = 4 >> l, rgs = h2l >> 2;
+        const int64_t eg = (int64_t)ns * (P >> 6) + (pc >> 6);
+        const half_t* base = reinterpret_cast<const half_t*>(lv.p[l]);
+        const int yr = rowok ? y1 : 0;
+        auto piece = [&](int cc) {
+          const int64_t run = eg * ((int64_t)rgs * (w2 >> 5)) + (cc / T) * rgs + (yr >> 2);
+          return *reinterpret_cast<const uint4v*>(base + (run * 64 + (pc & 63)) * (T * 32) + (cc % T) * 32 + (yr & 3) * 8);
+        };
+        if (rowok & (c0 >= 0) & (c0 < nchunks)) lo[l] = piece(c0);
+        if (rowok & (c0 + 1 >= 0) & (c0 + 1 < nchunks)) hi[l] = piece(c0 + 1);
+      } else {
+        const half_t* slab = reinterpret_cast<const half_t*>(lv.p[l]) + ((int64_t)ns * P + pc) * ((int64_t)h2l * w2l);
+        const uint4v* rowp = reinterpret_cast<const uint4v*>(slab + (int64_t)(rowok ? y1 : 0) * w2l);
+        if (rowok & (c0 >= 0) & (c0 < nchunks)) lo[l] = rowp[c0];
+        if (rowok & (c0 + 1 >= 0) & (c0 + 1 < nchunks)) hi[l] = rowp[c0 + 1];
+      }
     }
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -645,7 +660,8 @@ VIPE_EXPORT int vipe_corr_pyramid_lookup_nhwc(const void* const* h_levels, const
 
 VIPE_EXPORT int vipe_corr_lookup_conv1x1(const void* const* h_levels, const float* d_coords, const void* d_w_packed,
                                          const float* d_bias, void* d_out, int out_ctot, int out_coff, int B, int h1,
-                                         int w1, int h2, int w2, int Cout, int act, const int* d_slots, void* stream) {
+                                         int w1, int h2, int w2, int Cout, int act, const int* d_slots, int layout,
+                                         void* stream) {
   VIPE_CHECK_ARG(B >= 0 && h1 > 0 && w1 > 0 && h2 > 0 && w2 > 0);
   if (B == 0) return VIPE_OK;
   VIPE_CHECK_ARG(h_levels && d_coords && d_w_packed && d_bias && d_out);
@@ -653,6 +669,8 @@ VIPE_EXPORT int vipe_corr_lookup_conv1x1(const void* const* h_levels, const floa
   VIPE_CHECK_ARG(out_ctot % 8 == 0 && out_coff % 8 == 0 && out_coff + Cout <= out_ctot);
   // 4 levels, radius 3, fp16 volume whose coarsest level still has 8-element row chunks; 128 output channels
   if (Cout != 128 || ((w2 >> 3) & 7) != 0 || (h2 >> 3) < 1) return VIPE_EUNSUPPORTED;
+  VIPE_CHECK_ARG(layout == VIPE_PYRAMID_REFERENCE || layout == VIPE_PYRAMID_BLOCKED);
+  if (layout == VIPE_PYRAMID_BLOCKED) VIPE_CHECK_ARG(h1 == h2 && w1 == w2 && w2 % 64 == 0 && h2 % 8 == 0);
   LevelPtrs lv;
   for (int i = 0; i < 4; ++i) {
     VIPE_CHECK_ARG(h_levels[i]);
@@ -662,6 +680,6 @@ VIPE_EXPORT int vipe_corr_lookup_conv1x1(const void* const* h_levels, const floa
   const int blocks = (int)std::min<int64_t>(ngroups, 256 * 4);
   corr_lookup_conv_kernel<<<blocks, 256, 0, as_stream(stream)>>>(lv, d_coords, (const half_t*)d_w_packed, d_bias,
                                                                  (half_t*)d_out, out_ctot, out_coff, h1, w1, h2, w2, B,
-                                                                 128, act, d_slots);
+                                                                 128, act, d_slots, layout);
   return vipe_launch_status();
 }

@@ -74,6 +74,40 @@ def corr_volume(fmap1, fmap2):
     return torch.matmul(f1.transpose(1, 2), f2)
 
 
+REFERENCE, BLOCKED = 0, 1  # VIPE_PYRAMID_* (include/vipe_amd.h)
+
+
+def fused_build_covers(C, h, w, num_levels, dtype=torch.float16):
+    """shapes of the fused volume + pyramid kernel (the DROID maps at 1/8 of 512x384 and multiples)"""
+    return dtype == torch.float16 and C == 128 and w % 64 == 0 and h % 8 == 0 and num_levels <= 4 and (h >> (num_levels - 1)) > 0
+
+
+def pyramid_level_shapes(n, h, w, num_levels, layout):
+    """per-level tensor shapes of `n` edges' pyramids in `layout` (same element count per level in both layouts)"""
+    shapes = [(n, h, w, h >> i, w >> i) for i in range(num_levels)]
+    if layout == BLOCKED:
+        G, runs = h * w // 64, (h // 4) * (w // 32)
+        shapes[0] = (n, G, runs, 64, 4, 4, 8)
+        if num_levels > 1:
+            shapes[1] = (n, G, runs // 2, 64, 2, 4, 8)
+    return shapes
+
+
+def pyramid_to_reference(levels, h, w):
+    """BLOCKED levels -> the reference's [n,h,w,h>>i,w>>i] tensors (copies of levels 0 / 1; levels 2.. are shared)"""
+    out = list(levels)
+    for i in range(min(2, len(levels))):
+        lv = levels[i]
+        if lv.dim() != 7:
+            continue
+        n, G, _, _, T = lv.shape[:5]
+        hl, wl = h >> i, w >> i
+        # [n, G, strip, rowgroup, p, tile, row, col] -> [n, G, p, rowgroup, row, strip, tile, col]
+        x = lv.reshape(n, G, wl // (8 * T), hl // 4, 64, T, 4, 8).permute(0, 1, 4, 3, 6, 2, 5, 7)
+        out[i] = x.reshape(n, h, w, hl, wl)
+    return out
+
+
 def corr_pyramid_build(fmap1, fmap2, num_levels=4):
     """CorrBlock.__init__ (droid_net.py:56-69): list of [E,h,w,h>>i,w>>i].
 
@@ -81,8 +115,7 @@ def corr_pyramid_build(fmap1, fmap2, num_levels=4):
     through the fused HIP kernel (volume + the three pooled levels in one pass, `vipe_corr_pyramid_build`); other
     shapes / dtypes are a plain library GEMM + pooling on the GPU (`corr_volume`, hipBLASLt)."""
     E, C, h, w = fmap1.shape
-    if (fmap1.dtype == torch.float16 and fmap2.dtype == torch.float16 and fmap1.is_cuda and C == 128 and w % 64 == 0
-            and h % 8 == 0 and num_levels <= 4 and (h >> (num_levels - 1)) > 0):
+    if fmap1.dtype == fmap2.dtype and fmap1.is_cuda and fused_build_covers(C, h, w, num_levels, fmap1.dtype):
         check_gpu_contig(fmap1, fmap2)
         levels = [torch.empty((E, h, w, h >> i, w >> i), dtype=torch.float16, device=fmap1.device)
                   for i in range(num_levels)]
@@ -96,6 +129,34 @@ def corr_pyramid_build(fmap1, fmap2, num_levels=4):
         levels.append(vol.view(E, h, w, h >> i, w >> i))
         if i + 1 < num_levels:
             vol = torch.nn.functional.avg_pool2d(vol, 2, stride=2)
+    return levels
+
+
+def corr_pyramid_build_indexed(fmaps, idx1, idx2, levels=None, slots=None, layout=BLOCKED, num_levels=4):
+    """[fused] pyramids of the edges (idx1[e] -> idx2[e]) straight from the keyframe buffer: fmaps [n_frames,C,h,w] f16,
+    idx1 / idx2 [E] int64 frame indices (factor_graph.py:147-148 gathers `fmaps[ii]`, `fmaps[jj]` first - never
+    materialised here).  `levels`: existing level buffers of a pooled store, edge e is written to slot slots[e] (int32
+    [E]); None: fresh buffers for E edges, slot e.  Returns the level list."""
+    n, C, h, w = fmaps.shape
+    E = int(idx1.shape[0])
+    require(fused_build_covers(C, h, w, num_levels, fmaps.dtype) and fmaps.is_cuda,
+            "corr_pyramid_build_indexed: fp16 maps, C == 128, w % 64 == 0, h % 8 == 0")
+    check_gpu_contig(fmaps, idx1, idx2)
+    require(idx1.dtype == torch.int64 and idx2.dtype == torch.int64 and idx2.shape[0] == E, "idx1 / idx2: int64 [E]")
+    if levels is None:
+        levels = [torch.empty(s, dtype=torch.float16, device=fmaps.device)
+                  for s in pyramid_level_shapes(E, h, w, num_levels, layout)]
+    else:
+        want = pyramid_level_shapes(levels[0].shape[0], h, w, num_levels, layout)
+        require(len(levels) == num_levels and all(tuple(lv.shape) == s and lv.is_contiguous() for lv, s in zip(levels, want)),
+                "level buffers do not match the layout")
+    if slots is not None:
+        check_gpu_contig(slots)
+        require(slots.dtype == torch.int32 and slots.shape[0] == E, "slots: int32 [E]")
+    ptrs = (ctypes.c_void_p * num_levels)(*[lv.data_ptr() for lv in levels])
+    check(lib().vipe_corr_pyramid_build_indexed(ptr(fmaps), ptr(idx1), ptr(idx2), ptr(slots) if slots is not None else None,
+                                                ptrs, E, C, h, w, num_levels, layout, stream_ptr(fmaps)),
+          "corr_pyramid_build_indexed")
     return levels
 
 
@@ -136,12 +197,15 @@ def corr_pyramid_lookup_nhwc(levels, coords, radius=3, channel_stride=200):
 def corr_lookup_conv1x1(levels, coords, w_packed, bias, out, out_coff=0, cout=128, act="relu", slots=None):
     """[fused] `CorrBlock.__call__` (4 levels, radius 3) + the correlation encoder's first 1x1 convolution
     (droid_net.py:436-437): writes out[E,h,w,C] channels [out_coff, out_coff + cout) without materialising the
-    196-channel lookup.  levels: fp16 pyramid of `corr_pyramid_build`; coords [E,h,w,2] f32.
+    196-channel lookup.  levels: fp16 pyramid of `corr_pyramid_build` (reference layout) or of
+    `corr_pyramid_build_indexed` (blocked layout: 7-D level 0); coords [E,h,w,2] f32.
     Raises NotImplementedError for configurations the fused kernel does not cover (callers fall back to
     `corr_pyramid_lookup_nhwc` + the conv)."""
     check_gpu_contig(coords, out, *levels)
     require(len(levels) == 4 and levels[0].dtype == torch.float16 and coords.dtype == torch.float32, "fp16 4-level pyramid")
-    cap, h1, w1, h2, w2 = levels[0].shape
+    layout = BLOCKED if levels[0].dim() == 7 else REFERENCE
+    cap, h1, w1 = levels[2].shape[:3]
+    h2, w2 = levels[2].shape[3] << 2, levels[2].shape[4] << 2
     E = cap if slots is None else int(slots.shape[0])  # slots [E] int32: edge e reads pyramid slot slots[e] (pooled store)
     if slots is not None:
         check_gpu_contig(slots)
@@ -151,6 +215,6 @@ def corr_lookup_conv1x1(levels, coords, w_packed, bias, out, out_coff=0, cout=12
     arr = (ctypes.c_void_p * 4)(*[lv.data_ptr() for lv in levels])
     check(lib().vipe_corr_lookup_conv1x1(ctypes.cast(arr, ctypes.c_void_p), ptr(coords), ptr(w_packed), ptr(bias), ptr(out),
                                          out.shape[-1], out_coff, E, h1, w1, h2, w2, cout, {"none": 0, "relu": 1}[act],
-                                         ptr(slots) if slots is not None else None, stream_ptr(coords)),
+                                         ptr(slots) if slots is not None else None, layout, stream_ptr(coords)),
           "corr_lookup_conv1x1")
     return out

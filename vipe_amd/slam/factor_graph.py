@@ -92,8 +92,10 @@ class FactorGraph:
         jj = torch.from_numpy(jj_h).to(self.device)
         pi, qi, _, pj, qj, _ = self.buffer.expand_edge_multiview(ii, jj)
         if self.incremental:
-            corr = CorrBlock(self.buffer.fmaps[pi, qi][None], self.buffer.fmaps[pj, qj][None])
-            self.corr = (CorrPool(capacity=max(64, self.max_factors + 16)) if self.corr is None else self.corr).cat(corr)
+            if self.corr is None:
+                self.corr = CorrPool(capacity=max(64, self.max_factors + 16))
+            V = self.buffer.n_views
+            self.corr.add_edges(self.buffer.flattened_fmaps, pi * V + qi, pj * V + qj)
             xb = torch.zeros((ii.shape[0] * self.buffer.n_views, self.ht, self.wd, 320), dtype=torch.half,
                              device=self.device)
             xb[..., 0:128] = self.buffer.inps[pi, qi].permute(0, 2, 3, 1)
@@ -461,7 +463,7 @@ class FactorGraph:
                 if use_volume:
                     vol = vols.get(gi)
                     if vol is None:
-                        vol = CorrBlock(buf.fmaps[pis, qis][None], buf.fmaps[pjs, qjs][None])
+                        vol = CorrBlock.from_buffer(buf.flattened_fmaps, pis * V + qis, pjs * V + qjs)
                         if keep_vols:
                             vols[gi] = vol
                     corr_n = vol.lookup_deferred(c1)

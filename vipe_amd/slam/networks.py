@@ -19,15 +19,40 @@ class CorrBlock:
     """All-pairs correlation pyramid + 7x7 bilinear lookup (droid_net.py:48-102).
 
     Layout: level i is [E, h1, w1, h2/2^i, w2/2^i], contiguous, dtype of the feature maps (fp16 under
-    autocast in the reference, factor_graph.py:119) - 25.1 MB/edge at 48x64.
+    autocast in the reference, factor_graph.py:119) - 25.1 MB/edge at 48x64.  `from_buffer` builds the same pyramid
+    from frame indices in the BLOCKED internal layout (include/vipe_amd.h) that the fused lookup kernel reads with half
+    the memory sectors; `corr_pyramid` then converts on access.
     """
 
     def __init__(self, fmap1, fmap2, num_levels=4, radius=3):
         self.num_levels = num_levels
         self.radius = radius
         batch, num, dim, ht, wd = fmap1.shape
-        self.corr_pyramid = droid_net_ext.corr_pyramid_build(
+        self.ht, self.wd = ht, wd
+        self.levels = droid_net_ext.corr_pyramid_build(
             fmap1.reshape(batch * num, dim, ht, wd), fmap2.reshape(batch * num, dim, ht, wd), num_levels)
+
+    @classmethod
+    def from_buffer(cls, fmaps, idx1, idx2, num_levels=4, radius=3):
+        """fmaps [n_frames,C,h,w]; edge e correlates frame idx1[e] with frame idx2[e] - the gathered copies
+        `fmaps[idx1]`, `fmaps[idx2]` (factor_graph.py:147-148) are never made when the fused kernel covers the shape."""
+        n, C, ht, wd = fmaps.shape
+        if not (fmaps.is_cuda and droid_net_ext.fused_build_covers(C, ht, wd, num_levels, fmaps.dtype)):
+            return cls(fmaps[idx1][None], fmaps[idx2][None], num_levels, radius)
+        self = cls.__new__(cls)
+        self.num_levels, self.radius, self.ht, self.wd = num_levels, radius, ht, wd
+        self.levels = droid_net_ext.corr_pyramid_build_indexed(fmaps, idx1.contiguous(), idx2.contiguous(),
+                                                               num_levels=num_levels)
+        return self
+
+    @property
+    def corr_pyramid(self):
+        """the reference's attribute: list of [E,h,w,h>>i,w>>i] (a converted copy when the store is blocked)"""
+        return droid_net_ext.pyramid_to_reference(self.levels, self.ht, self.wd)
+
+    @corr_pyramid.setter
+    def corr_pyramid(self, levels):
+        self.levels = list(levels)
 
     def __call__(self, coords):
         batch, num, ht, wd, _ = coords.shape
@@ -41,20 +66,19 @@ class CorrBlock:
     def lookup_deferred(self, coords):
         """Handle for the fused lookup + correlation-encoder kernel (`UpdateEngine.forward_nhwc` consumes it), or the
         materialised channels-last lookup when the fused kernel does not cover this pyramid."""
-        lv = self.corr_pyramid
+        lv = self.levels
         if (self.num_levels == 4 and self.radius == 3 and lv[0].dtype == torch.float16 and lv[0].is_cuda
-                and (lv[0].shape[-1] >> 3) % 8 == 0 and (lv[0].shape[-2] >> 3) >= 1):
+                and (self.wd >> 3) % 8 == 0 and (self.ht >> 3) >= 1):
             return ("lookup", lv, coords.contiguous())
         return self.lookup_nhwc(coords)
 
     def cat(self, other):
-        for i in range(self.num_levels):
-            self.corr_pyramid[i] = torch.cat([self.corr_pyramid[i], other.corr_pyramid[i]], 0)
+        assert all(a.dim() == b.dim() for a, b in zip(self.levels, other.levels)), "layouts differ"
+        self.levels = [torch.cat([a, b], 0) for a, b in zip(self.levels, other.levels)]
         return self
 
     def __getitem__(self, index):
-        for i in range(self.num_levels):
-            self.corr_pyramid[i] = self.corr_pyramid[i][index]
+        self.levels = [lv[index] for lv in self.levels]
         return self
 
     @staticmethod
@@ -65,17 +89,33 @@ class CorrBlock:
         return vol.view(batch, num, ht, wd, ht, wd)
 
 
+def _to_blocked(levels, ht, wd):
+    """reference-layout levels -> BLOCKED (inverse of droid_net_ext.pyramid_to_reference; copies levels 0 / 1)"""
+    out = list(levels)
+    for i in range(min(2, len(levels))):
+        lv = levels[i]
+        n, T = lv.shape[0], 4 >> i
+        hl, wl = ht >> i, wd >> i
+        x = lv.reshape(n, ht * wd // 64, 64, hl // 4, 4, wl // (8 * T), T, 8).permute(0, 1, 5, 3, 2, 6, 4, 7)
+        out[i] = x.reshape(n, ht * wd // 64, (hl // 4) * (wl // (8 * T)), 64, T, 4, 8).contiguous()
+    return out
+
+
 class CorrPool:
     """Edge-indexed store of correlation pyramids for a graph whose edges come and go every keyframe
     (factor_graph.py:147-152 appends with `corr.cat`, :194-196 drops with `corr[~mask]` - each a copy of the whole
-    pyramid, 25 MB per edge).  Here the level buffers have spare capacity and edge e owns slot `slots[e]`: adding
-    writes only the new edges' volumes into free slots, removing only edits the slot vector, and the fused lookup
-    kernel follows the indirection.  Same call surface as CorrBlock (`cat`, `__getitem__`, `__call__`,
-    `lookup_nhwc`, `lookup_deferred`, `corr_pyramid`)."""
+    pyramid, 25 MB per edge).  Here the level buffers have spare capacity and edge e owns slot `slots[e]`: `add_edges`
+    has the build kernel write the new edges' pyramids straight into free slots (from frame indices - neither the
+    gathered feature maps nor a temporary pyramid exist), removing only edits the slot vector, and the fused lookup
+    kernel follows the indirection.  Being private, the store uses the BLOCKED layout (include/vipe_amd.h) whenever
+    the fused kernels cover the shape; `corr_pyramid` materialises the reference layout.  Same call surface as
+    CorrBlock (`cat`, `__getitem__`, `__call__`, `lookup_nhwc`, `lookup_deferred`, `corr_pyramid`)."""
 
     def __init__(self, num_levels=4, radius=3, capacity=64):
         self.num_levels, self.radius, self.capacity = num_levels, radius, capacity
         self.pool = None
+        self.blocked = False
+        self.ht = self.wd = None
         self.slots = None        # int32 [E] on the device
         self._slots_host = []    # the same, host side (edge bookkeeping never reads the device copy back)
         self._free = []
@@ -83,12 +123,13 @@ class CorrPool:
     def __len__(self):
         return len(self._slots_host)
 
-    def _grow(self, like, need):
+    def _reserve(self, need, shapes_of, dtype, device):
+        """make `need` free slots available; shapes_of(cap) -> per-level shapes of a `cap`-slot store"""
         if self.pool is None:
             cap = self.capacity
             while cap < need:
                 cap *= 2
-            self.pool = [torch.empty((cap,) + tuple(lv.shape[1:]), dtype=lv.dtype, device=lv.device) for lv in like]
+            self.pool = [torch.empty(s, dtype=dtype, device=device) for s in shapes_of(cap)]
             self._free = list(range(cap))
             return
         cap = new_cap = self.pool[0].shape[0]
@@ -99,75 +140,43 @@ class CorrPool:
                          for p in self.pool]
             self._free += list(range(cap, new_cap))
 
-    def cat(self, other):
-        for i in range(self.num_levels):
-            self.corr_pyramid[i] = torch.cat([self.corr_pyramid[i], other.corr_pyramid[i]], 0)
+    def _take(self, k, device):
+        ids = [self._free.pop(0) for _ in range(k)]
+        self._slots_host += ids
+        new = torch.tensor(ids, dtype=torch.int32, device=device)
+        self.slots = new if self.slots is None else torch.cat([self.slots, new], 0)
+        return ids, new
+
+    def add_edges(self, fmaps, idx1, idx2):
+        """append the edges (frame idx1[e] -> frame idx2[e]) of fmaps [n_frames,C,h,w]"""
+        n, C, ht, wd = fmaps.shape
+        k = int(idx1.shape[0])
+        fused = fmaps.is_cuda and droid_net_ext.fused_build_covers(C, ht, wd, self.num_levels, fmaps.dtype)
+        if not fused or (self.pool is not None and not self.blocked):
+            return self.cat(CorrBlock(fmaps[idx1][None], fmaps[idx2][None], self.num_levels, self.radius))
+        self.blocked, self.ht, self.wd = True, ht, wd
+        self._reserve(k, lambda cap: droid_net_ext.pyramid_level_shapes(cap, ht, wd, self.num_levels, droid_net_ext.BLOCKED),
+                      fmaps.dtype, fmaps.device)
+        _, new = self._take(k, fmaps.device)
+        droid_net_ext.corr_pyramid_build_indexed(fmaps, idx1.contiguous(), idx2.contiguous(), levels=self.pool, slots=new,
+                                                 num_levels=self.num_levels)
         return self
-
-    def __getitem__(self, index):
-        for i in range(self.num_levels):
-            self.corr_pyramid[i] = self.corr_pyramid[i][index]
-        return self
-
-    @staticmethod
-    def corr(fmap1, fmap2):
-        """all-pairs correlation (droid_net.py:94-102): (fmap1/4)^T (fmap2/4) -> [B,num,ht,wd,ht,wd]"""
-        batch, num, dim, ht, wd = fmap1.shape
-        vol = droid_net_ext.corr_volume(fmap1.reshape(batch * num, dim, ht, wd), fmap2.reshape(batch * num, dim, ht, wd))
-        return vol.view(batch, num, ht, wd, ht, wd)
-
-
-class CorrPool:
-    """Edge-indexed store of correlation pyramids for a graph whose edges come and go every keyframe
-    (factor_graph.py:147-152 appends with `corr.cat`, :194-196 drops with `corr[~mask]` - each a copy of the whole
-    pyramid, 25 MB per edge).  Here the level buffers have spare capacity and edge e owns slot `slots[e]`: adding
-    writes only the new edges' volumes into free slots, removing only edits the slot vector, and the fused lookup
-    kernel follows the indirection.  Same call surface as CorrBlock (`cat`, `__getitem__`, `__call__`,
-    `lookup_nhwc`, `lookup_deferred`, `corr_pyramid`)."""
-
-    def __init__(self, num_levels=4, radius=3, capacity=64):
-        self.num_levels, self.radius, self.capacity = num_levels, radius, capacity
-        self.pool = None
-        self.slots = None        # int32 [E] on the device
-        self._slots_host = []    # the same, host side (edge bookkeeping never reads the device copy back)
-        self._free = []
-
-    def __len__(self):
-        return len(self._slots_host)
-
-    def _grow(self, like, need):
-        cap = self.capacity if self.pool is None else self.pool[0].shape[0]
-        new_cap = cap
-        while new_cap - (0 if self.pool is None else cap - len(self._free)) < need:
-            new_cap *= 2
-        if self.pool is None:
-            self.pool = [torch.empty((new_cap,) + tuple(lv.shape[1:]), dtype=lv.dtype, device=lv.device) for lv in like]
-            self._free = list(range(new_cap))
-        elif new_cap > cap:
-            self.pool = [torch.cat([p, torch.empty((new_cap - cap,) + tuple(p.shape[1:]), dtype=p.dtype, device=p.device)], 0)
-                         for p in self.pool]
-            self._free += list(range(cap, new_cap))
 
     def cat(self, other):
         """append the edges of a CorrBlock (its volumes are copied into free slots)"""
-        lv = other.corr_pyramid
+        lv = other.levels if hasattr(other, "levels") else other.corr_pyramid
         k = lv[0].shape[0]
-        if self.pool is None and k >= self.capacity:
-            # a first block at least as large as the default capacity (a whole graph added at once): its level buffers
-            # BECOME the pool - no second copy of a multi-GB pyramid; later additions grow it like any full pool
-            self.pool = [l.contiguous() for l in lv]
-            self._slots_host = list(range(k))
-            self.slots = torch.arange(k, dtype=torch.int32, device=lv[0].device)
-            return self
-        if self.pool is None or len(self._free) < k:
-            self._grow(lv, k)
-        ids = [self._free.pop(0) for _ in range(k)]
+        if self.ht is None:
+            self.ht, self.wd = (int(x) for x in lv[min(2, len(lv) - 1)].shape[1:3])
+        if self.pool is not None and self.blocked and lv[0].dim() != 7:
+            lv = _to_blocked(lv, self.ht, self.wd)
+        elif self.pool is None:
+            self.blocked = lv[0].dim() == 7
+        self._reserve(k, lambda cap: [(cap,) + tuple(l.shape[1:]) for l in lv], lv[0].dtype, lv[0].device)
+        ids, _ = self._take(k, lv[0].device)
         idt = torch.tensor(ids, dtype=torch.long, device=lv[0].device)
         for p, l in zip(self.pool, lv):
             p.index_copy_(0, idt, l)
-        self._slots_host += ids
-        new = idt.to(torch.int32)
-        self.slots = new if self.slots is None else torch.cat([self.slots, new], 0)
         return self
 
     def __getitem__(self, index):
@@ -185,9 +194,10 @@ class CorrPool:
 
     @property
     def corr_pyramid(self):
-        """materialised [E, ...] levels in edge order (reference layout; copies)"""
+        """materialised [E, h, w, h>>i, w>>i] levels in edge order (reference layout; copies)"""
         idx = self.slots.long()
-        return [p.index_select(0, idx) for p in self.pool]
+        lv = [p.index_select(0, idx) for p in self.pool]
+        return droid_net_ext.pyramid_to_reference(lv, self.ht, self.wd) if self.blocked else lv
 
     def __call__(self, coords):
         batch, num, ht, wd, _ = coords.shape
@@ -200,7 +210,7 @@ class CorrPool:
     def lookup_deferred(self, coords):
         lv = self.pool
         if (self.num_levels == 4 and self.radius == 3 and lv[0].dtype == torch.float16 and lv[0].is_cuda
-                and (lv[0].shape[-1] >> 3) % 8 == 0 and (lv[0].shape[-2] >> 3) >= 1):
+                and (self.wd >> 3) % 8 == 0 and (self.ht >> 3) >= 1):
             return ("lookup", lv, coords.contiguous(), self.slots)
         return self.lookup_nhwc(coords)
 
