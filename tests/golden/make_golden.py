@@ -204,6 +204,95 @@ def gen_ba(R):
     np.savez_compressed(os.path.join(HERE, "ba_reference.npz"), **out)
 
 
+def reference_ba_rig(R, g, t0, t1, n_iters, pose_damping, pose_ep, motion_only=False, limited_disp=False,
+                     optimize_intrinsics=False, optimize_rig_rotation=False, alpha=0.001):
+    """The reference Solver on a multi-view rig exactly as GraphBuffer.bundle_adjustment sets it up (buffer.py:396-525):
+    V views, per-view intrinsics, `expand_edge_multiview` terms incl. cross-view self edges, rig group with view 0
+    fixed and the rotation-only retractor (buffer.py:497-506, retractor.py:32-37)."""
+    from vipe_amd.synth import expand_edges
+    Solver, SparseBlockVector = R.solver.Solver, R.vector.SparseBlockVector
+    T, RT = R.terms, R.retractor
+    cam = R.cameras.CameraType.PINHOLE
+    V, N, ht, wd = g.V, g.n, g.ht, g.wd
+    poses = torch.tensor(g.poses).float().clone()
+    dis = torch.tensor(g.disps).float().clone().view(N * V, ht * wd)
+    sens = torch.tensor(g.disps_sens).float().view(N * V, ht * wd)
+    intr = torch.tensor(g.intrinsics).float().clone()
+    rig = torch.tensor(g.rig).float().clone()
+    pi, qi, di, pj, qj = (torch.tensor(x) for x in expand_edges(g.ii, g.jj, V))
+    di_unique, pi_unique = torch.unique(di), torch.unique(torch.tensor(g.ii))
+    M = len(pi)
+    solver = Solver(compute_energy=True)
+    solver.add_term(T.DenseDepthFlowTerm(
+        pose_i_inds=pi, pose_j_inds=pj, rig_i_inds=qi, rig_j_inds=qj, dense_disp_i_inds=di,
+        target=torch.tensor(g.target).float().reshape(M, ht * wd, 2),
+        weight=0.001 * torch.tensor(g.weight).float().reshape(M, ht * wd, 2),
+        intrinsics=None, intrinsics_factor=8.0, rig=None, image_size=(ht, wd), camera_type=cam))
+    solver.set_fixed("pose", torch.cat([pi_unique[pi_unique < t0], pi_unique[pi_unique >= t1]]) if t0 < t1 else None)
+    solver.set_retractor("pose", RT.PoseRetractor())
+    solver.set_damping("pose", damping=pose_damping, ep=pose_ep)
+    if not motion_only:
+        sens_i = di_unique[sens[di_unique].sum(1) > 0.0]
+        if len(sens_i) > 0:
+            solver.add_term(T.DispSensRegularizationTerm(i_inds=sens_i, alpha=alpha, disps_sens=sens))
+        solver.set_retractor("dense_disp", RT.DenseDispRetractor())
+        damp = torch.tensor(g.eta).float().view(N * V, ht * wd)
+        solver.set_damping("dense_disp", damping=SparseBlockVector(inds=di_unique, data=0.2 * damp[di_unique] + 1e-7),
+                           ep=1e-7)
+        if limited_disp:
+            solver.set_fixed("dense_disp", torch.cat([di[pi < t0], di[pi >= t1]]))
+    else:
+        solver.set_fixed("dense_disp")
+    solver.set_marginilized("dense_disp")
+    solver.set_retractor("intrinsics", RT.IntrinsicsRetractor(cam))
+    solver.set_damping("intrinsics", damping=1e-6, ep=1e-6)
+    if not optimize_intrinsics:
+        solver.set_fixed("intrinsics")
+    solver.set_retractor("rig", RT.RigRotationOnlyRetractor())
+    solver.set_damping("rig", damping=1e-4, ep=1e-4)
+    if not optimize_rig_rotation:
+        solver.set_fixed("rig")
+    else:
+        solver.set_fixed("rig", torch.zeros(1).long())
+    energies = []
+    for _ in range(n_iters):
+        energies.append(solver.run_inplace({"pose": R.SE3(poses), "dense_disp": dis, "intrinsics": intr, "rig": R.SE3(rig)}))
+    dis.clamp_(min=0.001)
+    return _np(poses), _np(dis.view(N, V, ht, wd)), _np(intr), _np(rig), np.asarray(energies, dtype=np.float64)
+
+
+BA_RIG_CASES = {
+    # name: (make_rig_graph kwargs, BA kwargs) - V = 2 unless stated
+    "v2_fixed_rig": (dict(n=4, V=2, radius=2, seed=3),
+                     dict(t0=1, t1=4, n_iters=3, pose_damping=1e-3, pose_ep=0.1)),
+    "v2_rig_rotation": (dict(n=4, V=2, radius=2, seed=5),
+                        dict(t0=1, t1=4, n_iters=3, pose_damping=1e-5, pose_ep=1e-2, optimize_rig_rotation=True)),
+    "v2_intrinsics": (dict(n=4, V=2, radius=2, seed=7),
+                      dict(t0=1, t1=4, n_iters=2, pose_damping=1e-5, pose_ep=1e-2, optimize_intrinsics=True)),
+    "v2_rig_and_intrinsics_prior": (dict(n=5, V=2, radius=2, seed=9, depth_prior=True),
+                                    dict(t0=1, t1=5, n_iters=2, pose_damping=1e-5, pose_ep=1e-2, optimize_intrinsics=True,
+                                         optimize_rig_rotation=True)),
+    "v3_rig_rotation_window": (dict(n=5, V=3, radius=1, seed=11),
+                               dict(t0=2, t1=5, n_iters=2, pose_damping=1e-3, pose_ep=0.1, optimize_rig_rotation=True)),
+    "v2_no_self_edges_motion_only": (dict(n=4, V=2, radius=2, seed=13, self_edges=False),
+                                     dict(t0=1, t1=4, n_iters=2, pose_damping=1e-3, pose_ep=0.1, motion_only=True)),
+}
+
+
+def gen_ba_rig(R):
+    """Multi-view rigs through the reference Solver: fixed rig, rig-rotation group, per-view intrinsics, both + depth
+    prior, three views with a pose window, and a motion-only case without cross-view terms."""
+    from vipe_amd.synth import make_rig_graph
+    out = {}
+    for name, (gk, bk) in BA_RIG_CASES.items():
+        g = make_rig_graph(**gk)
+        p, d, k, r, en = reference_ba_rig(R, g, **bk)
+        out[name + "/poses"], out[name + "/disps"], out[name + "/intrinsics"], out[name + "/rig"] = p, d, k, r
+        out[name + "/energy"] = en
+        print(name, "energy", en)
+    np.savez_compressed(os.path.join(HERE, "ba_rig_reference.npz"), **out)
+
+
 def gen_reproject(R):
     """geom.iproj_i_proj_j_disp values + Jacobians, pinhole and MEI (geom.py:187-298)."""
     out = {}
@@ -372,6 +461,9 @@ if __name__ == "__main__":
     if os.environ.get("GOLDEN_ONLY") == "edges":
         gen_edge_selection(R)
         sys.exit(0)
+    if os.environ.get("GOLDEN_ONLY") == "ba_rig":
+        gen_ba_rig(R)
+        sys.exit(0)
     if os.environ.get("GOLDEN_ONLY") == "encoder":
         gen_encoder(R)
         sys.exit(0)
@@ -379,6 +471,7 @@ if __name__ == "__main__":
     gen_lie_wrapper(R)
     gen_reproject(R)
     gen_ba(R)
+    gen_ba_rig(R)
     gen_update_module(R)
     gen_corr(R)
     gen_encoder(R)

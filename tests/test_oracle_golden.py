@@ -28,6 +28,52 @@ def _ba_cases():
 BA_CASES = _ba_cases()
 
 
+def _ba_rig_cases():
+    src = open(os.path.join(GOLD, "make_golden.py")).read()
+    ns = {}
+    exec(src[src.index("BA_RIG_CASES = {"):src.index("def gen_ba_rig")], ns)
+    return ns["BA_RIG_CASES"]
+
+
+BA_RIG_CASES = _ba_rig_cases()
+
+
+def run_oracle_ba_rig(name, dtype):
+    from vipe_amd.synth import make_rig_graph
+    gk, bk = BA_RIG_CASES[name]
+    g = make_rig_graph(**gk)
+    M = g.target.shape[0]
+    return ba.bundle_adjustment(g.poses, g.disps, g.disps_sens, g.intrinsics, g.rig, g.target.reshape(M, -1, 2),
+                                g.weight.reshape(M, -1, 2), g.eta, g.ii, g.jj, dtype=dtype, **bk), g
+
+
+@pytest.mark.parametrize("name", sorted(BA_RIG_CASES))
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_ba_rig_matches_reference_solver(name, dtype):
+    """Multi-view rigs (V = 2, 3): per-view intrinsics blocks, the rig-rotation group (view 0 fixed, rotation-only
+    retraction, buffer.py:497-506, retractor.py:32-37), cross-view self edges - the oracle against the reference's own
+    Solver driven as GraphBuffer.bundle_adjustment drives it (tests/golden/make_golden.py:reference_ba_rig)."""
+    G = np.load(os.path.join(GOLD, "ba_rig_reference.npz"))
+    (p, d, k, r), g = run_oracle_ba_rig(name, dtype)
+    rp, rd, rk, rr = (G[f"{name}/{x}"] for x in ("poses", "disps", "intrinsics", "rig"))
+    tol = 2e-5 if dtype == np.float64 else 1e-4
+    assert np.abs(p - rp).max() <= tol * max(1.0, np.abs(rp).max())
+    assert np.abs(d - rd).max() <= tol * np.abs(rd).max()
+    assert np.abs(k - rk).max() <= 1e-4 * np.abs(rk).max()
+    assert np.abs(r - rr).max() <= tol
+    _, bk = BA_RIG_CASES[name]
+    assert np.array_equal(rr[0], g.rig[0])  # view 0 is the gauge
+    if bk.get("optimize_rig_rotation"):
+        # rotation-only step Exp([0, phi]) * R: the quaternion moves, |t| is preserved (t is rotated about the rig origin)
+        assert np.abs(rr[1:, 3:] - g.rig[1:, 3:]).max() > 1e-5
+        assert np.allclose(np.linalg.norm(rr[:, :3], axis=1), np.linalg.norm(g.rig[:, :3], axis=1), atol=1e-6)
+    else:
+        assert np.array_equal(rr, g.rig)
+    if bk.get("optimize_intrinsics"):
+        assert np.abs(rk[:, :2] - g.intrinsics[:, :2]).min() > 1e-4 and rk[0, 0] != rk[1, 0]  # one block per view
+    assert G[name + "/energy"][-1] < G[name + "/energy"][0]
+
+
 def run_oracle_ba(name, dtype):
     gk, bk = BA_CASES[name]
     bk = dict(bk)

@@ -81,6 +81,93 @@ def reproject_pinhole(poses, disps, intr8, ii, jj):
     return np.stack([fx * X1[..., 0] / Z + cx, fy * X1[..., 1] / Z + cy], -1)
 
 
+def expand_edges(ii, jj, V, cross_view_idx=None):
+    """buffer.py:318-361 on the host: every edge becomes V terms (pi,qi) -> (pj,qj), same view on both ends, except
+    self edges (i == j), which pair view v with view cross_view_idx[v] of the same keyframe.  -> pi, qi, di, pj, qj"""
+    ii, jj = np.asarray(ii, np.int64), np.asarray(jj, np.int64)
+    cv = np.asarray(cross_view_idx if cross_view_idx is not None else [(v + 1) % V for v in range(V)], np.int64)
+    pi, pj = np.repeat(ii, V), np.repeat(jj, V)
+    qi = np.tile(np.arange(V, dtype=np.int64), len(ii))
+    qj = np.where(pi == pj, cv[qi], qi)
+    return pi, qi, pi * V + qi, pj, qj
+
+
+@dataclass
+class SyntheticRigGraph:
+    ht: int
+    wd: int
+    n: int
+    V: int
+    poses_gt: np.ndarray  # [n,7] world->rig
+    rig_gt: np.ndarray  # [V,7] camera v -> rig (view 0 = identity)
+    disps_gt: np.ndarray  # [n,V,ht,wd]
+    poses: np.ndarray
+    rig: np.ndarray  # perturbed rotations for views >= 1
+    disps: np.ndarray
+    disps_sens: np.ndarray
+    intrinsics: np.ndarray  # [V,4] full resolution
+    ii: np.ndarray  # [E] keyframe edges incl. self edges (i,i) = cross-view terms
+    jj: np.ndarray
+    target: np.ndarray  # [E*V,ht,wd,2]
+    weight: np.ndarray
+    eta: np.ndarray  # [n,V,ht,wd]
+
+
+def make_rig_graph(n=4, V=2, height=96, width=128, radius=2, seed=3, self_edges=True, depth_prior=False,
+                   pose_noise=0.003, disp_noise=0.05, rig_noise=0.004):
+    """A small multi-camera rig clip (n keyframes x V views): view v looks ~0.06 v rad to the side of view 0 from a
+    0.08 v baseline, per-view focal lengths differ by a few percent.  Edges: the radius-r neighbourhood between
+    keyframes plus, with `self_edges`, (i,i) for every keyframe - which `expand_edges` turns into the cross-view terms
+    (factor_graph.py:62,454-458).  Targets = ground-truth reprojection + N(0, 0.5 px)."""
+    rng = np.random.default_rng(seed)
+    ht, wd = height // 8, width // 8
+    k = np.arange(n, dtype=np.float64)
+    c2w = np.concatenate([np.stack([0.05 * k, np.zeros(n), np.zeros(n)], -1) + rng.normal(0, 0.01, (n, 3)),
+                          _qexp(rng.normal(0, 0.01, (n, 3)))], -1)
+    c2w[0] = [0, 0, 0, 0, 0, 0, 1]
+    poses_gt = _se3_inv(c2w)
+    rig_gt = np.zeros((V, 7))
+    rig_gt[:, 6] = 1
+    for v in range(1, V):
+        rig_gt[v] = np.concatenate([[0.08 * v, 0.01 * v, 0.0], _qexp(np.array([0.0, 0.06 * v, 0.01 * v]))])
+    disps_gt = 1.0 / rng.uniform(1.0, 5.0, (n, V, ht, wd))
+    intr = np.stack([[0.9 * width * (1 + 0.03 * v), 0.9 * width * (1 + 0.03 * v), width / 2.0 + v, height / 2.0 - v]
+                     for v in range(V)])
+    ii, jj = neighbourhood_edges(n, radius)
+    if self_edges:
+        ii, jj = np.concatenate([ii, np.arange(n)]), np.concatenate([jj, np.arange(n)])
+    pi, qi, di, pj, qj = expand_edges(ii, jj, V)
+    M = len(pi)
+
+    def reproject(poses, rig, disps):
+        T = _se3_mul(_se3_mul(_se3_inv(rig[qj]), _se3_mul(poses[pj], _se3_inv(poses[pi]))), rig[qi])
+        v_, u_ = np.meshgrid(np.arange(ht, dtype=np.float64), np.arange(wd, dtype=np.float64), indexing="ij")
+        Ii, Ij = intr[qi] / 8.0, intr[qj] / 8.0
+        X0 = np.stack([(u_[None] - Ii[:, 2, None, None]) / Ii[:, 0, None, None],
+                       (v_[None] - Ii[:, 3, None, None]) / Ii[:, 1, None, None], np.ones((M, ht, wd))], -1)
+        d = disps.reshape(n * V, ht, wd)[di]
+        X1 = _qrot(T[:, None, None, 3:], X0) + T[:, None, None, :3] * d[..., None]
+        Z = np.where(X1[..., 2] < 0.1, 1.0, X1[..., 2])
+        return np.stack([Ij[:, 0, None, None] * X1[..., 0] / Z + Ij[:, 2, None, None],
+                         Ij[:, 1, None, None] * X1[..., 1] / Z + Ij[:, 3, None, None]], -1)
+
+    target = reproject(poses_gt, rig_gt, disps_gt) + rng.normal(0, 0.5, (M, ht, wd, 2))
+    weight = rng.uniform(0, 1, (M, ht, wd, 2))
+    eta = 0.01 * np.log1p(np.exp(rng.normal(0, 1, (n, V, ht, wd))))
+    dT = np.concatenate([rng.normal(0, pose_noise, (n, 3)), _qexp(rng.normal(0, pose_noise, (n, 3)))], -1)
+    dT[0] = [0, 0, 0, 0, 0, 0, 1]
+    poses = _se3_mul(dT, poses_gt)
+    rig = rig_gt.copy()
+    for v in range(1, V):  # rotation-only perturbation: what optimize_rig_rotation can undo
+        rig[v] = _se3_mul(np.concatenate([[0, 0, 0], _qexp(rng.normal(0, rig_noise, 3))]), rig_gt[v])
+    disps = disps_gt * (1 + rng.normal(0, disp_noise, disps_gt.shape))
+    sens = disps_gt * (1 + rng.normal(0, 0.05, disps_gt.shape)) if depth_prior else np.zeros_like(disps_gt)
+    f32 = np.float32
+    return SyntheticRigGraph(ht, wd, n, V, poses_gt.astype(f32), rig_gt.astype(f32), disps_gt.astype(f32),
+                             poses.astype(f32), rig.astype(f32), disps.astype(f32), sens.astype(f32), intr.astype(f32),
+                             ii, jj, target.astype(f32), weight.astype(f32), eta.astype(f32))
+
+
 def make_graph(n=48, height=384, width=512, radius=3, extra_edges=0, seed=1234, depth_prior=False,
                pose_noise=0.003, disp_noise=0.05):
     """Config 2/3 of BASELINE.json at the defaults (E=276); config 1 at n=2, 96x128."""
