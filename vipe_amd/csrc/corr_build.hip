@@ -155,14 +155,20 @@ __global__ __launch_bounds__(512) void corr_pyramid_build_kernel(BuildArgs a) {
     int y, x0;
     chunk_origin(ch, y, x0);
     if (BLK) {
-      // thread = (source pixel, tile 0..3 of the chunk, row pair 0..1 of the tile): 32 contiguous bytes of level 0; the
-      // workgroup's 512 x 32 B are one 16 KiB run
+      // Two roles per thread.  STORE: 16-byte pieces sseg and sseg + 8 of the source pixel's 256-byte run (piece q = row
+      // q % 4 of tile q / 4), so that each store instruction covers 128 contiguous bytes per source pixel and the
+      // workgroup's two instructions one 16 KiB run.  POOL: (tile sseg / 2, row pair sseg % 2) - the 2 x 8 patch whose
+      // level-1 entries this thread forms (re-read from the staged tile: LDS bandwidth is not the limit here).
       const int tile = sseg >> 1, hf = sseg & 1, rg = y >> 2;
+      half_t* dst = a.lv[0] + ((eg * nchunks + ch) * PB_M + sp1) * 128;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int q = sseg + 8 * s2;
+        *reinterpret_cast<half8*>(dst + q * 8) =
+            *reinterpret_cast<const half8*>(stage + sp1 * PB_PS + (q & 3) * 32 + (q >> 2) * 8);
+      }
       const half8 r0 = *reinterpret_cast<const half8*>(stage + sp1 * PB_PS + (2 * hf) * 32 + tile * 8);
       const half8 r1 = *reinterpret_cast<const half8*>(stage + sp1 * PB_PS + (2 * hf + 1) * 32 + tile * 8);
-      half_t* dst = a.lv[0] + ((eg * nchunks + ch) * PB_M + sp1) * 128 + tile * 32 + hf * 16;
-      *reinterpret_cast<half8*>(dst) = r0;
-      *reinterpret_cast<half8*>(dst + 8) = r1;
       if (a.nlev <= 1) return;
       half4 l1;  // level-1 row hf of the chunk (rows 2 (rg & 1) + hf of the level-1 tile), columns 4 tile .. + 3
 #pragma unroll

@@ -153,6 +153,45 @@ __global__ __launch_bounds__(256) void corr_pyramid_lookup_kernel(LevelPtrs lv, 
 // lane-per-pixel kernel.
 typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+// The 7 outputs out[a][j], a = 0..6, of ONE tap row j of one level, in packed fp16 arithmetic.  d[0..7]: the two aligned
+// 16-byte chunks of row y = by + j (zero outside the map), sh = (bx & 7): taps t[i] = halves d[sh + i], i = 0..7; the taps
+// nb[i] of row y + 1 come from lane + 1 of the 8-lane group.  out[a] = ((t[a] w00 + nb[a] w01) + t[a+1] w10) + nb[a+1] w11
+// with every product and every sum rounded to half - c10::Half's operators compute in float and round to half, which
+// for two half operands is the correctly rounded half product / sum (the float product of two halves is exact; the
+// float sum is exact unless the exponents differ by > 12, when both roundings return the larger operand), i.e. exactly
+// v_pk_mul_f16 / v_pk_add_f16.  -ffp-contract=off keeps the compiler from fusing them into v_pk_fma_f16.
+// Results: o[k] = (out[2k], out[2k+1]) as packed pairs, k = 0..3 (out[7] is a by-product that no one reads).
+__device__ __forceinline__ void row_outputs_pk(const unsigned (&d)[8], int sh, float w00, float w01, float w10, float w11,
+                                               half2v (&o)[4]) {
+  // funnel: e[k] = halves (sh + 2k, sh + 2k + 1) of the 16-half window.  Dword stages as bit-selects (v_bfi_b32; written
+  // as ternaries the compiler turns the stages into a dynamically indexed scratch array), then one v_alignbit by 0 / 16
+  const unsigned m1 = 0u - ((unsigned)(sh >> 1) & 1u), m2 = 0u - ((unsigned)(sh >> 2) & 1u);
+  unsigned a1[7], f[5];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) a1[k] = (d[k + 1] & m1) | (d[k] & ~m1);
+#pragma unroll
+  for (int k = 0; k < 5; ++k) f[k] = (a1[k + 2] & m2) | (a1[k] & ~m2);
+  const unsigned hs = ((unsigned)sh & 1u) << 4;
+  unsigned e[5];  // e[k] = (t[2k], t[2k+1]); e[4] = (t[8], .) only feeds the unused out[7]
+#pragma unroll
+  for (int k = 0; k < 4; ++k) e[k] = __builtin_amdgcn_alignbit(f[k + 1], f[k], hs);
+  e[4] = 0;
+  const half_t h00 = (half_t)w00, h01 = (half_t)w01, h10 = (half_t)w10, h11 = (half_t)w11;
+  const half2v v00 = {h00, h00}, v01 = {h01, h01}, v10 = {h10, h10}, v11 = {h11, h11};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned se = __builtin_amdgcn_alignbyte(e[k + 1], e[k], 2);  // (t[2k+1], t[2k+2])
+    const unsigned ne = __shfl_down(e[k], 1, 8), nse = __shfl_down(se, 1, 8);
+    half2v acc = __builtin_bit_cast(half2v, e[k]) * v00;   // (half)(0 + p) == p
+    acc = acc + __builtin_bit_cast(half2v, ne) * v01;
+    acc = acc + __builtin_bit_cast(half2v, se) * v10;
+    acc = acc + __builtin_bit_cast(half2v, nse) * v11;
+    o[k] = acc;
+  }
+}
+
 __global__ __launch_bounds__(256) void corr_pyramid_lookup_rows_kernel(LevelPtrs lv, const float* __restrict__ coords,
                                                                        half_t* __restrict__ out, int h1, int w1, int h2,
                                                                        int w2, int L, int nhwc_stride) {
@@ -184,48 +223,16 @@ __global__ __launch_bounds__(256) void corr_pyramid_lookup_rows_kernel(LevelPtrs
   uint4v lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
   if (rowok & (c0 >= 0) & (c0 < nchunks)) lo = rowp[c0];
   if (rowok & (c0 + 1 >= 0) & (c0 + 1 < nchunks)) hi = rowp[c0 + 1];
-  unsigned d[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  // dword funnel: f[k] = d[(sh >> 1) + k], k = 0..4
-  const int q = sh >> 1;
-  unsigned a1[7], f[5];
-#pragma unroll
-  for (int k = 0; k < 7; ++k) a1[k] = (q & 1) ? d[k + 1] : d[k];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) f[k] = (q & 2) ? a1[k + 2] : a1[k];
-  unsigned e[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) e[k] = (sh & 1) ? __builtin_amdgcn_alignbyte(f[k + 1], f[k], 2) : f[k];
-  // neighbour row (lane j+1 of the same 8-lane group)
-  unsigned ne[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) ne[k] = __shfl_down(e[k], 1, 8);
-  float t[8], nb[8];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    half_t h0, h1v;
-    unsigned short u0 = (unsigned short)(e[k] & 0xffffu), u1 = (unsigned short)(e[k] >> 16);
-    __builtin_memcpy(&h0, &u0, 2);
-    __builtin_memcpy(&h1v, &u1, 2);
-    t[2 * k] = (float)h0;
-    t[2 * k + 1] = (float)h1v;
-    u0 = (unsigned short)(ne[k] & 0xffffu);
-    u1 = (unsigned short)(ne[k] >> 16);
-    __builtin_memcpy(&h0, &u0, 2);
-    __builtin_memcpy(&h1v, &u1, 2);
-    nb[2 * k] = (float)h0;
-    nb[2 * k + 1] = (float)h1v;
-  }
+  const unsigned d[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  half2v o[4];
+  row_outputs_pk(d, sh, w00, w01, w10, w11, o);
   if (!pok || j >= RD) return;
 #pragma unroll
   for (int a = 0; a < RD; ++a) {
-    float acc = 0.0f;
-    acc = A::madd(acc, t[a], w00);       // tap (i=a,   j)
-    acc = A::madd(acc, nb[a], w01);      // tap (i=a,   j+1)
-    acc = A::madd(acc, t[a + 1], w10);   // tap (i=a+1, j)
-    acc = A::madd(acc, nb[a + 1], w11);  // tap (i=a+1, j+1)
     const int ch = l * (RD * RD) + a * RD + j;
-    if (nhwc_stride > 0) out[((int64_t)n * P + p) * nhwc_stride + ch] = A::store(acc);
-    else out[((int64_t)n * L * (RD * RD) + ch) * P + p] = A::store(acc);
+    const half_t v = o[a >> 1][a & 1];
+    if (nhwc_stride > 0) out[((int64_t)n * P + p) * nhwc_stride + ch] = v;
+    else out[((int64_t)n * L * (RD * RD) + ch) * P + p] = v;
   }
   if (nhwc_stride > 0 && l == L - 1 && j == 0)
     for (int qq = L * RD * RD; qq < nhwc_stride; ++qq) out[((int64_t)n * P + p) * nhwc_stride + qq] = (half_t)0;
@@ -275,44 +282,12 @@ __global__ __launch_bounds__(256) void corr_pyramid_lookup_rows4_kernel(LevelPtr
     const int sh = ((int)fx - R) & 7;
     const float w11 = A::weight(dx * dy), w10 = A::weight(dx * (1.0f - dy));
     const float w01 = A::weight((1.0f - dx) * dy), w00 = A::weight((1.0f - dx) * (1.0f - dy));
-    unsigned d[8] = {lo[l][0], lo[l][1], lo[l][2], lo[l][3], hi[l][0], hi[l][1], hi[l][2], hi[l][3]};
-    const int q = sh >> 1;
-    unsigned a1[7], f[5];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) a1[k] = (q & 1) ? d[k + 1] : d[k];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) f[k] = (q & 2) ? a1[k + 2] : a1[k];
-    unsigned e[4], ne[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) e[k] = (sh & 1) ? __builtin_amdgcn_alignbyte(f[k + 1], f[k], 2) : f[k];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) ne[k] = __shfl_down(e[k], 1, 8);
-    float t[8], nb[8];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      half_t h0, h1v;
-      unsigned short u0 = (unsigned short)(e[k] & 0xffffu), u1 = (unsigned short)(e[k] >> 16);
-      __builtin_memcpy(&h0, &u0, 2);
-      __builtin_memcpy(&h1v, &u1, 2);
-      t[2 * k] = (float)h0;
-      t[2 * k + 1] = (float)h1v;
-      u0 = (unsigned short)(ne[k] & 0xffffu);
-      u1 = (unsigned short)(ne[k] >> 16);
-      __builtin_memcpy(&h0, &u0, 2);
-      __builtin_memcpy(&h1v, &u1, 2);
-      nb[2 * k] = (float)h0;
-      nb[2 * k + 1] = (float)h1v;
-    }
+    const unsigned d[8] = {lo[l][0], lo[l][1], lo[l][2], lo[l][3], hi[l][0], hi[l][1], hi[l][2], hi[l][3]};
+    half2v o[4];
+    row_outputs_pk(d, sh, w00, w01, w10, w11, o);
     if (j < RD) {
 #pragma unroll
-      for (int a = 0; a < RD; ++a) {
-        float acc = 0.0f;
-        acc = A::madd(acc, t[a], w00);       // tap (i=a,   j)
-        acc = A::madd(acc, nb[a], w01);      // tap (i=a,   j+1)
-        acc = A::madd(acc, t[a + 1], w10);   // tap (i=a+1, j)
-        acc = A::madd(acc, nb[a + 1], w11);  // tap (i=a+1, j+1)
-        stage[pl * LK4_PITCH + l * (RD * RD) + a * RD + j] = A::store(acc);
-      }
+      for (int a = 0; a < RD; ++a) stage[pl * LK4_PITCH + l * (RD * RD) + a * RD + j] = o[a >> 1][a & 1];
     }
   }
   if (j < 4) stage[pl * LK4_PITCH + L * RD * RD + j] = (half_t)0;
@@ -415,44 +390,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const int sh = ((int)fx - R) & 7;
       const float w11 = A::weight(dx * dy), w10 = A::weight(dx * (1.0f - dy));
       const float w01 = A::weight((1.0f - dx) * dy), w00 = A::weight((1.0f - dx) * (1.0f - dy));
-      unsigned d[8] = {lo[l][0], lo[l][1], lo[l][2], lo[l][3], hi[l][0], hi[l][1], hi[l][2], hi[l][3]};
-      const int q = sh >> 1;
-      unsigned a1[7], f[5];
-#pragma unroll
-      for (int k = 0; k < 7; ++k) a1[k] = (q & 1) ? d[k + 1] : d[k];
-#pragma unroll
-      for (int k = 0; k < 5; ++k) f[k] = (q & 2) ? a1[k + 2] : a1[k];
-      unsigned e[4], ne[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) e[k] = (sh & 1) ? __builtin_amdgcn_alignbyte(f[k + 1], f[k], 2) : f[k];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) ne[k] = __shfl_down(e[k], 1, 8);
-      float t[8], nb[8];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        half_t h0, h1v;
-        unsigned short u0 = (unsigned short)(e[k] & 0xffffu), u1 = (unsigned short)(e[k] >> 16);
-        __builtin_memcpy(&h0, &u0, 2);
-        __builtin_memcpy(&h1v, &u1, 2);
-        t[2 * k] = (float)h0;
-        t[2 * k + 1] = (float)h1v;
-        u0 = (unsigned short)(ne[k] & 0xffffu);
-        u1 = (unsigned short)(ne[k] >> 16);
-        __builtin_memcpy(&h0, &u0, 2);
-        __builtin_memcpy(&h1v, &u1, 2);
-        nb[2 * k] = (float)h0;
-        nb[2 * k + 1] = (float)h1v;
-      }
+      const unsigned d[8] = {lo[l][0], lo[l][1], lo[l][2], lo[l][3], hi[l][0], hi[l][1], hi[l][2], hi[l][3]};
+      half2v o[4];
+      row_outputs_pk(d, sh, w00, w01, w10, w11, o);
       if (j < RD) {
 #pragma unroll
-        for (int a = 0; a < RD; ++a) {
-          float acc = 0.0f;
-          acc = A::madd(acc, t[a], w00);
-          acc = A::madd(acc, nb[a], w01);
-          acc = A::madd(acc, t[a + 1], w10);
-          acc = A::madd(acc, nb[a + 1], w11);
-          stage[pl * LKC_PITCH + l * (RD * RD) + a * RD + j] = A::store(acc);
-        }
+        for (int a = 0; a < RD; ++a) stage[pl * LKC_PITCH + l * (RD * RD) + a * RD + j] = o[a >> 1][a & 1];
       }
     }
     __syncthreads();
