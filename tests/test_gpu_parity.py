@@ -233,6 +233,75 @@ def test_dense_ba_matches_reference_solver(name):
     assert np.abs(rp - g.poses).max() + np.abs(rd - g.disps).max() > 1e-3
 
 
+def _ba_rig_cases():
+    src = open(os.path.join(GOLD, "make_golden.py")).read()
+    ns = {}
+    exec(src[src.index("BA_RIG_CASES = {"):src.index("def gen_ba_rig")], ns)
+    return ns["BA_RIG_CASES"]
+
+
+BA_RIG_CASES = _ba_rig_cases()
+
+
+def run_hip_ba_rig(g, bk):
+    """multi-view rig through the C ABI exactly as GraphBuffer.bundle_adjustment calls it (flattened (n v) disparities)"""
+    from vipe_amd.ext import slam_ext
+    from vipe_amd.synth import expand_edges
+    pi, qi, di, pj, qj = expand_edges(g.ii, g.jj, g.V)
+    M = len(pi)
+    poses, intr, rig = T(g.poses).clone(), T(g.intrinsics).clone(), T(g.rig).clone()
+    disps = T(g.disps.reshape(g.n * g.V, g.ht, g.wd)).clone()
+    info = slam_ext.dense_ba(poses, disps, T(g.disps_sens.reshape(g.n * g.V, g.ht, g.wd)), intr, rig,
+                             T(g.target.reshape(M, -1, 2)), T(g.weight.reshape(M, -1, 2)),
+                             T(g.eta.reshape(g.n * g.V, g.ht, g.wd)), T(pi), T(qi), T(pj), T(qj), T(di), want_info=True, **bk)
+    torch.cuda.synchronize()
+    return (poses.cpu().numpy(), disps.cpu().numpy().reshape(g.n, g.V, g.ht, g.wd), intr.cpu().numpy(), rig.cpu().numpy(),
+            info.cpu().numpy())
+
+
+@pytest.mark.parametrize("name", sorted(BA_RIG_CASES))
+def test_dense_ba_rig_matches_reference_solver(name):
+    """Multi-view rigs in the fused BA (SURVEY 8 BA-diff "optional intrinsics / rig groups"): V = 2 and 3 views,
+    cross-view self edges, one intrinsics block per view, the rig-rotation group (view 0 fixed, rotation-only
+    retraction) - against the reference's own Solver (ba_rig_reference.npz) at the north_star tolerance, 1e-4 relative."""
+    from vipe_amd.synth import make_rig_graph
+    G = np.load(os.path.join(GOLD, "ba_rig_reference.npz"))
+    gk, bk = BA_RIG_CASES[name]
+    g = make_rig_graph(**gk)
+    p, d, k, r, info = run_hip_ba_rig(g, dict(bk))
+    rp, rd, rk, rr = (G[f"{name}/{x}"] for x in ("poses", "disps", "intrinsics", "rig"))
+    assert info[2] == 0, "Cholesky must not fail"
+    n_tail = (g.V * 1 if bk.get("optimize_intrinsics") else 0) + (6 * (g.V - 1) if bk.get("optimize_rig_rotation") else 0)
+    assert info[3] == 6 * info[0] + n_tail
+    assert np.abs(p - rp).max() <= 1e-4 * max(1.0, np.abs(rp).max()), np.abs(p - rp).max()
+    assert np.abs(d - rd).max() <= 1e-4 * np.abs(rd).max(), np.abs(d - rd).max() / np.abs(rd).max()
+    assert np.abs(k - rk).max() <= 1e-4 * np.abs(rk).max()
+    assert np.abs(r - rr).max() <= 1e-4, np.abs(r - rr).max()
+    assert np.array_equal(r[0], g.rig[0])
+    if not bk.get("optimize_rig_rotation"):
+        assert np.array_equal(r, g.rig)
+    if not bk.get("optimize_intrinsics"):
+        assert np.array_equal(k, g.intrinsics)
+    assert np.abs(rp - g.poses).max() + np.abs(rd - g.disps).max() > 1e-3
+
+
+def test_dense_ba_rig_at_bench_resolution_against_fp64_oracle():
+    """A 2-camera rig at the BASELINE grid (48x64, 6 keyframes, radius 2 + cross-view terms, rig rotation + per-view
+    intrinsics + sensor depth): fp32 HIP vs the fp64 oracle (itself pinned to the reference by the fixtures above)."""
+    from vipe_amd.synth import make_rig_graph
+    g = make_rig_graph(n=6, V=2, height=384, width=512, radius=2, seed=21, depth_prior=True)
+    bk = dict(t0=1, t1=6, n_iters=2, pose_damping=1e-5, pose_ep=1e-2, optimize_intrinsics=True, optimize_rig_rotation=True)
+    p, d, k, r, info = run_hip_ba_rig(g, bk)
+    M = g.target.shape[0]
+    op, od, ok_, orr = oba.bundle_adjustment(g.poses, g.disps, g.disps_sens, g.intrinsics, g.rig, g.target.reshape(M, -1, 2),
+                                             g.weight.reshape(M, -1, 2), g.eta, g.ii, g.jj, **bk)
+    assert info[2] == 0 and info[3] == 6 * 5 + 2 + 6
+    assert np.abs(p - op).max() <= 1e-4 * max(1.0, np.abs(op).max())
+    assert np.abs(d - od).max() <= 1e-4 * np.abs(od).max()
+    assert np.abs(k - ok_).max() <= 1e-4 * np.abs(ok_).max()
+    assert np.abs(r - orr).max() <= 1e-4
+
+
 def test_dense_ba_bench_size_against_fp64_oracle():
     """N=12, 48x64 grid (the BASELINE resolution), E=66: HIP fp32 vs the fp64 oracle."""
     g = make_graph(n=12, height=384, width=512, radius=3, seed=1234)
@@ -667,6 +736,70 @@ def test_factor_graph_update_full_size_with_sensor_depth():
     slam_ext.dense_ba(pz, dz, torch.zeros_like(dz), T(g.intrinsics), T(rig), T(tg.reshape(E, -1, 2)),
                       T(wg.reshape(E, -1, 2)), T(damping), T(g.ii), T(zz), T(g.jj), T(zz), T(g.ii), 1, n, 3, 1e-3, 0.1)
     assert np.abs(dz.cpu().numpy() - d1).max() > 10 * 1e-4 * np.abs(od).max()
+
+
+def test_factor_graph_on_a_two_camera_rig():
+    """V = 2 through the host classes (GraphBuffer n_views = 2, FactorGraph cross_view): edge expansion incl. the
+    cross-view self edges (buffer.py:318-361), per-(frame, view) hidden state / correlation / damping indexing, one
+    `update` (frontend flags: rig and intrinsics fixed) whose BA equals the fp64 oracle fed the device's own targets /
+    weights / damping, then `update_batch` with the rig-rotation and intrinsics groups switched on (backend flags)."""
+    from vipe_amd.slam.buffer import GraphBuffer
+    from vipe_amd.slam.factor_graph import FactorGraph
+    from vipe_amd.slam.networks import UpdateModule
+    from vipe_amd.synth import expand_edges, make_rig_graph
+    g = make_rig_graph(n=4, V=2, height=128, width=128, radius=2, seed=33)
+    n, V = g.n, g.V
+    buf = GraphBuffer(128, 128, n_views=V, buffer_size=6, device=dev())
+    buf.n_frames = n
+    buf.poses[:n] = T(g.poses)
+    buf.disps[:n] = T(g.disps)
+    buf.intrinsics[:] = T(g.intrinsics)
+    buf.rig[:] = T(g.rig)
+    gen = torch.Generator().manual_seed(5)
+    buf.fmaps[:n] = torch.randn(n, V, 128, 16, 16, generator=gen).half().to(dev())
+    buf.nets[:n] = torch.randn(n, V, 128, 16, 16, generator=gen).tanh().half().to(dev())
+    buf.inps[:n] = torch.randn(n, V, 128, 16, 16, generator=gen).relu().half().to(dev())
+    torch.manual_seed(0)
+    graph = FactorGraph(UpdateModule().eval(), buf, dev(), max_factors=-1, cross_view=True)
+    graph.add_factors(torch.from_numpy(g.ii), torch.from_numpy(g.jj))
+    pi, qi, di, pj, qj = expand_edges(g.ii, g.jj, V)
+    M = len(pi)
+    P_ = graph._edge_plan()
+    for name, want in (("pi", pi), ("qi", qi), ("di", di), ("pj", pj), ("qj", qj)):
+        assert np.array_equal(P_[name].cpu().numpy(), want), name
+    assert graph.net_n.shape[0] == M and graph.target.shape[1] == M and len(graph.corr) == M
+    # hidden state of term (edge e, view v) = nets[pi, qi]
+    assert torch.equal(graph.net_n[5].permute(2, 0, 1), buf.nets[int(pi[5]), int(qi[5])])
+    graph.target = T(g.target)[None].contiguous()
+    graph.weight = T(g.weight)[None].contiguous()
+    poses0, disps0 = buf.poses[:n].cpu().numpy().copy(), buf.disps[:n].cpu().numpy().copy()
+    graph.update(t0=1, t1=n, itrs=2)
+    torch.cuda.synchronize()
+    tg, wg = graph.target[0].cpu().numpy(), graph.weight[0].cpu().numpy()
+    damping = graph.damping.view(-1, V, 16, 16)[:n].cpu().numpy()
+    kw = dict(t0=1, t1=n, n_iters=2, pose_damping=1e-3, pose_ep=0.1)
+    op, od, ok_, orr = oba.bundle_adjustment(poses0, disps0, g.disps_sens, g.intrinsics, g.rig, tg.reshape(M, -1, 2),
+                                             wg.reshape(M, -1, 2), damping, g.ii, g.jj, **kw)
+    assert np.abs(buf.poses[:n].cpu().numpy() - op).max() <= 1e-4 * max(1.0, np.abs(op).max())
+    assert np.abs(buf.disps[:n].cpu().numpy() - od).max() <= 1e-4 * np.abs(od).max()
+    assert np.array_equal(buf.rig.cpu().numpy(), g.rig) and np.array_equal(buf.intrinsics.cpu().numpy(), g.intrinsics)
+    # backend pass: rig rotation + per-view intrinsics
+    p1, d1 = buf.poses[:n].cpu().numpy().copy(), buf.disps[:n].cpu().numpy().copy()
+    graph.update_batch(itrs=3, steps=1, optimize_intrinsics=True, optimize_rig_rotation=True)
+    torch.cuda.synchronize()
+    tg, wg = graph.target[0].cpu().numpy(), graph.weight[0].cpu().numpy()
+    damping = graph.damping.view(-1, V, 16, 16)[:n].cpu().numpy()
+    kw = dict(t0=1, t1=n, n_iters=3, pose_damping=1e-5, pose_ep=1e-2, optimize_intrinsics=True, optimize_rig_rotation=True)
+    op, od, ok_, orr = oba.bundle_adjustment(p1, d1, g.disps_sens, g.intrinsics, g.rig, tg.reshape(M, -1, 2),
+                                             wg.reshape(M, -1, 2), damping, g.ii, g.jj, **kw)
+    assert np.abs(buf.poses[:n].cpu().numpy() - op).max() <= 1e-4 * max(1.0, np.abs(op).max())
+    assert np.abs(buf.disps[:n].cpu().numpy() - od).max() <= 1e-4 * np.abs(od).max()
+    assert np.abs(buf.rig.cpu().numpy() - orr).max() <= 1e-4 and np.abs(buf.rig[1, 3:].cpu().numpy() - g.rig[1, 3:]).max() > 1e-6
+    assert np.abs(buf.intrinsics.cpu().numpy() - ok_).max() <= 1e-4 * np.abs(ok_).max()
+    e0 = oba.energy(p1, d1, g.intrinsics, g.rig, tg, wg, g.ii, g.jj)
+    e1 = oba.energy(buf.poses[:n].cpu().numpy(), buf.disps[:n].cpu().numpy(), buf.intrinsics.cpu().numpy(),
+                    buf.rig.cpu().numpy(), tg, wg, g.ii, g.jj)
+    assert e1 < e0
 
 
 def test_factor_graph_update_batch_runs_and_reduces_energy():

@@ -42,6 +42,7 @@ struct BAWs {
   float* wv;        // [nF,P]
   float* Ekk;       // [nF,6,P]
   float* Ef;        // [nF,2,P]
+  float* Et;        // [nF,ntail,P] multi-view rigs: rows of the tail unknowns (per-view intrinsics, rig rotations)
   float* Ej;        // [M,6,P]
   double* S;        // [(nmax+1),(nmax+1)] lower triangle + rhs row
   double* Hd;       // [nmax] undamped diagonal of H (for lambda * diag)
@@ -57,6 +58,10 @@ struct BAArgs {
   const int64_t *pi, *qi, *pj, *qj, *di;
   BAWs w;
   int P, nF, D;
+  // multi-view rigs (n_views > 1): the tail of the reduced system holds one intrinsics block
+  // per view (nintr = V (1 + D) unknowns when optimize_intrinsics) and one rotation block per view >= 1 (6 (V - 1) when
+  // optimize_rig_rotation; view 0 is the gauge, buffer.py:506); ntail = both.  Mono: the F <= 2 shared intrinsics.
+  int mv, nintr, ntail;
   int force_simple;  // VIPE_BA_ACCUM_SIMPLE: shuffle-reduction accumulate kernel for every graph (A/B, debugging)
   // DROID semantics of slam_ext.ba (geom_kernels.cu:178-432, 1273-1404; see oracle/droid_ba.py for the list):
   // target / weight [M,2,P], eta [K,P] by krow, per-pixel depth prior, reduced-diagonal damping, poses free iff in
@@ -67,9 +72,18 @@ struct BAArgs {
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+constexpr int RG_VMAX = 4;  // views of a rig the multi-view kernels handle
+inline bool is_multiview(const vipe_ba_params& p) { return p.n_views > 1; }  // a mono rig has no rig unknowns (view 0 is the gauge)
+inline int tail_intr(const vipe_ba_params& p) {
+  const int F = 1 + (p.camera == VIPE_CAM_MEI ? 1 : 0);
+  return p.optimize_intrinsics ? (is_multiview(p) ? p.n_views * F : F) : 0;
+}
+inline int tail_rig(const vipe_ba_params& p) { return p.optimize_rig_rotation ? 6 * (p.n_views - 1) : 0; }
+
 size_t carve(const vipe_ba_params& p, char* base, BAWs* out) {
   const size_t nP = p.n_poses, nF = (size_t)p.n_poses * p.n_views, P = (size_t)p.ht * p.wd, M = p.M;
-  const size_t nmax = 6 * nP + 2;
+  const size_t ntail_max = is_multiview(p) ? (size_t)p.n_views * 2 + 6 * (size_t)(p.n_views - 1) : 2;
+  const size_t nmax = 6 * nP + ntail_max;
   size_t off = 0;
   auto take = [&](size_t bytes) {
     char* ptr = base ? base + off : nullptr;
@@ -89,6 +103,7 @@ size_t carve(const vipe_ba_params& p, char* base, BAWs* out) {
   w.wv = (float*)take(4 * nF * P);
   w.Ekk = (float*)take(4 * nF * 6 * P);
   w.Ef = (float*)take(4 * nF * 2 * P);
+  w.Et = (float*)take(is_multiview(p) ? 4 * nF * ntail_max * P : 0);
   w.Ej = (float*)take(4 * (M + 1) * 6 * P);
   w.S = (double*)take(8 * (nmax + 1) * (nmax + 1));
   w.Hd = (double*)take(8 * (nmax + 16));  // + 16 debug stamp slots
@@ -211,11 +226,10 @@ __global__ __launch_bounds__(1024) void ba_plan_kernel(BAArgs a) {
     __syncthreads();
   }
   if (t == 0) {
-    const int F = p.optimize_intrinsics ? 1 + a.D : 0;
     a.w.info[0] = n_free;
     a.w.info[1] = lds[0];
     a.w.info[2] = 0;
-    a.w.info[3] = 6 * n_free + F;
+    a.w.info[3] = 6 * n_free + a.ntail;
     a.w.info[4] = 0;  // band width of the reduced pose system in 6x6 blocks (filled below)
     a.w.info[6] = 0;  // largest number of terms of one source frame (selects the accumulate kernel)
   }
@@ -1338,6 +1352,282 @@ __global__ __launch_bounds__(TILE) void ba_walk_kernel(BAArgs a) {
   }
 }
 
+// ---- multi-view rigs (n_views > 1, optionally the rig-rotation group): the general walk with per-term LOCAL variable
+// blocks.  Every Jacobian of a term is a linear image of 6 + 2F "base" rows the walk forms per pixel:
+//     base = [Jj (6: d r / d pose_j), JfA (F: intrinsics of the source view qi, plus the target's when qj == qi),
+//             JfB (F: intrinsics of the target view qj when qj != qi)]
+//     pose_i = Mi0 Jj   (Mi0 = -Adj(G_ij)^T, geom.py:277)      pose_j = Jj
+//     rig_qi = -pose_i, rig_qj = -pose_j (geom.py:292-294)       intr_qi = JfA, intr_qj = JfB (terms.py:224-227)
+// so ONE Gram matrix of [base; r] per term (matrix cores, as in ba_walk_kernel) gives every block of J^T W J through a
+// small map Lm [28 local columns x 10 base rows] and a table gcol[28] of reduced-system columns (-1: fixed).  Local
+// columns that land on the same unknown (cross-view self edges: pose_i = pose_j; qi == qj: one rig block) are summed by
+// adding ALL ordered pairs (a, b) with gcol[a] >= gcol[b] - exactly (Ja + Jb)^T W (Ja + Jb), what the reference's block
+// coalescing produces (matrix.py:124-177).  The E rows of the tail unknowns are accumulated per pixel in registers and
+// left in the workspace (Et) for ba_schur_kernel / ba_retract_kernel.
+constexpr int RG_NB = 10;  // base rows: Jj 0..5, JfA 6..7, JfB 8..9  (Gram tile rows 0..5, 7..8, 9..10; tile row 6 = r)
+constexpr int RG_NL = 28;  // local columns: pose_i 0..5, pose_j 6..11, intr A 12..13, intr B 14..15, rig A 16..21, rig B 22..27
+struct TermGeomR {
+  TermGeom g;
+  int qj, same_view;
+  int gcol[RG_NL];
+  float Lm[RG_NL][RG_NB];
+};
+constexpr size_t walk_rig_lds() {
+  return sizeof(float) * (NWAVE * 16 * AM_P1 + WK_CH * 256) + WK_CH * sizeof(TermGeomR);
+}
+__device__ __forceinline__ int rg_tile_row(int b) { return b < 6 ? b : b + 1; }
+
+template <int CAM>
+__global__ __launch_bounds__(TILE) void ba_walk_rig_kernel(BAArgs a) {
+  constexpr int WBUF = 16 * AM_P1;
+  constexpr int F = CAM == VIPE_CAM_MEI ? 2 : 1;
+  const vipe_ba_params& prm = a.p;
+  const BAWs& w = a.w;
+  const int k = blockIdx.y;
+  const int beg = w.rowptr[k], end = w.rowptr[k + 1];
+  if (beg == end) return;
+  const int deg_all = end - beg;
+  const int P = a.P, V = prm.n_views, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p_raw = blockIdx.x * TILE + tid;
+  const bool inb = p_raw < P;
+  const int p = inb ? p_raw : P - 1;
+  const int flags = w.fflags[k];
+  const bool dfree = flags & 2;
+  const int pose_i = k / V, qi = k % V;
+  const int si = w.pose_slot[pose_i];
+  const int n_free = w.info[0], nrow = w.info[3];
+  const int foff = 6 * n_free, roff = foff + a.nintr;
+  const bool oi = prm.optimize_intrinsics, orr = prm.optimize_rig_rotation;
+
+  extern __shared__ __align__(16) float am_smem[];
+  float* wbuf = am_smem + wave * WBUF;   // wave-private R1 tile; reused as scratch by the flush
+  float* acc1 = am_smem + NWAVE * WBUF;  // [WK_CH][16][16] per-term Gram accumulators of the current chunk
+  TermGeomR* tg = reinterpret_cast<TermGeomR*>(acc1 + WK_CH * 256);
+
+  const cam::Intr Ii = cam::load_scaled(a.intr + qi * (4 + a.D), a.D, 1.0f / prm.intr_factor);
+  const float u = (float)(p % prm.wd), v = (float)(p / prm.wd);
+  const float d = a.disps[(int64_t)k * P + p];
+  float X0, Y0, dX0[F], dY0[F];
+  cam::iproj<CAM, F>(Ii, u, v, X0, Y0, dX0, dY0);
+  float C = 0.f, wz = 0.f, Ei[6] = {0, 0, 0, 0, 0, 0};
+  float EfA[F] = {}, ErA[6] = {0, 0, 0, 0, 0, 0};      // tail rows of the source view qi
+  float Efv[RG_VMAX][F] = {}, Erv[RG_VMAX][6] = {};    // ... of the target views (selected by predicate)
+  const int l16 = lane & 15, kq = lane >> 4;
+
+  for (int cb = 0; cb < deg_all; cb += WK_CH) {
+    const int deg = min(WK_CH, deg_all - cb);
+    __syncthreads();  // the previous chunk's flush is done with acc1 / tg
+    for (int i = tid; i < WK_CH * 256; i += TILE) acc1[i] = 0.0f;
+    if (tid < deg) {
+      TermGeomR& m = tg[tid];
+      const int e = w.order[beg + cb + tid];
+      const int pi = (int)a.pi[e], pj = (int)a.pj[e], qj = (int)a.qj[e];
+      term_transforms(a.poses, a.rig, pi, qi, pj, qj, m.g.T, m.g.G, m.g.Rr);
+      m.g.Ij = cam::load_scaled(a.intr + qj * (4 + a.D), a.D, 1.0f / prm.intr_factor);
+      m.g.e = e;
+      m.g.merge = (pi == pj);
+      m.g.rig_adj = !(m.g.Rr.t[0] == 0.f && m.g.Rr.t[1] == 0.f && m.g.Rr.t[2] == 0.f && m.g.Rr.R[0] == 1.f &&
+                      m.g.Rr.R[4] == 1.f && m.g.Rr.R[8] == 1.f);
+      m.g.sj = m.g.merge ? -1 : w.pose_slot[pj];  // E_j row of the Schur stack: absent when merged into pose i
+      m.qj = qj;
+      m.same_view = (qj == qi);
+      const int sjj = w.pose_slot[pj];
+      for (int c = 0; c < RG_NL; ++c)
+        for (int b = 0; b < RG_NB; ++b) m.Lm[c][b] = 0.0f;
+      for (int c = 0; c < 6; ++c) {
+        float ec[6] = {0, 0, 0, 0, 0, 0}, col[6];
+        ec[c] = 1.0f;
+        adjT_apply(m.g.G, ec, col);
+        for (int r = 0; r < 6; ++r) {
+          m.Lm[r][c] = -col[r];       // pose_i = Mi0 Jj
+          m.Lm[16 + r][c] = col[r];   // rig of view qi = -pose_i
+        }
+        m.Lm[6 + c][c] = 1.0f;        // pose_j
+        m.Lm[22 + c][c] = -1.0f;      // rig of view qj = -pose_j
+      }
+      for (int f = 0; f < 2; ++f) {
+        m.Lm[12 + f][6 + f] = 1.0f;
+        m.Lm[14 + f][8 + f] = 1.0f;
+      }
+      for (int q = 0; q < 6; ++q) {
+        m.gcol[q] = si >= 0 ? 6 * si + q : -1;
+        m.gcol[6 + q] = sjj >= 0 ? 6 * sjj + q : -1;
+        m.gcol[16 + q] = (orr && qi >= 1) ? roff + 6 * (qi - 1) + q : -1;
+        m.gcol[22 + q] = (orr && qj >= 1) ? roff + 6 * (qj - 1) + q : -1;
+      }
+      for (int f = 0; f < 2; ++f) {
+        m.gcol[12 + f] = (oi && f < F) ? foff + qi * F + f : -1;
+        m.gcol[14 + f] = (oi && f < F && qj != qi) ? foff + qj * F + f : -1;
+      }
+    }
+    __syncthreads();
+
+    for (int t = 0; t < deg; ++t) {
+      const TermGeom& G = tg[t].g;
+      const int e = G.e, qj = tg[t].qj;
+      const bool same = tg[t].same_view;
+      const float X = G.T.R[0] * X0 + G.T.R[1] * Y0 + G.T.R[2] + G.T.t[0] * d;
+      const float Y = G.T.R[3] * X0 + G.T.R[4] * Y0 + G.T.R[5] + G.T.t[1] * d;
+      const float Z = G.T.R[6] * X0 + G.T.R[7] * Y0 + G.T.R[8] + G.T.t[2] * d;
+      float x, y, Jp[2][3], Jfj[2][F];
+      cam::proj<CAM, true, F>(G.Ij, X, Y, Z, x, y, Jp, Jfj);
+      float2 tgt, wg;
+      load_tw(a, e, p, P, tgt, wg);
+      const float val = valid_weight(a, Z, inb);  // geom.py:263, buffer.py:413
+      const float wc[2] = {val * wg.x, val * wg.y};
+      const float rc[2] = {x - tgt.x, y - tgt.y};
+      float Ja[3][6] = {{d, 0, 0, 0, Z, -Y}, {0, d, 0, -Z, 0, X}, {0, 0, d, Y, -X, 0}};
+      if (G.rig_adj) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          float tmp[6];
+          adjT_apply(G.Rr, Ja[r], tmp);
+#pragma unroll
+          for (int q = 0; q < 6; ++q) Ja[r][q] = tmp[q];
+        }
+      }
+      float Ejv[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float Jj[6], JfA[F], JfB[F];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Jj[q] = Jp[c][0] * Ja[0][q] + Jp[c][1] * Ja[1][q] + Jp[c][2] * Ja[2][q];
+        const float Jz = Jp[c][0] * G.T.t[0] + Jp[c][1] * G.T.t[1] + Jp[c][2] * G.T.t[2];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          // Jfi = Jp . (R_T dX0/df) (geom.py:286-288), Jfj from the target camera; J_scale 1/8 (terms.py:224-227)
+          const float ax = G.T.R[0] * dX0[f] + G.T.R[1] * dY0[f];
+          const float ay = G.T.R[3] * dX0[f] + G.T.R[4] * dY0[f];
+          const float az = G.T.R[6] * dX0[f] + G.T.R[7] * dY0[f];
+          const float ji = (Jp[c][0] * ax + Jp[c][1] * ay + Jp[c][2] * az) * (1.0f / prm.intr_factor);
+          const float jj = Jfj[c][f] * (1.0f / prm.intr_factor);
+          JfA[f] = same ? ji + jj : ji;
+          JfB[f] = same ? 0.0f : jj;
+        }
+        const float sw = __builtin_amdgcn_sqrtf(wc[c]);
+        float* col = wbuf + c * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) col[q * AM_P1] = Jj[q] * sw;
+        col[6 * AM_P1] = rc[c] * sw;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          col[(7 + f) * AM_P1] = f < F ? JfA[f < F ? f : 0] * sw : 0.0f;
+          col[(9 + f) * AM_P1] = f < F ? JfB[f < F ? f : 0] * sw : 0.0f;
+        }
+#pragma unroll
+        for (int r = 11; r < 16; ++r) col[r * AM_P1] = 0.0f;
+        if (dfree) {
+          const float wJz = wc[c] * Jz;
+          C += wc[c] * Jz * Jz;
+          wz -= wc[c] * Jz * rc[c];
+          float tmp[6];
+          adjT_apply(G.G, Jj, tmp);  // pose_i Jacobian before merging: -tmp
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            Ei[q] += ((G.merge ? Jj[q] : 0.0f) - tmp[q]) * wJz;
+            ErA[q] += tmp[q] * wJz;          // rig of view qi: -(pose_i Jacobian)
+            Ejv[q] += Jj[q] * wJz;
+          }
+#pragma unroll
+          for (int f = 0; f < F; ++f) EfA[f] += JfA[f] * wJz;
+#pragma unroll
+          for (int vv = 0; vv < RG_VMAX; ++vv) {
+            if (vv == qj) {
+#pragma unroll
+              for (int f = 0; f < F; ++f) Efv[vv][f] += JfB[f] * wJz;
+#pragma unroll
+              for (int q = 0; q < 6; ++q) Erv[vv][q] -= Jj[q] * wJz;  // rig of view qj: -(pose_j Jacobian)
+            }
+          }
+        }
+      }
+      if (dfree && G.sj >= 0 && inb) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) w.Ej[((int64_t)e * 6 + q) * P + p] = Ejv[q];
+      }
+      // ---- Gram matrix of [base; r] over this wave's 64 pixels x 2 components
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      float4m g4 = {0.f, 0.f, 0.f, 0.f};
+      const float* arow = wbuf + l16 * AM_P1 + kq;
+#pragma unroll 8
+      for (int s2 = 0; s2 < 32; ++s2) {
+        const float av = arow[4 * s2];
+        g4 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, av, g4, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&acc1[t * 256 + (4 * kq + r) * 16 + l16], g4[r]);
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    __syncthreads();
+    // ---- per-term blocks from the Gram sums (one wave per term): T1 = Lm Gb, H = T1 Lm^T, v = -Lm g
+    for (int t = wave; t < deg; t += NWAVE) {
+      const TermGeomR& TG = tg[t];
+      const float* Gm = acc1 + t * 256;
+      float* T1 = wbuf;  // [RG_NL][RG_NB]
+      for (int i = lane; i < RG_NL * RG_NB; i += 64) {
+        const int c = i / RG_NB, b = i % RG_NB;
+        float acc = 0.f;
+#pragma unroll
+        for (int b2 = 0; b2 < RG_NB; ++b2) acc += TG.Lm[c][b2] * Gm[rg_tile_row(b2) * 16 + rg_tile_row(b)];
+        T1[i] = acc;
+      }
+      if (lane < RG_NL && TG.gcol[lane] >= 0) {
+        float acc = 0.f;
+#pragma unroll
+        for (int b2 = 0; b2 < RG_NB; ++b2) acc += TG.Lm[lane][b2] * Gm[rg_tile_row(b2) * 16 + 6];
+        atomicAdd(&w.S[(int64_t)nrow * w.ld + TG.gcol[lane]], -(double)acc);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int i = lane; i < RG_NL * RG_NL; i += 64) {
+        const int ca = i / RG_NL, cb2 = i % RG_NL;
+        const int ga = TG.gcol[ca], gb = TG.gcol[cb2];
+        if (ga < 0 || gb < 0 || ga < gb) continue;
+        float acc = 0.f;
+#pragma unroll
+        for (int b = 0; b < RG_NB; ++b) acc += T1[ca * RG_NB + b] * TG.Lm[cb2][b];
+        atomicAdd(&w.S[(int64_t)ga * w.ld + gb], (double)acc);
+        if (ga == gb) atomicAdd(&w.Hd[ga], (double)acc);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+
+  // ---- finish the disparity block of this pixel and leave the E rows for the Schur / back-substitution kernels
+  if (dfree) {
+    const int64_t kp = (int64_t)k * P + p;
+    finish_disp(a, k, p, P, flags, d, C, wz);
+    if (inb) {
+      w.C[kp] = C;
+      w.wv[kp] = wz;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) w.Ekk[((int64_t)k * 6 + q) * P + p] = Ei[q];
+      float* et = w.Et + (int64_t)k * a.ntail * P + p;
+      if (oi) {
+#pragma unroll
+        for (int vv = 0; vv < RG_VMAX; ++vv) {
+          if (vv < V) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) et[(int64_t)(vv * F + f) * P] = Efv[vv][f] + (vv == qi ? EfA[f] : 0.0f);
+          }
+        }
+      }
+      if (orr) {
+#pragma unroll
+        for (int vv = 1; vv < RG_VMAX; ++vv) {
+          if (vv < V) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+              et[(int64_t)(a.nintr + 6 * (vv - 1) + q) * P] = Erv[vv][q] + (vv == qi ? ErA[q] : 0.0f);
+          }
+        }
+      }
+    }
+  }
+}
+
 // Schur complement of one source frame from the E rows in the workspace (general path, after ba_walk_kernel):
 // rows = sqrt(Q) * [E_kk (pose i); E_j of every term; E_f; w], Gram over all P pixels, one workgroup per 16 x 16 tile
 // pair of the lower triangle.  Each wave takes every fourth 64-pixel chunk: the two row tiles are staged in LDS
@@ -1347,13 +1637,14 @@ constexpr int SC_GRID = 96;  // tile pairs processed in parallel per frame (the 
 template <int F>
 __global__ __launch_bounds__(TILE) void ba_schur_kernel(BAArgs a) {
   const BAWs& w = a.w;
-  if (a.force_simple == 1 || (a.force_simple == 0 && w.info[6] <= AM_DMAX)) return;
+  if (!a.mv && (a.force_simple == 1 || (a.force_simple == 0 && w.info[6] <= AM_DMAX))) return;
   const int k = blockIdx.y;
   const int flags = w.fflags[k];
   const int beg = w.rowptr[k], end = w.rowptr[k + 1];
   if (!(flags & 2) || beg == end) return;
   const int deg = end - beg, P = a.P, V = a.p.n_views;
-  const int NR = 6 * (deg + 1) + F + 1, RT = (NR + 15) >> 4, npairs = RT * (RT + 1) / 2;
+  const int NT = a.mv ? a.ntail : F;  // tail rows: per-view intrinsics + rig rotations (Et), or the shared intrinsics (Ef)
+  const int NR = 6 * (deg + 1) + NT + 1, RT = (NR + 15) >> 4, npairs = RT * (RT + 1) / 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
   const int si = w.pose_slot[k / V];
   const int n_free = w.info[0], nrow = w.info[3], foff = 6 * n_free;
@@ -1367,7 +1658,12 @@ __global__ __launch_bounds__(TILE) void ba_schur_kernel(BAArgs a) {
     ptr = nullptr; g = -1;
     if (r >= NR) return;
     if (r == NR - 1) { ptr = w.wv + (int64_t)k * P; g = -2; return; }
-    if (r >= 6 * (deg + 1)) { const int f = r - 6 * (deg + 1); ptr = w.Ef + ((int64_t)k * 2 + f) * P; g = foff + f; return; }
+    if (r >= 6 * (deg + 1)) {
+      const int f = r - 6 * (deg + 1);
+      ptr = a.mv ? w.Et + ((int64_t)k * NT + f) * P : w.Ef + ((int64_t)k * 2 + f) * P;
+      g = foff + f;
+      return;
+    }
     const int m = r / 6, q = r % 6;
     if (m == 0) {
       if (si >= 0) { ptr = w.Ekk + ((int64_t)k * 6 + q) * P; g = 6 * si + q; }
@@ -1467,7 +1763,23 @@ __device__ __forceinline__ void apply_retraction(const BAArgs& a, int t, int nth
     lie::SE3<float> X(a.poses + 7 * pidx);
     (lie::SE3<float>::exp(xi) * X).store(a.poses + 7 * pidx);
   }
-  if (a.p.optimize_intrinsics && t == 0) {
+  if (a.mv) {
+    // one intrinsics block per view (retractor.py:50-62 with len(dx) == V) and one rotation-only step per view >= 1
+    // (retractor.py:32-37: the translation part of the tangent is zeroed, X <- Exp([0, phi]) X)
+    const int F = 1 + a.D, V = a.p.n_views;
+    if (a.p.optimize_intrinsics && t < V) {
+      float* I = a.intr + t * (4 + a.D);
+      const float df = w.dx[6 * n_free + t * F];
+      I[0] += df; I[1] += df;
+      if (F > 1) I[4] += 0.01f * w.dx[6 * n_free + t * F + 1];
+    }
+    if (a.p.optimize_rig_rotation && t >= 1 && t < V) {
+      float xi[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int q = 3; q < 6; ++q) xi[q] = w.dx[6 * n_free + a.nintr + 6 * (t - 1) + q];
+      lie::SE3<float> X(a.rig + 7 * t);
+      (lie::SE3<float>::exp(xi) * X).store(a.rig + 7 * t);
+    }
+  } else if (a.p.optimize_intrinsics && t == 0) {
     const int F = 1 + a.D;
     const float df = w.dx[6 * n_free];
     for (int vq = 0; vq < a.p.n_views; ++vq) {
@@ -1858,8 +2170,10 @@ __global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_c
   if (n == 0 || w.info[5] == 1) return;
   // LM damping on the diagonal: += ep + lambda * diag(H)  (matrix.py:179-186)
   for (int dd = t; dd < n; dd += SOLVE_T) {
-    const bool pose = dd < 6 * n_free;
-    const double ep = pose ? (double)prm.pose_ep : 1e-6, lam = pose ? (double)prm.pose_damping : 1e-6;
+    // poses: the caller's (lambda, ep); intrinsics 1e-6 / 1e-6; rig rotations 1e-4 / 1e-4 (buffer.py:466,498,503)
+    const bool pose = dd < 6 * n_free, rigrow = a.mv && dd >= 6 * n_free + a.nintr;
+    const double ep = pose ? (double)prm.pose_ep : (rigrow ? 1e-4 : 1e-6);
+    const double lam = pose ? (double)prm.pose_damping : (rigrow ? 1e-4 : 1e-6);
     S[(int64_t)dd * ld + dd] += ep + lam * (a.droid ? S[(int64_t)dd * ld + dd] : w.Hd[dd]);
   }
   __syncthreads();
@@ -2143,6 +2457,9 @@ __global__ __launch_bounds__(TILE) void ba_retract_kernel(BAArgs a) {
 #pragma unroll
     for (int f = 0; f < F; ++f) rhs -= w.Ef[((int64_t)k * 2 + f) * P + p] * w.dx[6 * n_free + f];
   }
+  if (a.mv) {
+    for (int f = 0; f < a.ntail; ++f) rhs -= w.Et[((int64_t)k * a.ntail + f) * P + p] * w.dx[6 * n_free + f];
+  }
   float dz = rhs / w.C[kp];
   if (!a.droid && dz > 10.0f) dz = 0.0f;  // retractor.py:41
   a.disps[kp] += dz;
@@ -2172,6 +2489,7 @@ int run_iters(const BAArgs& a, hipStream_t s) {
   }
   (void)hipFuncSetAttribute((const void*)ba_accum_mfma_kernel<CAM, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_mfma_lds());
   (void)hipFuncSetAttribute((const void*)ba_walk_kernel<CAM, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds());
+  (void)hipFuncSetAttribute((const void*)ba_walk_rig_kernel<CAM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_rig_lds());
   // S / Hd start each accumulation zeroed: by ba_retract_kernel of the previous iteration when it runs (not motion_only),
   // also across calls when the caller vouches for the workspace (reuse_plan: same key, hence the same motion_only), else
   // by memsets
@@ -2181,6 +2499,14 @@ int run_iters(const BAArgs& a, hipStream_t s) {
       hipError_t e1 = hipMemsetAsync(a.w.S, 0, sbytes, s);
       hipError_t e2 = hipMemsetAsync(a.w.Hd, 0, sizeof(double) * nmax, s);
       if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
+    }
+    if (a.mv) {
+      // multi-view rigs: local-block walk, Schur Gram over the stacked E rows, global-memory Cholesky with the dense tail
+      ba_walk_rig_kernel<CAM><<<dim3(tiles, a.nF), TILE, walk_rig_lds(), s>>>(a);
+      ba_schur_kernel<0><<<dim3(SC_GRID, a.nF), TILE, 0, s>>>(a);
+      ba_solve_kernel<<<1, SOLVE_T, solve_lds, s>>>(a, panel_cap, nullptr);
+      if (!a.p.motion_only) ba_retract_kernel<0><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
+      continue;
     }
     // path_hint (vipe_ba_params): what the caller learnt from an earlier call with this plan; 0 launches everything
     const int hint = a.force_simple ? 0 : a.p.path_hint;
@@ -2221,8 +2547,7 @@ VIPE_EXPORT int vipe_dense_ba(const vipe_ba_params* p, float* d_poses, float* d_
   VIPE_CHECK_ARG(p->t0 <= p->t1 && p->intr_factor > 0);
   VIPE_CHECK_ARG(p->camera == VIPE_CAM_PINHOLE || p->camera == VIPE_CAM_MEI);
   VIPE_CHECK_ARG(p->M == 0 || (d_target && d_weight && d_pi && d_qi && d_pj && d_qj && d_di));
-  if (p->optimize_rig_rotation) return VIPE_EUNSUPPORTED;            // multi-view rigs only; not built yet
-  if (p->optimize_intrinsics && p->n_views != 1) return VIPE_EUNSUPPORTED;
+  if (is_multiview(*p) && p->n_views > RG_VMAX) return VIPE_EUNSUPPORTED;  // rigs of up to 4 cameras
   if ((int64_t)p->n_poses * p->n_views > 65535) return VIPE_EINVAL;
   BAArgs a;
   a.p = *p;
@@ -2233,6 +2558,9 @@ VIPE_EXPORT int vipe_dense_ba(const vipe_ba_params* p, float* d_poses, float* d_
   a.P = p->ht * p->wd;
   a.nF = p->n_poses * p->n_views;
   a.D = p->camera == VIPE_CAM_MEI ? 1 : 0;
+  a.mv = is_multiview(*p) ? 1 : 0;
+  a.nintr = tail_intr(*p);
+  a.ntail = a.nintr + tail_rig(*p);
   a.force_simple = getenv("VIPE_BA_ACCUM_SIMPLE") ? 1 : (getenv("VIPE_BA_ACCUM_GENERAL") ? 2 : 0);
   a.droid = 0;
   a.dz_out = nullptr;
@@ -2305,6 +2633,7 @@ VIPE_EXPORT int vipe_ba(float* d_poses, float* d_disps, const float* d_intrinsic
   a.sens = d_disps_sens; a.target = d_targets; a.weight = d_weights; a.eta = d_eta;
   a.pi = d_ii; a.qi = zeros; a.pj = d_jj; a.qj = zeros; a.di = d_ii;
   a.P = ht * wd; a.nF = n_poses; a.D = 0;
+  a.mv = 0; a.nintr = 0; a.ntail = 0;
   a.force_simple = getenv("VIPE_BA_ACCUM_SIMPLE") ? 1 : (getenv("VIPE_BA_ACCUM_GENERAL") ? 2 : 0);
   a.droid = 1;
   a.dz_out = d_dz;
