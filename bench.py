@@ -562,11 +562,15 @@ def update_mode(args, D):
         else:
             orig(pk, x0, x0_coff, B, H, W, *a, **k)
 
-    eng._conv = timed_conv
+    # the operator is normally ONE natively sequenced library call; for these few steps the same kernels are issued one
+    # by one from Python (forward_nhwc(native=False)) so that single launches can be bracketed by events
+    fwd = eng.forward_nhwc
+    eng._conv, eng.forward_nhwc = timed_conv, (lambda *a, **k: fwd(*a, **dict(k, native=False)))
     for _ in range(args.prof_steps):
         step()
     torch.cuda.synchronize()
     eng._conv = orig
+    del eng.forward_nhwc
     tot_ms = sum(a.elapsed_time(b) for a, b, _ in rec) or float("nan")
     tot_fl = sum(f for _, _, f in rec)
     gate_ms = tot_ms / max(1, len(rec))

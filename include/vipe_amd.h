@@ -224,7 +224,8 @@ typedef struct {
                         exit at once (the choice depends on the plan, which lives on the device).  A caller that has read
                         d_info[4..7] of an earlier call with the SAME plan may pass what it learnt so that those launches are
                         not made: bit 0 source degree <= 6 (matrix-core accumulate), bit 1 degree > 6 (walk + Schur),
-                        bit 2 the LDS band solver takes the system, bit 3 it does not (global-memory Cholesky). */
+                        bit 2 an LDS solver takes the system (the global-memory Cholesky is not launched), bit 3 the LDS
+                        band solver does not take it, bit 4 the LDS dense solver does not take it. */
 } vipe_ba_params;
 
 int64_t vipe_dense_ba_workspace_bytes(const vipe_ba_params* p);
@@ -341,6 +342,51 @@ int vipe_conv2d_fused(const void* d_x0, int x0_ctot, int x0_coff, const void* d_
                       const void* d_net, int net_ctot, int net_coff, const void* d_z, float* d_fout,
                       const void* d_accinit, int ai_ctot, int ai_coff, int B, int H, int W, int Cin, int Cout, int KH,
                       int KW, int act, int mode, void* stream);
+
+/* [fused] the whole flow-update operator (UpdateModule.forward, droid_net.py:467-499) sequenced natively: the 13 fused
+ * convolutions above + vipe_corr_lookup_conv1x1 + vipe_segment_mean_nhwc_f16 + the pooled-context product in ONE call
+ * (issued one by one from the host each launch costs more than most of them run for on a frontend window).
+ * All tensors channels-last fp16 unless noted; the weight descriptors are `vipe_conv_pack_weights` outputs + fp32 biases. */
+typedef struct {
+  const void *corr0_w, *corr2_w, *flow0_w, *flow2_w, *gw_w, *zr_w, *q_w, *zr_s_w, *q_s_w, *heads0_w, *heads2_w, *agg2_w, *eta_w;
+  const float *corr0_b, *corr2_b, *flow0_b, *flow2_b, *gw_b, *zr_b, *q_b, *heads0_b, *heads2_b, *agg2_b, *eta_b;
+  const float* glo_wT; /* [128,384] f32: (convz_glo | convr_glo | convq_glo) weights transposed */
+  const float* glo_b;  /* [384] */
+} vipe_update_weights;
+typedef struct {
+  int E, H, W, n_src;        /* edges, grid, source nodes (0: no GraphAgg / eta) */
+  /* correlation features: either a pyramid to look up (levels[0] != NULL; lookup fused with corr_encoder[0]) ... */
+  const void* levels[4];
+  const float* coords;       /* [E,H,W,2] */
+  const int* slots;          /* optional [E] */
+  int h2, w2, pyramid_layout;
+  const void* corr;          /* ... or the looked-up features [E,H,W,200] */
+  const void* motn;          /* [E,H,W,4] */
+  const void* net;           /* [E,H,W,128] hidden state (read) */
+  void* net_out;             /* [E,H,W,128] new hidden state (must not alias net: 3x3 halo) */
+  void* xbuf;                /* [E,H,W,320]: [inp | corr features | flow features], channels >= 128 overwritten */
+  const void* pgate;         /* optional [E,H,W,384]: context-feature part of the gate convolutions (gate-context hoisting) */
+  void *c1, *f1, *zb, *rnet; /* scratch [E,H,W,128] */
+  void* hbuf;                /* scratch [E,H,W,384] */
+  float* dw;                 /* out [E,H,W,4] f32: (delta_x, delta_y, weight_x, weight_y) */
+  float *glo, *extra;        /* scratch [E,128], [E,384] f32 */
+  const int *order, *rowptr; /* CSR of the edges by source node (vipe_segment_mean_nhwc_f16) */
+  void *agg, *a2;            /* scratch [n_src,H,W,128] */
+  float* eta;                /* out [n_src,H,W] f32 */
+} vipe_update_buffers;
+int vipe_update_operator(const vipe_update_weights* weights, const vipe_update_buffers* buffers, void* stream);
+
+/* the ConvGRU's three global-context 1x1 convolutions on the pooled vector (droid_net.py:392-399):
+ * extra[E,384] = bias + (glo_sum[E,128] / hw) @ wT[128,384]   (all f32) */
+int vipe_glo_context(const float* d_glo_sum, const float* d_wT, const float* d_bias, float* d_extra, int E, int hw,
+                     void* stream);
+
+/* [fused] tail of FactorGraph.update (factor_graph.py:270-276): target = coords1 + delta, weight = (masked source frame
+ * ? 0 : w), damping[du[k]] = eta[k].  coords1 / target / weight [E,ht,wd,2] f32, dw [E,ht,wd,4] f32, mask [E,ht,wd] bytes
+ * (optional), eta [n_src,ht,wd], du [n_src] int64, damping [*,ht,wd]. */
+int vipe_update_finish(const float* d_coords1, const float* d_dw, const unsigned char* d_mask, float* d_target,
+                       float* d_weight, const float* d_eta, const int64_t* d_du, float* d_damping, int E, int n_src, int ht,
+                       int wd, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Frame encoders: BasicEncoder fnet / cnet (vipe/slam/networks/droid_net.py:290-370,

@@ -819,6 +819,27 @@ def test_factor_graph_update_batch_runs_and_reduces_energy():
     assert e_after < e_before
 
 
+def test_dense_ba_dense_window_takes_lds_dense_solver():
+    """The frontend's windows: ~20 free poses, every pair coupled (proximity + inactive edges) - too wide for the LDS
+    band solver, but the packed lower triangle of the reduced system (n = 114, and 115 with the focal length) fits LDS:
+    `ba_solve_dense_kernel` (info[5] == 2) must give the fp64 oracle's answer."""
+    g = make_graph(n=20, height=96, width=128, radius=19, seed=91)  # all ordered pairs: E = 380
+    assert len(g.ii) == 380
+    for intr in (False, True):
+        bk = dict(t0=1, t1=20, n_iters=2, pose_damping=1e-3, pose_ep=0.1, motion_only=False, limited_disp=False,
+                  optimize_intrinsics=intr)
+        p, d, k, info = run_hip_ba(g, g.intrinsics, "pinhole", bk)
+        E = len(g.ii)
+        op, od, ok_, _ = oba.bundle_adjustment(g.poses, g.disps[:, None], g.disps_sens[:, None], g.intrinsics,
+                                               ose3.se3_identity(1), g.target.reshape(E, -1, 2), g.weight.reshape(E, -1, 2),
+                                               g.eta[:, None], g.ii, g.jj, **bk)
+        assert info[0] == 19 and info[3] == 114 + int(intr) and info[2] == 0 and info[4] == 18
+        assert info[5] == 2, "the LDS dense solver should have taken this system"
+        assert np.abs(p - op).max() <= 1e-4 * max(1.0, np.abs(op).max())
+        assert np.abs(d - od[:, 0]).max() <= 1e-4 * np.abs(od).max()
+        assert np.abs(k - ok_).max() <= 1e-4 * np.abs(ok_).max()
+
+
 def test_dense_ba_non_banded_graph_takes_global_memory_solver():
     """Long-range (loop-closure-like) edges make the reduced system dense: it no longer fits the LDS band solver and
     the blocked global-memory Cholesky (fp64 MFMA trailing update) must give the same answer as the fp64 oracle."""
@@ -972,6 +993,46 @@ def test_fused_lookup_conv1x1_matches_lookup_then_conv():
     assert float((out[..., 16:144].float().cpu() - r32).abs().max()) < 3e-2
 
 
+def test_natively_sequenced_operator_equals_python_sequenced():
+    """`vipe_update_operator` (one library call for the 13 convolutions, the lookup, the segmented mean and the pooled
+    context product) issues exactly the kernels `forward_nhwc(native=False)` issues one by one: bit-identical state,
+    heads and eta, with and without the hoisted gate context, from a deferred lookup and from materialised features."""
+    from vipe_amd.slam.networks import CorrBlock, UpdateModule
+    from vipe_amd.slam.update_engine import segment_csr
+    torch.manual_seed(0)
+    eng = UpdateModule().eval().engine(dev())
+    E, h, w = 5, 8, 64
+    g = torch.Generator().manual_seed(3)
+    net = torch.randn(E, h, w, 128, generator=g).tanh().half().to(dev())
+    xbuf = torch.zeros(E, h, w, 320, dtype=torch.float16, device=dev())
+    xbuf[..., :128] = torch.randn(E, h, w, 128, generator=g).relu().half().to(dev())
+    motn = (torch.randn(E, h, w, 4, generator=g) * 3).half().to(dev())
+    fm = torch.randn(4, 128, h, w, generator=g).half().to(dev())
+    i1, i2 = torch.tensor([0, 1, 2, 3, 0], device=dev()), torch.tensor([1, 2, 3, 0, 2], device=dev())
+    cb = CorrBlock.from_buffer(fm, i1, i2)
+    coords = (torch.rand(E, h, w, 2, generator=g) * torch.tensor([w - 1.0, h - 1.0])).to(dev())
+    ix = torch.tensor([0, 0, 1, 2, 2], device=dev())
+    csr = segment_csr(ix, 3)
+    pg = eng.gate_context(xbuf)
+    for corr in (cb.lookup_deferred(coords), cb.lookup_nhwc(coords)):
+        for pgate in (pg, None):
+            outs = []
+            for native in (True, False):
+                xb = xbuf.clone()
+                n2, dw, eta, _ = eng.forward_nhwc(net, xb, corr, motn, ix=ix, n_src=3, csr=csr, pgate=pgate, native=native)
+                outs.append((n2.clone(), dw.clone(), eta.clone(), xb))
+            for a, b_ in zip(*outs):
+                assert torch.equal(a, b_)
+    # without GraphAgg (ix None), and the upmask branch on top of the native call
+    n2a, dwa, eta_a, up_a = eng.forward_nhwc(net, xbuf.clone(), cb.lookup_deferred(coords), motn, native=True)
+    n2b, dwb, _, _ = eng.forward_nhwc(net, xbuf.clone(), cb.lookup_deferred(coords), motn, native=False)
+    assert eta_a is None and up_a is None and torch.equal(n2a, n2b) and torch.equal(dwa.clone(), dwb)
+    _, _, _, up1 = eng.forward_nhwc(net, xbuf.clone(), cb.lookup_deferred(coords), motn, ix=ix, n_src=3, csr=csr, want_upmask=True)
+    _, _, _, up2 = eng.forward_nhwc(net, xbuf.clone(), cb.lookup_deferred(coords), motn, ix=ix, n_src=3, csr=csr, want_upmask=True,
+                                    native=False)
+    assert up1.shape == (3, h, w, 576) and torch.equal(up1, up2)
+
+
 def test_gate_context_hoisting_equals_full_gate_convolutions():
     """`UpdateEngine.gate_context` + accumulator initialisation (linearity of the gate convolutions in their input
     channels) against the full 448-channel gate convolutions on the same inputs: identical up to the fp16 rounding of
@@ -1121,6 +1182,49 @@ def test_frontend_mirror_runs_and_keeps_graph_state_consistent():
     assert int(g.age.max()) >= 6 and int(g.ii.max()) == 13
     assert bool(torch.isfinite(buf.poses[:15]).all()) and bool(torch.isfinite(buf.disps[:15]).all())
     assert bool((buf.disps[:14] >= 1e-3).all())
+
+
+def test_frontend_prefetched_frame_distances_change_nothing():
+    """The frontend launches the frame-distance kernel for the NEXT keyframe's edge proposal at the end of each step and
+    reads the result from pinned memory one step later (no stream drain).  Same kernel, same inputs: the edge lists must
+    be identical to a frontend that computes the distances on demand, keyframe after keyframe - and the prefetch must
+    actually be hit, and be dropped when somebody touches the geometry in between."""
+    from vipe_amd.slam.buffer import GraphBuffer
+    from vipe_amd.slam.frontend import FrontendArgs, SLAMFrontend
+    from vipe_amd.slam.networks import UpdateModule
+
+    def make(prefetch):
+        torch.manual_seed(0)
+        buf = GraphBuffer(128, 128, buffer_size=24, device=dev())
+        buf.intrinsics[:] = torch.tensor([115.0, 115.0, 64.0, 64.0], device=dev())
+        fe = SLAMFrontend(UpdateModule().eval(), buf, FrontendArgs(keyframe_thresh=0.0), dev())
+        if not prefetch:
+            fe._prefetch_proximity = lambda: None
+        hits = []
+        orig = fe._prefetched_distances
+        fe._prefetched_distances = lambda *a: (hits.append(1) or True) and (lambda r: (hits.pop() if r is None else None, r)[1])(orig(*a))
+        return buf, fe, hits
+
+    (b1, f1, h1), (b2, f2, h2) = make(True), make(False)
+    gen = torch.Generator().manual_seed(7)
+    for t in range(16):
+        fm = torch.randn(128, 16, 16, generator=gen).half().to(dev())
+        nt = torch.randn(128, 16, 16, generator=gen).tanh().half().to(dev())
+        ip = torch.randn(128, 16, 16, generator=gen).relu().half().to(dev())
+        dd = (1.0 / (1.0 + 4.0 * torch.rand(16, 16, generator=gen))).to(dev())
+        for buf, fe in ((b1, f1), (b2, f2)):
+            buf.fmaps[t, 0], buf.nets[t, 0], buf.inps[t, 0] = fm, nt, ip
+            if t < 8:
+                buf.poses[t, 0] = 0.05 * t
+                buf.disps[t, 0] = dd
+            if t == 12:
+                buf.touch()  # an outside writer declares a change: this keyframe's prefetch must be discarded
+            buf.n_frames += 1
+            fe.run()
+        assert torch.equal(f1.graph.ii, f2.graph.ii) and torch.equal(f1.graph.jj, f2.graph.jj), t
+        assert torch.equal(f1.graph.ii_inac, f2.graph.ii_inac) and torch.equal(f1.graph.jj_inac, f2.graph.jj_inac), t
+    assert len(h1) == 7 and len(h2) == 0  # keyframes 8..15 except the touched one
+    assert float((b1.poses[:16] - b2.poses[:16]).abs().max()) < 1e-3  # same edges; float atomics differ run to run
 
 
 def test_update_batch_volume_path_matches_altcorr_path(monkeypatch):

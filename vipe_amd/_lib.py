@@ -32,6 +32,33 @@ class BAParams(ctypes.Structure):
     ]
 
 
+def parse_struct(name, path=HEADER):
+    """ctypes.Structure mirroring `typedef struct { ... } name;` of the header (int / float scalars, pointers of any type
+    as addresses, fixed-size pointer arrays) - field order and types come from the header itself."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    m = re.search(r"typedef\s+struct\s*\{([^{}]*)\}\s*" + name + r"\s*;", src)
+    if m is None:
+        raise KeyError(name)
+    fields = []
+    for decl in m.group(1).split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        first, *rest = decl.split(",")
+        toks = first.replace("*", " * ").split()
+        base = [t for t in toks[:-1] if t != "*"]
+        names = [(first.count("*") > 0, toks[-1])] + [(r.count("*") > 0, r.replace("*", "").strip()) for r in rest]
+        scalar = {"int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "int64_t": ctypes.c_int64}
+        for is_ptr, nm in names:
+            arr = re.match(r"(\w+)\[(\d+)\]", nm)
+            ctype = ctypes.c_void_p if is_ptr else scalar[[b for b in base if b != "const"][0]]
+            if arr:
+                nm, ctype = arr.group(1), ctype * int(arr.group(2))
+            fields.append((nm, ctype))
+    return type(name, (ctypes.Structure,), {"_fields_": fields})
+
+
 _SCALARS = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "double": ctypes.c_double}
 
 
@@ -116,6 +143,25 @@ def stream_ptr(t=None):
                 _RESTORE_DEVICE = cur
             torch.cuda.set_device(dev)
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def upload(data, device, dtype=torch.int64):
+    """Small host array (list / numpy / CPU tensor) -> device tensor WITHOUT draining the stream: the data is staged in
+    pinned host memory (torch's caching pinned allocator: reuse is event-guarded) and copied asynchronously on the
+    current stream.  `torch.tensor(x, device=...)` / `.to(device)` from pageable memory synchronise the stream - a
+    pipeline bubble per call; the edge bookkeeping of the keyframe frontend makes a dozen of them per keyframe."""
+    import numpy as np
+    if torch.is_tensor(data):
+        if data.is_cuda:
+            return data.to(device=device, dtype=dtype)
+        data = data.detach().numpy()
+    arr = np.ascontiguousarray(np.asarray(data), dtype=torch.empty(0, dtype=dtype).numpy().dtype)
+    if torch.device(device).type != "cuda":
+        return torch.from_numpy(arr.copy()).to(device)
+    stage = torch.empty(arr.shape, dtype=dtype, pin_memory=True)
+    if arr.size:
+        stage.numpy()[...] = arr
+    return stage.to(device, non_blocking=True)
 
 
 def ptr(t):

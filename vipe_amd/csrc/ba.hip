@@ -2129,6 +2129,205 @@ __global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds
   else band_solve_body<2, false>(a, lds_doubles, smem_raw);
 }
 
+// ------------------------------------------------------------------------------------------------ solve (LDS dense)
+//
+// Dense windows that the band solver cannot hold (the keyframe frontend: up to ~25 free poses, every pair coupled through
+// proximity and inactive edges) but whose PACKED lower triangle still fits LDS (n + 1 <= ~190 rows: 145 KB of fp64): the
+// whole factorisation runs out of LDS like the band solver's, instead of three L2 round trips per block step in the
+// global-memory kernel (99 us at n = 150).  Row r (columns 0..r) lives at r (r + 1) / 2; row n is the rhs, so the forward
+// substitution falls out of the factorisation.  Per 6-column block step: panel (one row per thread, forward
+// substitution against the 6 x 6 factor block), barrier, trailing update (waves 1..7: a 28 x 16 thread grid walks the
+// remaining triangle) while wave 0 updates the 21 entries of the NEXT diagonal block and its lane 0 factors it
+// (look-ahead), barrier.  Back substitution by wave 0 alone, column oriented, wave barriers only.
+// Sets info[5] = 2 when it solved the system.
+constexpr int DN_T = 512;
+
+__global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_doubles) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* const L = reinterpret_cast<double*>(smem_raw);
+  const vipe_ba_params& prm = a.p;
+  const BAWs& w = a.w;
+  const int t = threadIdx.x;
+  const int n = w.info[3], n_free = w.info[0];
+  const int npr = 6 * n_free, F = n - npr;
+  const int NP = (n + 1) * (n + 2) / 2;  // packed size incl. the rhs row
+  // info[5] == 1: the band solver (which resets the flag whenever it runs) solved THIS iteration.  A 2 can only be this
+  // kernel's own mark from the previous Gauss-Newton iteration of the call (ba_sens_kernel clears the flag per call).
+  if (n == 0 || w.info[5] == 1 || a.mv || NP + 64 + n > lds_doubles || F > 2) return;
+  double* const blk = L + NP;   // 6x7: the current diagonal factor block
+  double* const rd = blk + 42;  // its reciprocal pivots
+  int* const failp = reinterpret_cast<int*>(rd + 6);
+  double* const rdall = rd + 8; // [n] reciprocal pivots of every column (back substitution)
+  auto off = [](int r) { return r * (r + 1) / 2; };
+  const double* S = w.S;
+  const int ld = w.ld;
+  if (t == 0) *failp = 0;
+  // ---- load with LM damping on the diagonal (matrix.py:179-186): one row per wave and pass, lanes over the columns
+  {
+    const int wv = t >> 6, ln = t & 63;
+    for (int r = wv; r <= n; r += DN_T / 64) {
+      for (int c = ln; c <= r && c < n; c += 64) {
+        double v = S[(int64_t)r * ld + c];
+        if (c == r) {
+          const bool pose = r < npr;
+          v += (pose ? (double)prm.pose_ep : 1e-6) + (pose ? (double)prm.pose_damping : 1e-6) * (a.droid ? v : w.Hd[r]);
+        }
+        L[off(r) + c] = v;
+      }
+    }
+  }
+  const int nblk = n_free + (F > 0 ? 1 : 0);
+  // factor the diagonal block of step kb (bw columns) in registers; publish L, blk, rd
+  auto factor_diag = [&](int kb) {
+    const int j0 = 6 * kb, bw = min(6, n - j0);
+    double A[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) A[i][j] = (i < bw) ? L[off(j0 + i) + j0 + j] : (i == j ? 1.0 : 0.0);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      double d = A[j][j];
+#pragma unroll
+      for (int m = 0; m < j; ++m) d -= A[j][m] * A[j][m];
+      if (!(d > 0.0)) { *failp = 1; d = 1.0; }
+      const double rl = rsqrt_nr(d);
+      A[j][j] = d * rl;
+      rd[j] = rl;
+      if (j < bw) rdall[j0 + j] = rl;
+#pragma unroll
+      for (int i = j + 1; i < 6; ++i) {
+        double sacc = A[i][j];
+#pragma unroll
+        for (int m = 0; m < j; ++m) sacc -= A[i][m] * A[j][m];
+        A[i][j] = sacc * rl;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        if (i < bw) L[off(j0 + i) + j0 + j] = A[i][j];
+        blk[i * 7 + j] = A[i][j];
+      }
+  };
+  __syncthreads();
+  if (t == 0) factor_diag(0);
+  __syncthreads();
+  for (int kb = 0; kb < nblk; ++kb) {
+    const int j0 = 6 * kb, bw = min(6, n - j0), R0 = j0 + bw;
+    // panel: rows R0..n (row n = rhs)
+    {
+      const int r = R0 + t;
+      if (r <= n) {
+        double* row = L + off(r) + j0;
+        double x[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          double sacc = j < bw ? row[j] : 0.0;
+#pragma unroll
+          for (int m = 0; m < j; ++m) sacc -= x[m] * blk[j * 7 + m];
+          x[j] = sacc * rd[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          if (j < bw) row[j] = x[j];
+      }
+    }
+    __syncthreads();
+    const int nbw = min(6, n - R0);  // width of the next diagonal block
+    if (t < 64) {
+      // wave 0: the next diagonal block's entries (i, j), j <= i < nbw, then its factorisation by lane 0
+      if (t < 21) {
+        const int i = SYM_R[t], j = SYM_C[t];
+        if (i < nbw) {
+          const double* pa = L + off(R0 + i) + j0;
+          const double* pb = L + off(R0 + j) + j0;
+          double sacc = 0.0;
+#pragma unroll
+          for (int m = 0; m < 6; ++m)
+            if (m < bw) sacc += pa[m] * pb[m];
+          L[off(R0 + i) + R0 + j] -= sacc;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (t == 0 && kb + 1 < nblk) factor_diag(kb + 1);
+    } else {
+      // waves 1..7: rows r >= R0, columns R0 <= c <= min(r, n - 1), without the next diagonal block
+      const int u = t - 64, rr = u >> 4, cc = u & 15;  // 28 x 16
+      for (int r = R0 + rr; r <= n; r += 28) {
+        const double* pa = L + off(r) + j0;
+        double xr[6];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) xr[m] = m < bw ? pa[m] : 0.0;
+        double* drow = L + off(r);
+        const int cmax = min(r, n - 1);
+        for (int c = R0 + cc; c <= cmax; c += 16) {
+          if (r < R0 + nbw) continue;  // c <= r < R0 + nbw: an entry of the next diagonal block (wave 0 owns it)
+          const double* pb = L + off(c) + j0;
+          double sacc = 0.0;
+#pragma unroll
+          for (int m = 0; m < 6; ++m)
+            if (m < bw) sacc += xr[m] * pb[m];
+          drow[c] -= sacc;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- back substitution L^T x = y (y = row n), wave 0, column oriented: once x of block kb is known every lane
+  //      subtracts its columns' contributions from y
+  double* y = L + off(n);
+  if (t < 64) {
+    for (int kb = nblk - 1; kb >= 0; --kb) {
+      const int j0 = 6 * kb, bw = min(6, n - j0);
+      double x[6];
+#pragma unroll
+      for (int j = 5; j >= 0; --j) {
+        double sacc = 0.0;
+        if (j < bw) {
+          sacc = y[j0 + j];
+#pragma unroll
+          for (int m = 5; m > j; --m)
+            if (m < bw) sacc -= L[off(j0 + m) + j0 + j] * x[m];
+          sacc *= rdall[j0 + j];
+        }
+        x[j] = sacc;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (t < bw) {
+        double xo = x[0];
+#pragma unroll
+        for (int j = 1; j < 6; ++j) xo = t == j ? x[j] : xo;
+        y[j0 + t] = xo;
+      }
+      for (int c = t; c < j0; c += 64) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          if (j < bw) sacc += L[off(j0 + j) + c] * x[j];
+        y[c] -= sacc;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  const bool bad = *failp != 0;
+  if (t == 0) {
+    if (bad) w.info[2] += 1;
+    w.info[5] = 2;
+  }
+  for (int dd = t; dd < n; dd += DN_T) {
+    double x = y[dd];
+    if (bad || !(x == x)) x = 0.0;
+    w.dx[dd] = (float)x;
+  }
+  __syncthreads();
+  apply_retraction(a, t, DN_T, n_free);
+}
+
 // ------------------------------------------------------------------------------------------------ solve
 
 // Dense Cholesky solve of the reduced system by ONE workgroup (16 waves), fp64.
@@ -2167,7 +2366,7 @@ __global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_c
   long long tacc[5] = {0, 0, 0, 0, 0};
 #define STAMP(i) if (dbg && t == 0) { long long tn = wall_clock64(); tacc[i] += tn - tprev; tprev = tn; }
   if (t == 0) sh.fail = 0;
-  if (n == 0 || w.info[5] == 1) return;
+  if (n == 0 || w.info[5] != 0) return;  // an LDS solver (band: 1, dense: 2) took the system
   // LM damping on the diagonal: += ep + lambda * diag(H)  (matrix.py:179-186)
   for (int dd = t; dd < n; dd += SOLVE_T) {
     // poses: the caller's (lambda, ep); intrinsics 1e-6 / 1e-6; rig rotations 1e-4 / 1e-4 (buffer.py:466,498,503)
@@ -2486,6 +2685,7 @@ int run_iters(const BAArgs& a, hipStream_t s) {
   if (vipe_first_on_device(attr_set)) {
     (void)hipFuncSetAttribute((const void*)ba_solve_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ba_solve_dense_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   (void)hipFuncSetAttribute((const void*)ba_accum_mfma_kernel<CAM, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_mfma_lds());
   (void)hipFuncSetAttribute((const void*)ba_walk_kernel<CAM, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds());
@@ -2517,6 +2717,7 @@ int run_iters(const BAArgs& a, hipStream_t s) {
     }
     if (a.force_simple == 1) ba_accum_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
     if (!(hint & 8)) ba_solve_band_kernel<<<1, BAND_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)));
+    if (!(hint & 16)) ba_solve_dense_kernel<<<1, DN_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)));
     if (!(hint & 4)) ba_solve_kernel<<<1, SOLVE_T, solve_lds, s>>>(a, panel_cap, getenv("VIPE_BA_DEBUG_TIMING") ? (long long*)(a.w.Hd + nmax) : nullptr);
     if (!a.p.motion_only) ba_retract_kernel<F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
   }

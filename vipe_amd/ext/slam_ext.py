@@ -55,19 +55,37 @@ def reproject_motion(poses, disps, intrinsics, rig, pi, qi, pj, qj, di, target, 
     return coords, motn
 
 
-def reproject_motion_nhwc(poses, disps, intrinsics, rig, pi, qi, pj, qj, di, target, camera="pinhole", intr_factor=8.0):
-    """coords1 + clamped motion features channels-last [M,ht,wd,4] fp16 in one launch."""
+def reproject_motion_nhwc(poses, disps, intrinsics, rig, pi, qi, pj, qj, di, target, camera="pinhole", intr_factor=8.0,
+                          out=None):
+    """coords1 + clamped motion features channels-last [M,ht,wd,4] fp16 in one launch.  `out` = (coords, motn) buffers
+    to write into (a caller iterating over an unchanged edge set keeps them: stable addresses, no allocation)."""
     check_gpu_contig(poses, disps, intrinsics, rig, pi, qi, pj, qj, di, target)
     M = pi.shape[0]
     _, ht, wd = disps.shape
     require(target.numel() == M * ht * wd * 2 and target.dtype == torch.float32, "target must be [M,ht,wd,2] float32")
-    coords = torch.empty((M, ht, wd, 2), dtype=torch.float32, device=poses.device)
-    motn = torch.empty((M, ht, wd, 4), dtype=torch.float16, device=poses.device)
+    if out is not None:
+        coords, motn = out
+        require(tuple(coords.shape) == (M, ht, wd, 2) and coords.dtype == torch.float32 and coords.is_contiguous()
+                and tuple(motn.shape) == (M, ht, wd, 4) and motn.dtype == torch.float16 and motn.is_contiguous(), "bad out buffers")
+    else:
+        coords = torch.empty((M, ht, wd, 2), dtype=torch.float32, device=poses.device)
+        motn = torch.empty((M, ht, wd, 4), dtype=torch.float16, device=poses.device)
     check(lib().vipe_reproject_motion_nhwc(ptr(poses), ptr(disps), ptr(intrinsics), ptr(rig), ptr(_i64(pi)),
                                            ptr(_i64(qi)), ptr(_i64(pj)), ptr(_i64(qj)), ptr(_i64(di)), ptr(target),
                                            ptr(coords), ptr(motn), M, ht, wd, rig.shape[0], CAMERA_CODE[camera],
                                            float(intr_factor), stream_ptr(poses)), "reproject_motion_nhwc")
     return coords, motn
+
+
+def update_finish(coords1, dw, mask, target, weight, eta, du, damping):
+    """Tail of FactorGraph.update (factor_graph.py:270-276) in one launch: target = coords1 + delta, weight = w with the
+    masked source frames zeroed, damping[du] = eta.  coords1 [E,h,w,2], dw [E,h,w,4] f32 (delta | weight), mask [E,h,w]
+    bool or None, target / weight [1,E,h,w,2] (written in place), eta [n_src,h,w], du [n_src] int64, damping [*,h,w]."""
+    E, ht, wd, _ = coords1.shape
+    n_src = 0 if eta is None else int(eta.shape[0])
+    require(target.is_contiguous() and weight.is_contiguous() and target.numel() == E * ht * wd * 2, "target / weight: contiguous [1,E,h,w,2]")
+    check(lib().vipe_update_finish(ptr(coords1), ptr(dw), ptr(mask), ptr(target), ptr(weight), ptr(eta), ptr(du), ptr(damping),
+                                   E, n_src, ht, wd, stream_ptr(coords1)), "update_finish")
 
 
 def dense_ba(poses, disps, disps_sens, intrinsics, rig, target, weight, disp_damping, pi, qi, pj, qj, di, t0, t1,
@@ -142,9 +160,9 @@ def _path_hint(state, key):
         del state["pending"]
         if len(hints) > 64:
             hints.clear()
-        degree, solved = int(host[6]), int(host[5])
+        degree, solved = int(host[6]), int(host[5])  # solved: 0 global-memory Cholesky, 1 LDS band solver, 2 LDS dense solver
         if degree > 0:  # AM_DMAX = 6 in csrc/ba.hip: the matrix-core accumulate kernel covers source degrees up to 6
-            hints[k] = (1 if degree <= 6 else 2) | (4 if solved else 8)
+            hints[k] = (1 if degree <= 6 else 2) | {0: 8 | 16, 1: 4 | 16, 2: 4 | 8}.get(solved, 0)
     return hints.get(key, 0)
 
 

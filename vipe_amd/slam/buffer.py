@@ -26,6 +26,7 @@ class GraphBuffer:
         if cross_view_idx is None:
             cross_view_idx = [(i + 1) % n_views for i in range(n_views)]
         self.n_frames = 0
+        self.geom_version = 0  # counts writes to poses / disps / intrinsics made through this class, see touch()
         self.height, self.width, self.n_views, self.device = height, width, n_views, device
         self.ba_config = ba_config or BAConfig()
         self.camera_type = camera_type
@@ -48,6 +49,12 @@ class GraphBuffer:
         self.cross_view_idx = torch.zeros(buffer_size, n_views, 2, device=device, dtype=torch.long)
         self.cross_view_idx[..., 0] = torch.arange(buffer_size, device=device)[:, None]
         self.cross_view_idx[..., 1] = torch.tensor(cross_view_idx, device=device).long()[None]
+
+    def touch(self):
+        """Declare that poses / disps / intrinsics / rig changed.  Results derived from them and kept across calls (the
+        frontend's prefetched frame distances) are only reused while this counter stands still; `bundle_adjustment` and
+        `remove_second_newest` call it, code that writes the tensors directly must too."""
+        self.geom_version += 1
 
     @property
     def images(self):
@@ -102,6 +109,7 @@ class GraphBuffer:
             pi, qi, di, pj, qj = plan if plan is not None else self.expand_edge_multiview(ii, jj)[:5]
         V = self.n_views
         n_poses = max(self.n_frames, int(t1)) - base
+        self.touch()
         return slam_ext.dense_ba(
             self.poses[base:], self.flattened_disps[base * V:], self.flattened_disps_sens[base * V:], self.intrinsics,
             self.rig, target.contiguous(), weight.contiguous(), disp_damping[base * V:].contiguous(), pi, qi, pj, qj, di,
@@ -128,6 +136,7 @@ class GraphBuffer:
     def remove_second_newest(self, ix):
         """buffer.py:218-231: keyframe ix is overwritten by its successor (the newest frame)."""
         assert ix == self.n_frames - 2
+        self.touch()
         for name in ("tstamp", "_images", "poses", "disps", "disps_sens", "nets", "inps", "fmaps", "masks",
                      "cross_view_idx"):
             arr = getattr(self, name, None)
@@ -137,13 +146,13 @@ class GraphBuffer:
             self.dirty[ix] = True
         self.n_frames -= 1
 
-    def frame_distance_dense_disp(self, ii, jj, beta=0.3, bidirectional=True, view_offset=0):
-        """buffer.py:550-593 -> [M, n_views]."""
+    def frame_distance_dense_disp(self, ii, jj, beta=0.3, bidirectional=True, view_offset=0, n_frames=None):
+        """buffer.py:550-593 -> [M, n_views].  `n_frames`: frames the indices may address (default: the buffer's count)."""
         from ..ext.lietorch import SE3
 
         pi, qi, di, pj, qj, dj = self.expand_edge_multiview(ii, jj, cross=False, view_offset=view_offset)
         V = self.n_views
-        poses = SE3(self.poses[: self.n_frames])
+        poses = SE3(self.poses[: self.n_frames if n_frames is None else n_frames])
         rig = SE3(self.rig)
         # expand poses into (n v) space: R_v^-1 * G_n   (geom.py:338)
         exp = (rig.inv().view((1, -1)) * poses.view((-1, 1))).view((-1,)).data.contiguous()

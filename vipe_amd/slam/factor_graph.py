@@ -11,6 +11,7 @@ import os
 import numpy as np
 import torch
 
+from .._lib import upload
 from ..ext import slam_ext
 from .networks import AltCorrBlock, CorrBlock, CorrPool
 
@@ -27,7 +28,8 @@ class FactorGraph:
         self.ht, self.wd = ht, wd
         self.ii = torch.as_tensor([], dtype=torch.long, device=device)
         self.jj = torch.as_tensor([], dtype=torch.long, device=device)
-        self.age = torch.as_tensor([], dtype=torch.long, device=device)
+        self._age = torch.as_tensor([], dtype=torch.long, device=device)
+        self._age_lag = 0
         self.damping = 1e-6 * torch.ones_like(buffer.flattened_disps)  # factor_graph.py:76
         self.target = torch.zeros([1, 0, ht, wd, 2], device=device, dtype=torch.float)
         self.weight = torch.zeros([1, 0, ht, wd, 2], device=device, dtype=torch.float)
@@ -42,6 +44,19 @@ class FactorGraph:
         self._plan_serial = 0   # counts rebuilt edge plans: (serial, kind) identifies the index arrays handed to the BA
         self._ba_state = {}     # private BA workspace + the key of the plan it holds (slam_ext.dense_ba)
         self._h = None  # host mirror of the integer edge state (ii, jj, age, ii_inac, jj_inac), see host_edges()
+
+    @property
+    def age(self):
+        """factor_graph.py:72 - edge ages on the device.  `update` only counts its calls (the host mirror is what the
+        scheduling logic reads); the device tensor catches up when somebody looks at it."""
+        if self._age_lag:
+            self._age += self._age_lag
+            self._age_lag = 0
+        return self._age
+
+    @age.setter
+    def age(self, value):
+        self._age, self._age_lag = value, 0
 
     def host_edges(self):
         """Host-side copy of the integer edge bookkeeping {ii, jj, age, ii_inac, jj_inac} (numpy int64).  Every method
@@ -88,8 +103,8 @@ class FactorGraph:
             # leaves the order of equal ages unspecified - the stable order is used here)
             ix = np.argsort(self.host_edges()["age"], kind="stable")
             self.rm_factors(ix >= self.max_factors - ii_h.shape[0], store=True)
-        ii = torch.from_numpy(ii_h).to(self.device)
-        jj = torch.from_numpy(jj_h).to(self.device)
+        ii = upload(ii_h, self.device)
+        jj = upload(jj_h, self.device)
         pi, qi, _, pj, qj, _ = self.buffer.expand_edge_multiview(ii, jj)
         if self.incremental:
             if self.corr is None:
@@ -132,8 +147,8 @@ class FactorGraph:
             self._have.difference_update(zip(h["ii"][m].tolist(), h["jj"][m].tolist()))
         h["ii"], h["jj"], h["age"] = h["ii"][~m], h["jj"][~m], h["age"][~m]
         V = self.buffer.n_views
-        keep = torch.from_numpy(np.flatnonzero(~m)).to(self.device)
-        drop = torch.from_numpy(np.flatnonzero(m)).to(self.device)
+        keep = upload(np.flatnonzero(~m), self.device)
+        drop = upload(np.flatnonzero(m), self.device)
         views = torch.arange(V, device=self.device)
         keep_x = (keep[:, None] * V + views).view(-1) if V > 1 else keep
         drop_x = (drop[:, None] * V + views).view(-1) if V > 1 else drop
@@ -164,7 +179,7 @@ class FactorGraph:
         self.add_factors(ii[keep], jj[keep])
 
     @torch.no_grad()
-    def add_proximity_factors(self, t0=0, t1=0, rad=2, nms=2, beta=0.25, thresh=16.0, remove=False):
+    def add_proximity_factors(self, t0=0, t1=0, rad=2, nms=2, beta=0.25, thresh=16.0, remove=False, dist=None):
         """Edge proposal (factor_graph.py:411-488): neighbourhood edges i-rad-1..i-1 <-> i for i in [t0, t), then
         proximity edges (i, j), i in [t0, t), j in [t1, t), j <= i - rad, in order of increasing frame distance with
         non-maximum suppression around every edge already present or just added; all made bidirectional.
@@ -178,8 +193,12 @@ class FactorGraph:
         iin, jjn = iin.reshape(-1), jjn.reshape(-1)
         if iin.size == 0:
             return
-        ii, jj = torch.from_numpy(iin).to(self.device), torch.from_numpy(jjn).to(self.device)
-        d = self.buffer.frame_distance_dense_disp(ii, jj, beta=beta).mean(-1).cpu().numpy().astype(np.float32)
+        if dist is not None:  # frame distances of exactly these candidates, computed earlier (SLAMFrontend prefetch)
+            d = np.array(dist, dtype=np.float32).reshape(-1)
+            assert d.shape[0] == iin.shape[0]
+        else:
+            ii, jj = upload(iin, self.device), upload(jjn, self.device)
+            d = self.buffer.frame_distance_dense_disp(ii, jj, beta=beta).mean(-1).cpu().numpy().astype(np.float32)
         nj = t - t1
 
         def suppress(i, j):
@@ -243,7 +262,7 @@ class FactorGraph:
         h["jj_inac"] = h["jj_inac"] - (h["jj_inac"] >= ix)
         if m.any():
             V = self.buffer.n_views
-            keep = torch.from_numpy(np.flatnonzero(~m)).to(self.device)
+            keep = upload(np.flatnonzero(~m), self.device)
             keep_x = (keep[:, None] * V + torch.arange(V, device=self.device)).view(-1) if V > 1 else keep
             self.ii_inac, self.jj_inac = self.ii_inac[keep], self.jj_inac[keep]
             self.target_inac = self.target_inac[:, keep_x]
@@ -293,13 +312,19 @@ class FactorGraph:
                 n_src = int(du.numel())
             else:
                 du_h, dix_h = np.unique(di_h, return_inverse=True)
-                du = torch.from_numpy(du_h).to(self.device)
-                dix = torch.from_numpy(dix_h.astype(np.int64)).to(self.device)
+                du = upload(du_h, self.device)
+                dix = upload(dix_h.astype(np.int64), self.device)
                 n_src = int(du_h.shape[0])
             from .update_engine import segment_csr
             self._plan_serial = getattr(self, "_plan_serial", 0) + 1
+            if self.cross_view or V > 1:
+                csr = segment_csr(dix, n_src)
+            else:  # the same CSR from the host mirror (torch.bincount reads its maximum back: a stream drain)
+                order_h = np.argsort(dix_h, kind="stable").astype(np.int32)
+                rowptr_h = np.concatenate([[0], np.cumsum(np.bincount(dix_h, minlength=n_src))]).astype(np.int32)
+                csr = (upload(order_h, self.device, torch.int32), upload(rowptr_h, self.device, torch.int32))
             self._plan = dict(pi=pi, qi=qi, di=di, pj=pj, qj=qj, du=du, dix=dix, n_src=n_src,
-                              csr=segment_csr(dix, n_src),
+                              csr=csr,
                               t0=int(max(1, h["ii"].min() + 1)),
                               t1=int(max(h["ii"].max(), h["jj"].max()) + 1))
         return self._plan
@@ -338,27 +363,28 @@ class FactorGraph:
         t0 = P["t0"] if t0 is None else t0
         t1 = P["t1"] if t1 is None else t1
         buf = self.buffer
+        E_act = int(P["pi"].shape[0])
+        if "io" not in P:  # per edge set: persistent coords / motion-feature buffers (stable addresses), frame masks
+            P["io"] = (torch.empty((E_act, self.ht, self.wd, 2), dtype=torch.float32, device=self.device),
+                       torch.empty((E_act, self.ht, self.wd, 4), dtype=torch.float16, device=self.device))
+            P["mask"] = buf.masks[P["pi"], P["qi"]].contiguous()
+        if not self.weight.is_contiguous() or not self.target.is_contiguous():
+            self.weight, self.target = self.weight.contiguous(), self.target.contiguous()
         # motion features + coords1 in one launch (factor_graph.py:253-261)
         coords1, motn = slam_ext.reproject_motion_nhwc(buf.poses, buf.flattened_disps, buf.intrinsics, buf.rig,
                                                        P["pi"], P["qi"], P["pj"], P["qj"], P["di"],
-                                                       self.target[0].contiguous(), camera=buf.camera_type)
+                                                       self.target[0], camera=buf.camera_type, out=P["io"])
         eng = self.update_op.engine(self.device)
-        # the lookup is deferred into the correlation encoder's first convolution (one kernel, no [E,h,w,200] tensor)
+        # the lookup is deferred into the correlation encoder's first convolution (one kernel, no [E,h,w,200] tensor); the
+        # whole operator is one natively sequenced library call
         corr = self.corr.lookup_deferred(coords1)
         self.net_n, dw, eta, _ = eng.forward_nhwc(self.net_n, self.xbuf, corr, motn, ix=P["dix"], n_src=P["n_src"],
                                                   net_out=self._net_spare(), csr=P["csr"], pgate=self.pgate)
-        # factor_graph.py:272 (`weight[:, masks[pi, qi]] = 0`) without the host sync of a boolean-mask assignment.
-        # target / weight are rewritten IN PLACE: their addresses only change with the edge set, so a captured HIP graph of
-        # consecutive iterations chains through them (iteration k+1 reads what iteration k wrote) and the steady state
-        # allocates nothing
-        if "mask" not in P:
-            P["mask"] = buf.masks[P["pi"], P["qi"]][None, ..., None]
-        if not self.weight.is_contiguous() or not self.target.is_contiguous():
-            self.weight, self.target = self.weight.contiguous(), self.target.contiguous()
-        torch.add(coords1[None], dw[None, ..., 0:2], out=self.target)
-        self.weight.copy_(dw[None, ..., 2:4])
-        self.weight.masked_fill_(P["mask"], 0.0)
-        self.damping[P["du"]] = eta
+        # factor_graph.py:270-276 in one launch: target = coords1 + delta, weight with masked frames zeroed
+        # (`weight[:, masks[pi, qi]] = 0` without the host sync of a boolean-mask assignment), damping[du] = eta.
+        # target / weight are rewritten IN PLACE: their addresses only change with the edge set, so consecutive
+        # iterations chain through them and the steady state allocates nothing
+        slam_ext.update_finish(coords1, dw, P["mask"], self.target, self.weight, eta, P["du"], self.damping)
         if use_inactive:
             # factor_graph.py:296-304.  The selection of inactive edges and its multiview expansion only change with
             # the edge sets (or t0): cached in the edge plan, so the steady-state iteration has no boolean-mask
@@ -367,7 +393,7 @@ class FactorGraph:
             if key not in P:
                 h = self.host_edges()
                 sel_h = np.flatnonzero((h["ii_inac"] >= t0 - 3) & (h["jj_inac"] >= t0 - 3))  # host mirror: no read-back
-                sel = torch.from_numpy(sel_h).to(self.device)
+                sel = upload(sel_h, self.device)
                 ii = torch.cat([self.ii_inac[sel], self.ii], 0)
                 jj = torch.cat([self.jj_inac[sel], self.jj], 0)
                 V = buf.n_views
@@ -376,8 +402,23 @@ class FactorGraph:
                 P[key] = (ii, jj, sel_exp, self._shift_plan(buf.expand_edge_multiview(ii, jj)[:5], base))
             ii, jj, sel_exp, plan = P[key]
             plan_key = (self._plan_serial, "inac", t0)
-            target = torch.cat([self.target_inac.index_select(1, sel_exp), self.target], 1)
-            weight = torch.cat([self.weight_inac.index_select(1, sel_exp), self.weight], 1)
+            # [selected inactive | active] targets / weights live in ONE buffer per edge set: the inactive part is
+            # gathered once (it never changes), self.target / self.weight are views of the tail that the iteration
+            # rewrites in place - the reference concatenates both every call (factor_graph.py:300-304)
+            ckey = ("comb", t0)
+            if ckey not in P:
+                n_sel = int(sel_exp.shape[0])
+                comb = tuple(torch.empty((1, n_sel + E_act) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+                             for x in (self.target, self.weight))
+                comb[0][:, :n_sel] = self.target_inac.index_select(1, sel_exp)
+                comb[1][:, :n_sel] = self.weight_inac.index_select(1, sel_exp)
+                P[ckey] = (comb, n_sel)
+            comb, n_sel = P[ckey]
+            if self.target.data_ptr() != comb[0][:, n_sel:].data_ptr():
+                comb[0][:, n_sel:] = self.target
+                comb[1][:, n_sel:] = self.weight
+                self.target, self.weight = comb[0][:, n_sel:], comb[1][:, n_sel:]
+            target, weight = comb
         else:
             ii, jj, target, weight = self.ii, self.jj, self.target, self.weight
             if "ba_plan" not in P:  # cached expand_edge_multiview of the edge set, relative to the oldest keyframe used
@@ -390,8 +431,8 @@ class FactorGraph:
         buf.bundle_adjustment(target.view(E, -1, 2), weight.view(E, -1, 2), self.damping, ii, jj, t0,
                               t1 if not fixed_motion else t0, itrs, 1e-3, 0.1, motion_only, limited_disp, False, False,
                               plan=plan, ba_state=getattr(self, "_ba_state", None), plan_key=plan_key)
-        self.age += 1
-        if getattr(self, "_h", None) is not None and self._h["age"].shape[0] == self.age.shape[0]:
+        self._age_lag += 1
+        if getattr(self, "_h", None) is not None and self._h["age"].shape[0] == self._age.shape[0]:
             self._h["age"] += 1
 
     @torch.no_grad()
@@ -449,15 +490,15 @@ class FactorGraph:
                     iis, jjs = self.ii, self.jj
                     take = lambda x, dim=0: x  # noqa: E731
                 else:
-                    idx = torch.from_numpy(sel).to(self.device)
+                    idx = upload(sel, self.device)
                     idx_x = (idx[:, None] * V + torch.arange(V, device=self.device)).view(-1) if V > 1 else idx
                     iis, jjs = self.ii[idx], self.jj[idx]
                     take = lambda x, dim=0: x.index_select(dim, idx_x)  # noqa: E731
                 pis, qis, dis, pjs, qjs, djs = buf.expand_edge_multiview(iis, jjs)
                 dis_np = (ii_np[sel][:, None] * V + np.arange(V)).reshape(-1)
                 du_np, dixs_np = np.unique(dis_np, return_inverse=True)
-                du = torch.from_numpy(du_np).to(self.device)
-                dixs = torch.from_numpy(dixs_np.astype(np.int64)).to(self.device)
+                du = upload(du_np, self.device)
+                dixs = upload(dixs_np.astype(np.int64), self.device)
                 n = sel.shape[0] * V
                 c1 = take(coords1)
                 if use_volume:

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .._lib import upload
 from ..ext import droid_net_ext
 from ..ext.scatter import scatter_mean
 
@@ -143,7 +144,7 @@ class CorrPool:
     def _take(self, k, device):
         ids = [self._free.pop(0) for _ in range(k)]
         self._slots_host += ids
-        new = torch.tensor(ids, dtype=torch.int32, device=device)
+        new = upload(ids, device, torch.int32)
         self.slots = new if self.slots is None else torch.cat([self.slots, new], 0)
         return ids, new
 
@@ -174,7 +175,7 @@ class CorrPool:
             self.blocked = lv[0].dim() == 7
         self._reserve(k, lambda cap: [(cap,) + tuple(l.shape[1:]) for l in lv], lv[0].dtype, lv[0].device)
         ids, _ = self._take(k, lv[0].device)
-        idt = torch.tensor(ids, dtype=torch.long, device=lv[0].device)
+        idt = upload(ids, lv[0].device)
         for p, l in zip(self.pool, lv):
             p.index_copy_(0, idt, l)
         return self
@@ -189,7 +190,7 @@ class CorrPool:
         gone = set(self._slots_host) - set(kept)
         self._free += sorted(gone)
         self._slots_host = kept
-        self.slots = torch.tensor(kept, dtype=torch.int32, device=self.pool[0].device)
+        self.slots = upload(kept, self.pool[0].device, torch.int32)
         return self
 
     @property

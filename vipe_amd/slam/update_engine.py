@@ -25,7 +25,10 @@ import os
 
 import torch
 
-from .._lib import check, lib, ptr, stream_ptr
+from .._lib import check, lib, parse_struct, ptr, stream_ptr
+
+UpdateWeights = parse_struct("vipe_update_weights")   # include/vipe_amd.h: field order / types come from the header
+UpdateBuffers = parse_struct("vipe_update_buffers")
 
 ACT = {"none": 0, "relu": 1, "sigmoid": 2, "tanh": 3}
 EPI = {"plain": 0, "glo": 1, "zr": 2, "q": 3, "heads": 4, "eta": 5}
@@ -108,6 +111,16 @@ class UpdateEngine:
         self.glo_w = torch.cat([g.convz_glo.weight, g.convr_glo.weight, g.convq_glo.weight], 0).detach().to(d).float() \
             .reshape(384, 128).t().contiguous()
         self.glo_b = torch.cat([g.convz_glo.bias, g.convr_glo.bias, g.convq_glo.bias], 0).detach().to(d).float()
+        # descriptor of all of the above for the natively sequenced operator (vipe_update_operator)
+        wd_ = UpdateWeights()
+        for name, pk in dict(corr0=self.corr0, corr2=self.corr2, flow0=self.flow0, flow2=self.flow2, gw=self.gw, zr=self.zr,
+                             q=self.q, heads0=self.heads0, heads2=self.heads2, agg2=self.agg2, eta=self.eta).items():
+            setattr(wd_, name + "_w", pk.packed.data_ptr())
+            setattr(wd_, name + "_b", pk.bias.data_ptr())
+        wd_.zr_s_w, wd_.q_s_w = self.zr_s.packed.data_ptr(), self.q_s.packed.data_ptr()
+        wd_.glo_wT, wd_.glo_b = self.glo_w.data_ptr(), self.glo_b.data_ptr()
+        self._wdesc = wd_
+        self._bdesc = {}
 
     # ------------------------------------------------------------------ launches
     def _conv(self, pk, x0, x0_coff, B, H, W, y=None, y_coff=0, act="none", mode="plain", x1=None, x1_coff=0,
@@ -147,13 +160,17 @@ class UpdateEngine:
 
     @torch.no_grad()
     def forward_nhwc(self, net, xbuf, corr, motn, ix=None, n_src=None, net_out=None, want_upmask=False, csr=None,
-                     pgate=None):
+                     pgate=None, native=True):
         """The operator on channels-last state.
 
         net  [E,h,w,128] f16 hidden state;  xbuf [E,h,w,320] f16 with the context features `inp` in channels
         [0,128) (channels [128,320) are scratch, overwritten);  corr [E,h,w,200] f16 (196 + zero pad);
         motn [E,h,w,4] f16;  ix [E] int64 -> source slot.  Returns (net' [E,h,w,128] f16, dw [E,h,w,4] f32 =
-        (delta_x, delta_y, weight_x, weight_y), eta [n_src,h,w] f32 or None, upmask or None)."""
+        (delta_x, delta_y, weight_x, weight_y), eta [n_src,h,w] f32 or None, upmask or None).
+
+        `native` (default): ONE library call sequences the whole operator (`vipe_update_operator`); native=False issues
+        the same kernels one by one from here - the instrumentable form (bench.py brackets single launches with events),
+        checked equal to the native one by tests/test_gpu_parity.py."""
         E, H, W, _ = net.shape
         c1 = self._buf("c1", (E, H, W, 128))
         f1 = self._buf("f1", (E, H, W, 128))
@@ -164,6 +181,9 @@ class UpdateEngine:
         glo = self._buf("glo", (E, 128), torch.float32)
         if net_out is None:
             net_out = torch.empty_like(net)
+        if native:
+            return self._forward_native(net, xbuf, corr, motn, ix, n_src, net_out, want_upmask, csr, pgate,
+                                        (c1, f1, zb, rnet, hbuf, dw, glo))
         # encoders (droid_net.py:481-482).  `corr` may be a deferred lookup ("lookup", levels, coords): lookup and the
         # first 1x1 convolution then run as ONE kernel and the [E,h,w,200] tensor never exists
         if isinstance(corr, tuple):
@@ -178,7 +198,9 @@ class UpdateEngine:
         # global context (droid_net.py:392-393) and its three 1x1s (a [E,128] x [128,384] product)
         glo.zero_()
         self._conv(self.gw, net, 0, E, H, W, mode="glo", net=net, fout=glo)
-        extra = torch.addmm(self.glo_b, glo, self.glo_w, alpha=1.0 / (H * W))  # [E,384] fp32
+        extra = self._buf("extra", (E, 384), torch.float32)
+        check(lib().vipe_glo_context(ptr(glo), ptr(self.glo_w), ptr(self.glo_b), ptr(extra), E, H * W, stream_ptr(glo)),
+              "glo_context")  # [E,128] x [128,384] + bias, / HW
         # gates (droid_net.py:395-399)
         if pgate is not None:  # context part precomputed (gate_context): 320 input channels, accumulators start at it
             self._conv(self.zr_s, net, 0, E, H, W, x1=xbuf, x1_coff=128, split=128, y=zb, y2=rnet, net=net, mode="zr",
@@ -205,12 +227,59 @@ class UpdateEngine:
             check(lib().vipe_segment_mean_nhwc_f16(ptr(hbuf), 384, 256, ptr(order), ptr(rowptr), ptr(agg), n_src, H * W,
                                                    128, stream_ptr(hbuf)), "segment_mean")
             a2 = self._buf("a2", (n_src, H, W, 128))
-            eta = torch.empty((n_src, H, W), dtype=torch.float32, device=self.device)
+            eta = self._buf("eta", (n_src, H, W), torch.float32)
             self._conv(self.agg2, agg, 0, n_src, H, W, y=a2, act="relu")
             self._conv(self.eta, a2, 0, n_src, H, W, mode="eta", fout=eta)
             if want_upmask:
                 upmask = torch.empty((n_src, H, W, 576), dtype=torch.float16, device=self.device)
                 self._conv(self.upmask, a2, 0, n_src, H, W, y=upmask)
+        return net_out, dw, eta, upmask
+
+    def _forward_native(self, net, xbuf, corr, motn, ix, n_src, net_out, want_upmask, csr, pgate, scratch):
+        c1, f1, zb, rnet, hbuf, dw, glo = scratch
+        E, H, W, _ = net.shape
+        extra = self._buf("extra", (E, 384), torch.float32)
+        eta = agg = a2 = order = rowptr = None
+        if ix is not None:
+            if n_src is None:  # the reference syncs here too (scatter.py:40: int(index.max()) + 1)
+                n_src = int(ix.max().item()) + 1 if ix.numel() else 0
+            if csr is None:
+                csr = segment_csr(ix, n_src)
+            order, rowptr = csr
+            agg = self._buf("agg", (n_src, H, W, 128))
+            a2 = self._buf("a2", (n_src, H, W, 128))
+            eta = self._buf("eta", (n_src, H, W), torch.float32)  # persistent: callers consume it before the next call
+        lookup = isinstance(corr, tuple)
+        tensors = (net, net_out, xbuf, motn, pgate, c1, f1, zb, rnet, hbuf, dw, glo, extra, order, rowptr, agg, a2, eta) + \
+            ((tuple(corr[1]) + (corr[2],) + ((corr[3],) if len(corr) > 3 else ())) if lookup else (corr,))
+        key = tuple(0 if t is None else t.data_ptr() for t in tensors) + (E, H, W, n_src or 0)
+        b = self._bdesc.get(key)
+        if b is None:
+            if len(self._bdesc) > 16:
+                self._bdesc.clear()
+            b = UpdateBuffers()
+            b.E, b.H, b.W, b.n_src = E, H, W, int(n_src or 0) if ix is not None else 0
+            if lookup:
+                lv = corr[1]
+                for i in range(4):
+                    b.levels[i] = lv[i].data_ptr()
+                b.coords = corr[2].data_ptr()
+                b.slots = corr[3].data_ptr() if len(corr) > 3 and corr[3] is not None else None
+                b.h2, b.w2 = int(lv[2].shape[3]) << 2, int(lv[2].shape[4]) << 2
+                b.pyramid_layout = 1 if lv[0].dim() == 7 else 0
+            else:
+                b.corr = corr.data_ptr()
+            for name, t in dict(motn=motn, net=net, net_out=net_out, xbuf=xbuf, pgate=pgate, c1=c1, f1=f1, zb=zb, rnet=rnet,
+                                hbuf=hbuf, dw=dw, glo=glo, extra=extra, order=order, rowptr=rowptr, agg=agg, a2=a2,
+                                eta=eta).items():
+                setattr(b, name, None if t is None else t.data_ptr())
+            self._bdesc[key] = b
+        check(lib().vipe_update_operator(ctypes.addressof(self._wdesc), ctypes.addressof(b), stream_ptr(net)),
+              "update_operator")
+        upmask = None
+        if want_upmask and ix is not None:
+            upmask = torch.empty((n_src, H, W, 576), dtype=torch.float16, device=self.device)
+            self._conv(self.upmask, a2, 0, n_src, H, W, y=upmask)
         return net_out, dw, eta, upmask
 
     # ------------------------------------------------------------------ reference-shaped entry point
@@ -242,4 +311,4 @@ class UpdateEngine:
         n_src = eta.shape[0]
         if upmask is not None:
             upmask = upmask.permute(0, 3, 1, 2).reshape(batch, n_src, 576, ht, wd)
-        return net_out, delta, weight, eta.view(batch, n_src, ht, wd), upmask
+        return net_out, delta, weight, eta.clone().view(batch, n_src, ht, wd), upmask
