@@ -1746,8 +1746,9 @@ __global__ __launch_bounds__(TILE) void ba_schur_kernel(BAArgs a) {
 // factorisation's critical path)
 __device__ __forceinline__ double rsqrt_nr(double x) {
   double r = __builtin_amdgcn_rsq(x);
-  r = r * (1.5 - 0.5 * x * r * r);
-  r = r * (1.5 - 0.5 * x * r * r);
+  const double hx = 0.5 * x;
+  r = r * __builtin_fma(-hx * r, r, 1.5);
+  r = r * __builtin_fma(-hx * r, r, 1.5);
   return r;
 }
 
@@ -2142,7 +2143,7 @@ __global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds
 // Sets info[5] = 2 when it solved the system.
 constexpr int DN_T = 512;
 
-__global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_doubles) {
+__global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_doubles, int dbg) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* const L = reinterpret_cast<double*>(smem_raw);
   const vipe_ba_params& prm = a.p;
@@ -2153,7 +2154,7 @@ __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_
   const int NP = (n + 1) * (n + 2) / 2;  // packed size incl. the rhs row
   // info[5] == 1: the band solver (which resets the flag whenever it runs) solved THIS iteration.  A 2 can only be this
   // kernel's own mark from the previous Gauss-Newton iteration of the call (ba_sens_kernel clears the flag per call).
-  if (n == 0 || w.info[5] == 1 || a.mv || NP + 64 + n > lds_doubles || F > 2) return;
+  if (n == 0 || w.info[5] == 1 || a.mv || NP + 64 + n > lds_doubles || F > 2 || n > 192) return;
   double* const blk = L + NP;   // 6x7: the current diagonal factor block
   double* const rd = blk + 42;  // its reciprocal pivots
   int* const failp = reinterpret_cast<int*>(rd + 6);
@@ -2162,17 +2163,26 @@ __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_
   const double* S = w.S;
   const int ld = w.ld;
   if (t == 0) *failp = 0;
-  // ---- load with LM damping on the diagonal (matrix.py:179-186): one row per wave and pass, lanes over the columns
+  long long tprev = dbg ? wall_clock64() : 0, tacc[6] = {0, 0, 0, 0, 0, 0};
+#define DN_STAMP(i) if (dbg && t == 0) { const long long tn = wall_clock64(); tacc[i] += tn - tprev; tprev = tn; }
+  // ---- load with LM damping on the diagonal (matrix.py:179-186): one row per wave and pass, lanes over the columns;
+  //      unrolled so that eight rows (x up to 4 column passes) are in flight per wave - the loop is otherwise one L2
+  //      round trip per row
   {
     const int wv = t >> 6, ln = t & 63;
-    for (int r = wv; r <= n; r += DN_T / 64) {
-      for (int c = ln; c <= r && c < n; c += 64) {
-        double v = S[(int64_t)r * ld + c];
-        if (c == r) {
-          const bool pose = r < npr;
-          v += (pose ? (double)prm.pose_ep : 1e-6) + (pose ? (double)prm.pose_damping : 1e-6) * (a.droid ? v : w.Hd[r]);
+    const int passes = (n + 63) >> 6;
+    for (int cp = 0; cp < passes; ++cp) {
+      const int c = cp * 64 + ln;
+#pragma unroll 8
+      for (int r = wv; r <= n; r += DN_T / 64) {
+        if (c <= r && c < n) {
+          double v = S[(int64_t)r * ld + c];
+          if (c == r) {
+            const bool pose = r < npr;
+            v += (pose ? (double)prm.pose_ep : 1e-6) + (pose ? (double)prm.pose_damping : 1e-6) * (a.droid ? v : w.Hd[r]);
+          }
+          L[off(r) + c] = v;
         }
-        L[off(r) + c] = v;
       }
     }
   }
@@ -2189,7 +2199,7 @@ __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_
     for (int j = 0; j < 6; ++j) {
       double d = A[j][j];
 #pragma unroll
-      for (int m = 0; m < j; ++m) d -= A[j][m] * A[j][m];
+      for (int m = 0; m < j; ++m) d = __builtin_fma(-A[j][m], A[j][m], d);
       if (!(d > 0.0)) { *failp = 1; d = 1.0; }
       const double rl = rsqrt_nr(d);
       A[j][j] = d * rl;
@@ -2199,7 +2209,7 @@ __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_
       for (int i = j + 1; i < 6; ++i) {
         double sacc = A[i][j];
 #pragma unroll
-        for (int m = 0; m < j; ++m) sacc -= A[i][m] * A[j][m];
+        for (int m = 0; m < j; ++m) sacc = __builtin_fma(-A[i][m], A[j][m], sacc);
         A[i][j] = sacc * rl;
       }
     }
@@ -2212,8 +2222,10 @@ __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_
       }
   };
   __syncthreads();
+  DN_STAMP(0)
   if (t == 0) factor_diag(0);
   __syncthreads();
+  DN_STAMP(1)
   for (int kb = 0; kb < nblk; ++kb) {
     const int j0 = 6 * kb, bw = min(6, n - j0), R0 = j0 + bw;
     // panel: rows R0..n (row n = rhs)
@@ -2226,7 +2238,7 @@ __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_
         for (int j = 0; j < 6; ++j) {
           double sacc = j < bw ? row[j] : 0.0;
 #pragma unroll
-          for (int m = 0; m < j; ++m) sacc -= x[m] * blk[j * 7 + m];
+          for (int m = 0; m < j; ++m) sacc = __builtin_fma(-x[m], blk[j * 7 + m], sacc);
           x[j] = sacc * rd[j];
         }
 #pragma unroll
@@ -2235,6 +2247,7 @@ __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_
       }
     }
     __syncthreads();
+    DN_STAMP(2)
     const int nbw = min(6, n - R0);  // width of the next diagonal block
     if (t < 64) {
       // wave 0: the next diagonal block's entries (i, j), j <= i < nbw, then its factorisation by lane 0
@@ -2246,74 +2259,113 @@ __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_
           double sacc = 0.0;
 #pragma unroll
           for (int m = 0; m < 6; ++m)
-            if (m < bw) sacc += pa[m] * pb[m];
+            if (m < bw) sacc = __builtin_fma(pa[m], pb[m], sacc);
           L[off(R0 + i) + R0 + j] -= sacc;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       if (t == 0 && kb + 1 < nblk) factor_diag(kb + 1);
+      DN_STAMP(5)
     } else {
-      // waves 1..7: rows r >= R0, columns R0 <= c <= min(r, n - 1), without the next diagonal block
+      // waves 1..7: rows r >= R0 + nbw (the rows of the next diagonal block belong to wave 0), columns R0 <= c <= min(r, n - 1).
+      // Four columns per pass: their operands are fetched together and the four dot products are independent chains
+      // (a dependent fp64 op costs ~40 cycles on this part; LDS stores would otherwise order the loads of the next column)
       const int u = t - 64, rr = u >> 4, cc = u & 15;  // 28 x 16
-      for (int r = R0 + rr; r <= n; r += 28) {
+      for (int r = R0 + nbw + rr; r <= n; r += 28) {
         const double* pa = L + off(r) + j0;
         double xr[6];
 #pragma unroll
         for (int m = 0; m < 6; ++m) xr[m] = m < bw ? pa[m] : 0.0;
         double* drow = L + off(r);
         const int cmax = min(r, n - 1);
-        for (int c = R0 + cc; c <= cmax; c += 16) {
-          if (r < R0 + nbw) continue;  // c <= r < R0 + nbw: an entry of the next diagonal block (wave 0 owns it)
-          const double* pb = L + off(c) + j0;
-          double sacc = 0.0;
+        for (int c0 = R0 + cc; c0 <= cmax; c0 += 64) {
+          double pb[4][6], dv[4];
 #pragma unroll
-          for (int m = 0; m < 6; ++m)
-            if (m < bw) sacc += xr[m] * pb[m];
-          drow[c] -= sacc;
+          for (int q = 0; q < 4; ++q) {
+            const int c = min(c0 + 16 * q, cmax);
+            const double* pbq = L + off(c) + j0;
+#pragma unroll
+            for (int m = 0; m < 6; ++m) pb[q][m] = m < bw ? pbq[m] : 0.0;
+            dv[q] = drow[c];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            double sacc = dv[q];
+#pragma unroll
+            for (int m = 0; m < 6; ++m) sacc = __builtin_fma(-xr[m], pb[q][m], sacc);
+            dv[q] = sacc;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (c0 + 16 * q <= cmax) drow[c0 + 16 * q] = dv[q];
         }
       }
     }
     __syncthreads();
+    DN_STAMP(3)
   }
   // ---- back substitution L^T x = y (y = row n), wave 0, column oriented: once x of block kb is known every lane
   //      subtracts its columns' contributions from y
   double* y = L + off(n);
   if (t < 64) {
+    // operands that do not depend on the running y - the block factor, its reciprocal pivots and this lane's columns of
+    // the six block rows - are fetched one block AHEAD, so that only y sits on the dependent chain
+    double Lk[6][6], rp[6], lc[3][6];
+    auto fetch_block = [&](int kb) {
+      const int j0 = 6 * kb, bw = min(6, n - j0);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        rp[i] = i < bw ? rdall[j0 + i] : 0.0;
+#pragma unroll
+        for (int j = 0; j < i; ++j) Lk[i][j] = i < bw ? L[off(j0 + i) + j0 + j] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int c = t + 64 * q;
+          lc[q][i] = (i < bw && c < j0) ? L[off(j0 + i) + c] : 0.0;
+        }
+      }
+    };
+    fetch_block(nblk - 1);
     for (int kb = nblk - 1; kb >= 0; --kb) {
       const int j0 = 6 * kb, bw = min(6, n - j0);
       double x[6];
 #pragma unroll
       for (int j = 5; j >= 0; --j) {
-        double sacc = 0.0;
-        if (j < bw) {
-          sacc = y[j0 + j];
+        double sacc = j < bw ? y[j0 + j] : 0.0;
 #pragma unroll
-          for (int m = 5; m > j; --m)
-            if (m < bw) sacc -= L[off(j0 + m) + j0 + j] * x[m];
-          sacc *= rdall[j0 + j];
-        }
-        x[j] = sacc;
+        for (int m = 5; m > j; --m) sacc = __builtin_fma(-Lk[m][j], x[m], sacc);
+        x[j] = sacc * rp[j];
       }
-      __builtin_amdgcn_wave_barrier();
+      double dy[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        dy[q] = lc[q][0] * x[0];
+#pragma unroll
+        for (int j = 1; j < 6; ++j) dy[q] = __builtin_fma(lc[q][j], x[j], dy[q]);
+      }
       if (t < bw) {
         double xo = x[0];
 #pragma unroll
         for (int j = 1; j < 6; ++j) xo = t == j ? x[j] : xo;
         y[j0 + t] = xo;
       }
-      for (int c = t; c < j0; c += 64) {
-        double sacc = 0.0;
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
-          if (j < bw) sacc += L[off(j0 + j) + c] * x[j];
-        y[c] -= sacc;
+      for (int q = 0; q < 3; ++q) {
+        const int c = t + 64 * q;
+        if (c < j0) y[c] -= dy[q];
       }
+      if (kb > 0) fetch_block(kb - 1);  // independent of y: overlaps the y round trip above
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
   }
   __syncthreads();
+  DN_STAMP(4)
+  if (dbg && t == 0)
+    printf("[ba_solve_dense n=%d] load %lld diag0 %lld panel %lld lookahead %lld wait-for-update %lld backsub %lld (x10ns)\n", n,
+           tacc[0], tacc[1], tacc[2], tacc[5], tacc[3], tacc[4]);
+#undef DN_STAMP
   const bool bad = *failp != 0;
   if (t == 0) {
     if (bad) w.info[2] += 1;
@@ -2717,7 +2769,7 @@ int run_iters(const BAArgs& a, hipStream_t s) {
     }
     if (a.force_simple == 1) ba_accum_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
     if (!(hint & 8)) ba_solve_band_kernel<<<1, BAND_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)));
-    if (!(hint & 16)) ba_solve_dense_kernel<<<1, DN_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)));
+    if (!(hint & 16)) ba_solve_dense_kernel<<<1, DN_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)), getenv("VIPE_BA_DEBUG_TIMING") ? 1 : 0);
     if (!(hint & 4)) ba_solve_kernel<<<1, SOLVE_T, solve_lds, s>>>(a, panel_cap, getenv("VIPE_BA_DEBUG_TIMING") ? (long long*)(a.w.Hd + nmax) : nullptr);
     if (!a.p.motion_only) ba_retract_kernel<F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
   }
