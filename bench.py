@@ -231,7 +231,7 @@ class Dist:
 
 
 # ---------------------------------------------------------------------------------------------- video clips
-def make_clip_runner(device, features=False):
+def make_clip_runner(device, features=False, pipelined=True):
     """-> run_clip(seed, n_frames, with_backend) -> dict.  One DroidNet (random-init weights, no checkpoint offline) is
     shared by all clips of this rank; every clip gets a fresh buffer / frontend (per-clip isolation, run.py:17-26)."""
     from vipe_amd.slam.buffer import GraphBuffer
@@ -241,6 +241,7 @@ def make_clip_runner(device, features=False):
     torch.manual_seed(0)
     dn = DroidNet()
     um = dn.update
+    side_stream = torch.cuda.Stream(device=device)
 
     def run_clip(seed, n_frames, with_backend=False):
         buf = GraphBuffer(384, 512, buffer_size=n_frames + 16, device=device)
@@ -262,19 +263,44 @@ def make_clip_runner(device, features=False):
             mf = MotionFilter(dn, thresh=0.0, device=device)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(n_frames):
-            t = buf.n_frames
-            if features:
+        if features:
+            for _ in range(n_frames):
+                t = buf.n_frames
                 buf.fmaps[t, 0], buf.nets[t, 0], buf.inps[t, 0] = pool_f[t % 32], pool_n[t % 32], pool_i[t % 32]
-            else:
-                keep = mf.check(pool_img[t % 32], None)
+                if t < fe.args.warmup:  # until the frontend owns the poses: smooth trajectory along x
+                    buf.poses[t, 0] = 0.05 * t
+                    buf.disps[t, 0] = pool_d[t % 32]
+                buf.n_frames += 1
+                fe.run()
+        else:
+            # Two-stage pipeline, as a streaming system runs it: the motion filter of frame f+1 (feature encoder + one
+            # operator application, which depend only on the last keyframe's features) is enqueued on a side stream
+            # BEFORE the frontend optimises keyframe f on the main stream, and its score is collected afterwards.  The
+            # frontend's single-workgroup solves and small grids leave most of the chip idle; the filter fills it.
+            main = torch.cuda.current_stream()
+            side = side_stream if pipelined else None
+            if side is not None:
+                side.wait_stream(main)
+            h = mf.begin(pool_img[0], None, stream=side)
+            for f in range(n_frames):
+                keep = mf.finish(h)
                 assert keep, "threshold 0 keeps every frame"
+                t = buf.n_frames
+                if side is not None:
+                    main.wait_stream(side)  # the keyframe's features were produced on the side stream
                 buf.fmaps[t], buf.nets[t], buf.inps[t] = mf.f_fmap, mf.f_net, mf.f_inp
-            if t < fe.args.warmup:  # until the frontend owns the poses: smooth trajectory along x
-                buf.poses[t, 0] = 0.05 * t
-                buf.disps[t, 0] = pool_d[t % 32]
-            buf.n_frames += 1
-            fe.run()
+                if side is not None:
+                    for x in (mf.f_fmap, mf.f_net, mf.f_inp):
+                        x.record_stream(main)
+                if t < fe.args.warmup:  # until the frontend owns the poses: smooth trajectory along x
+                    buf.poses[t, 0] = 0.05 * t
+                    buf.disps[t, 0] = pool_d[t % 32]
+                buf.n_frames += 1
+                if f + 1 < n_frames:
+                    h = mf.begin(pool_img[(f + 1) % 32], None, stream=side)
+                fe.run()
+            if side is not None:
+                main.wait_stream(side)
         torch.cuda.synchronize()
         t_fe = time.perf_counter() - t0
         backend_edges = None
@@ -307,7 +333,7 @@ def video_mode(args, D):
 
     dev, world, rank = D.device, D.world, D.rank
     D.init()
-    run_clip = make_clip_runner(dev, features=args.video_features)
+    run_clip = make_clip_runner(dev, features=args.video_features, pipelined=not args.no_pipeline)
     run_clip(seed=10_000 + rank, n_frames=24)  # untimed warm-up clip: code objects, workspaces, allocator pools
     n_clips = args.clips or world
     stats = []
@@ -348,7 +374,9 @@ def video_mode(args, D):
                                                                "keyframes", "edges_final", "backend_edges", "finite")},
                        "rank0_seconds_to_gather_end": t_gather_end - t0,
                        "input": "feature maps (encoders skipped)" if args.video_features else
-                                "RGB frames: motion filter + feature / context encoders in the timed region"}}))
+                                "RGB frames: motion filter + feature / context encoders in the timed region"
+                                + ("" if args.no_pipeline else "; two-stage pipeline: the filter of frame f+1 runs on a side "
+                                   "stream while the frontend optimises keyframe f")}}))
     D.close()
 
 
@@ -462,7 +490,8 @@ def secondary_figures(args, device, graph, step):
             "state_finite": r["finite"],
             "what": "one synthetic 512x384 clip from RGB frames resident in HBM, every frame a keyframe: motion filter + "
                     "encoders + proximity edges + 4+2 update iterations per keyframe (whole clip incl. the 8-keyframe "
-                    "initialisation); with_global_ba adds backend.run(7) + backend.run(24)"}
+                    "initialisation), the filter of frame f+1 on a side stream while the frontend optimises keyframe f; "
+                    "with_global_ba adds backend.run(7) + backend.run(24)"}
     except Exception as e:  # noqa: BLE001
         out["frames_per_s"] = f"failed: {type(e).__name__}: {e}"
     _log("secondary: video done")
@@ -653,6 +682,9 @@ def main():
     ap.add_argument("--with-backend", action="store_true",
                     help="video mode: after the frontend pass also run the two global-BA passes of SLAMSystem.run "
                          "(backend.run(7), backend.run(24): system.py:272-275) inside the timed region")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="video mode: run the motion filter of every frame on the main stream, strictly before the "
+                         "frontend step (no overlap of frame f+1's filter with keyframe f's optimisation)")
     ap.add_argument("--video-features", action="store_true",
                     help="video mode: feed seeded feature maps instead of RGB frames (skips motion filter + encoders)")
     args = ap.parse_args()

@@ -60,7 +60,7 @@ class MotionFilter:
         self.f_net, self.f_inp, self.f_fmap = net, inp, gmap
         self.f_mask = buffer_masks
         V, _, ht, wd = net.shape
-        eng = self.net.update.engine(net.device)
+        eng = self._engine(net.device)
         # channels-last state of the keyframe side of the one-iteration flow estimate, prepared once per keyframe
         self._net_nhwc = net.permute(0, 2, 3, 1).contiguous()
         self._xbuf = torch.empty((V, ht, wd, 320), dtype=torch.float16, device=net.device)
@@ -73,29 +73,72 @@ class MotionFilter:
     def check(self, images, buffer_masks=None):
         """images [V,3,H,W] fp32 RGB in [0,1] on the device; buffer_masks [V,h,w] bool (True = invalid) or None.
         Returns True when the frame is to become a keyframe (its features are then in f_fmap / f_net / f_inp)."""
+        return self.finish(self.begin(images, buffer_masks))
+
+    @torch.no_grad()
+    def begin(self, images, buffer_masks=None, stream=None):
+        """First half of `check`: feature encoder + one flow-update application against the last keyframe, the score on
+        its way to pinned host memory - everything is ENQUEUED (on `stream`, default the current one), nothing is
+        waited for.  A pipeline that filters frame t+1 on a side stream while the frontend optimises keyframe t on the
+        main stream calls begin(t+1) before `frontend.run()` and finish(...) after it: the filter only depends on the
+        last keyframe's features, which `finish(t)` has already installed."""
         require(not (self.sparse_tracks is not None and getattr(self.sparse_tracks, "enabled", False)),
                 "sparse tracks are outside the dense path")
-        x4 = normalize_images(images)
-        gmap = self.net.encode_features(images, x4)
-        if not self.initialized:
-            self._set_keyframe(images, x4, gmap, buffer_masks)
-            self.current_frame_idx = 0
-            self.last_kf_frame_idx = 0
-            self.initialized = True
-            return True
-        self.current_frame_idx += 1
-        eng = self.net.update.engine(gmap.device)
-        corr = CorrBlock(self.f_fmap[None], gmap[None]).lookup_deferred(self._coords0)
-        _, dw, _, _ = eng.forward_nhwc(self._net_nhwc, self._xbuf, corr, self._motn0, pgate=self._pgate)
-        dense_flow = dw[..., 0:2].half().float().norm(dim=-1)  # fp16 head output, norm in fp32 (autocast rules)
-        if self.f_mask is not None:
-            f_weight = (~self.f_mask).float()
-            score = (dense_flow * f_weight).mean([1, 2]) / (f_weight.mean([1, 2]) + 1e-6)
-        else:
-            score = dense_flow.mean([1, 2])
-        self.last_score = score.min().item()
-        if self.last_score > self.thresh:
-            self._set_keyframe(images, x4, gmap, buffer_masks)
-            self.last_kf_frame_idx = self.current_frame_idx
-            return True
+        ctx = torch.cuda.stream(stream) if stream is not None else _null_ctx()
+        with ctx:
+            x4 = normalize_images(images)
+            gmap = self.net.encode_features(images, x4)
+            h = dict(images=images, x4=x4, gmap=gmap, masks=buffer_masks, stream=stream, score=None, event=None)
+            if self.initialized:
+                eng = self._engine(gmap.device)
+                corr = CorrBlock(self.f_fmap[None], gmap[None]).lookup_deferred(self._coords0)
+                _, dw, _, _ = eng.forward_nhwc(self._net_nhwc, self._xbuf, corr, self._motn0, pgate=self._pgate)
+                dense_flow = dw[..., 0:2].half().float().norm(dim=-1)  # fp16 head output, norm in fp32 (autocast rules)
+                if self.f_mask is not None:
+                    f_weight = (~self.f_mask).float()
+                    score = (dense_flow * f_weight).mean([1, 2]) / (f_weight.mean([1, 2]) + 1e-6)
+                else:
+                    score = dense_flow.mean([1, 2])
+                host = torch.empty((), dtype=torch.float32, pin_memory=True)
+                host.copy_(score.min(), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                h["score"], h["event"] = host, ev
+        return h
+
+    @torch.no_grad()
+    def finish(self, h):
+        """Second half of `check`: wait for the score (the filter's stream only), decide, and on a keyframe run the
+        context encoder and install the frame as the new reference (on the same stream as `begin`)."""
+        ctx = torch.cuda.stream(h["stream"]) if h["stream"] is not None else _null_ctx()
+        with ctx:
+            if not self.initialized:
+                self._set_keyframe(h["images"], h["x4"], h["gmap"], h["masks"])
+                self.current_frame_idx = 0
+                self.last_kf_frame_idx = 0
+                self.initialized = True
+                return True
+            self.current_frame_idx += 1
+            h["event"].synchronize()
+            self.last_score = float(h["score"])
+            if self.last_score > self.thresh:
+                self._set_keyframe(h["images"], h["x4"], h["gmap"], h["masks"])
+                self.last_kf_frame_idx = self.current_frame_idx
+                return True
+            return False
+
+    def _engine(self, device):
+        """The filter's own execution engine of the update operator: private scratch buffers and descriptors, so that
+        a filter running on a side stream never shares them with the factor graph's iterations on the main stream."""
+        if getattr(self, "_eng", None) is None or self._eng.device != device:
+            from .update_engine import UpdateEngine
+            self._eng = UpdateEngine(self.net.update, device)
+        return self._eng
+
+
+class _null_ctx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
         return False
