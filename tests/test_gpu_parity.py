@@ -840,6 +840,27 @@ def test_dense_ba_dense_window_takes_lds_dense_solver():
         assert np.abs(k - ok_).max() <= 1e-4 * np.abs(ok_).max()
 
 
+@pytest.mark.parametrize("intr", [False, True])
+def test_dense_ba_large_dense_system_takes_tiled_cholesky(intr):
+    """The global BA's reduced systems (hundreds of coupled poses): 64 x 64 tiled Cholesky spread over the chip (potrf in
+    one wave's registers + tile inverse, trsm / syrk on the fp64 matrix cores, rhs row riding along, tiled back
+    substitution).  n = 414 (+1 with the focal length: a one-column last tile... 415 = 6 x 64 + 31), loop-closure-like
+    long-range edges, against the fp64 oracle."""
+    g = make_graph(n=70, height=96, width=128, radius=3, extra_edges=260, seed=101)
+    bk = dict(t0=1, t1=70, n_iters=2, pose_damping=1e-5, pose_ep=1e-2, motion_only=False, limited_disp=False,
+              optimize_intrinsics=intr)
+    p, d, k, info = run_hip_ba(g, g.intrinsics, "pinhole", bk)
+    E = len(g.ii)
+    op, od, ok_, _ = oba.bundle_adjustment(g.poses, g.disps[:, None], g.disps_sens[:, None], g.intrinsics,
+                                           ose3.se3_identity(1), g.target.reshape(E, -1, 2), g.weight.reshape(E, -1, 2),
+                                           g.eta[:, None], g.ii, g.jj, **bk)
+    assert info[0] == 69 and info[3] == 414 + int(intr) and info[2] == 0 and info[5] == 0
+    assert np.abs(p - op).max() <= 1e-4 * max(1.0, np.abs(op).max()), np.abs(p - op).max()
+    assert np.abs(d - od[:, 0]).max() <= 1e-4 * np.abs(od).max()
+    assert np.abs(k - ok_).max() <= 1e-4 * np.abs(ok_).max()
+    assert np.abs(p - g.poses).max() > 1e-4
+
+
 def test_dense_ba_non_banded_graph_takes_global_memory_solver():
     """Long-range (loop-closure-like) edges make the reduced system dense: it no longer fits the LDS band solver and
     the blocked global-memory Cholesky (fp64 MFMA trailing update) must give the same answer as the fp64 oracle."""

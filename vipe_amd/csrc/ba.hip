@@ -47,6 +47,7 @@ struct BAWs {
   double* S;        // [(nmax+1),(nmax+1)] lower triangle + rhs row
   double* Hd;       // [nmax] undamped diagonal of H (for lambda * diag)
   float* dx;        // [nmax]
+  double* Wi;       // [ceil(nmax / 64)][64][64] inverses of the diagonal factor tiles (tiled Cholesky)
   int* krow;        // [nF] DROID mode: row of frame k in the sorted unique set arange(t0,t1) U ii (eta / dz row)
   int ld;           // nmax + 1
 };
@@ -108,6 +109,7 @@ size_t carve(const vipe_ba_params& p, char* base, BAWs* out) {
   w.S = (double*)take(8 * (nmax + 1) * (nmax + 1));
   w.Hd = (double*)take(8 * (nmax + 16));  // + 16 debug stamp slots
   w.dx = (float*)take(4 * nmax);
+  w.Wi = (double*)take(8 * 64 * 64 * ((nmax + 63) / 64));
   w.krow = (int*)take(4 * (nF + 1));
   w.ld = (int)(nmax + 1);
   if (out) *out = w;
@@ -2393,6 +2395,7 @@ __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_
 //        32-byte row segments.
 //   Then blocked backward substitution L^T x = y and the pose / intrinsics retraction.
 constexpr int NB = 12;
+constexpr int CT_MIN_N = 256;  // larger systems take the tiled, chip-wide factorisation further down
 constexpr int SOLVE_T = 512;  // 8 waves: up to 256 VGPRs per lane, no spills in the register-resident phases
 
 struct SolveLds {
@@ -2418,7 +2421,7 @@ __global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_c
   long long tacc[5] = {0, 0, 0, 0, 0};
 #define STAMP(i) if (dbg && t == 0) { long long tn = wall_clock64(); tacc[i] += tn - tprev; tprev = tn; }
   if (t == 0) sh.fail = 0;
-  if (n == 0 || w.info[5] != 0) return;  // an LDS solver (band: 1, dense: 2) took the system
+  if (n == 0 || w.info[5] != 0 || n > CT_MIN_N) return;  // an LDS solver (band: 1, dense: 2) took the system; large ones: tiled
   // LM damping on the diagonal: += ep + lambda * diag(H)  (matrix.py:179-186)
   for (int dd = t; dd < n; dd += SOLVE_T) {
     // poses: the caller's (lambda, ep); intrinsics 1e-6 / 1e-6; rig rotations 1e-4 / 1e-4 (buffer.py:466,498,503)
@@ -2656,6 +2659,330 @@ __global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_c
   apply_retraction(a, t, SOLVE_T, n_free);
 }
 
+// ------------------------------------------------------------------------------------------------ solve (tiled, chip wide)
+//
+// The global BA's reduced systems (n = 600 ... 1200+ unknowns, dense: every keyframe pair may couple) are bound in the
+// single-workgroup kernel above by ~n/12 block steps of dependent fp64 chains and L2 round trips on ONE CU (2.1 ms at
+// n = 1200).  Here the factorisation is tiled 64 x 64 and spread over the chip, three launches per tile column k:
+//   chol_potrf_kernel  one workgroup: wave 0 factors the diagonal tile in registers (lane = row, right-looking: pivot
+//                      by readlane, rsqrt from an fp32 seed + one fp64 Newton step, rank-1 update with the column
+//                      broadcast lane by lane), then the workgroup inverts the factor (16 x 16 diagonal blocks by
+//                      substitution, off-diagonal blocks level by level) and leaves L^-1 in the workspace;
+//   chol_trsm_kernel   one workgroup per tile row below: X = A L^-T as a 64^3 product on the fp64 matrix cores;
+//   chol_syrk_kernel   one workgroup per tile pair (i >= j > k): A_ij -= X_i X_j^T, same tiles, same cores.
+// Row n (the rhs) rides along as a row of the last tile row, so the forward substitution is part of the factorisation;
+// chol_backsub_kernel (one workgroup) then solves L^T x = y tile column by tile column with the stored inverses and
+// retracts.  LM damping is added by potrf when it loads its tile (the trailing updates only subtract from later tiles,
+// so the order is immaterial).  A dependent fp64 operation costs ~40 cycles on this part: the pivot chain alone is
+// ~0.15 us per column - the floor of any Cholesky here - which is why the diagonal tile stays in one wave's registers.
+constexpr int CT = 64;
+
+__device__ __forceinline__ double rsqrt_seeded(double x) {
+  // branch free (the callers are long fully unrolled blocks): pivots of a damped normal matrix are far inside the float
+  // range; should one not be, the seed is clamped and the two Newton steps still converge from within a factor 2^64
+  const float xf = fminf(fmaxf((float)x, 1e-30f), 1e30f);
+  double r = (double)__builtin_amdgcn_rsqf(xf);  // 23 bits
+  const double hx = 0.5 * x;
+  r = r * __builtin_fma(-hx * r, r, 1.5);          // ~45 bits
+  r = r * __builtin_fma(-hx * r, r, 1.5);          // full fp64
+  return r;
+}
+
+__device__ __forceinline__ bool chol_active(const BAArgs& a, int& n) {
+  n = a.w.info[3];
+  return n > CT_MIN_N && a.w.info[5] == 0;
+}
+
+__global__ __launch_bounds__(256) void chol_potrf_kernel(BAArgs a, int k, int dbg) {
+  int n;
+  if (!chol_active(a, n)) return;
+  long long ts0 = dbg ? wall_clock64() : 0, ts1 = 0, ts2 = 0, ts3 = 0;
+  const int c0 = CT * k;
+  if (c0 >= n) return;
+  const int bw = min(CT, n - c0);
+  const BAWs& w = a.w;
+  const vipe_ba_params& prm = a.p;
+  const int ld = w.ld, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  double* S = w.S;
+  __shared__ double Ls[CT][CT + 1];   // the factor tile (lower), identity beyond bw
+  __shared__ double Li[CT][CT + 1];   // its inverse (lower)
+  __shared__ int fail;
+  if (t == 0) fail = 0;
+  if (k == 0 && t == 0) w.info[7] = 0;  // failure flag of this factorisation
+  __syncthreads();
+  // the tile travels global <-> LDS with all 256 threads (row segments, coalesced); wave 0 then takes one row per lane
+  for (int i = t; i < CT * CT; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    Ls[r][c] = (r < bw && c <= r) ? S[(int64_t)(c0 + r) * ld + c0 + c] : (c == r ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int r = lane;
+    const int n_free = w.info[0];
+    double arow[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) arow[c] = Ls[r][c];
+    // the last tile column of a system with n % 64 != 0 shares its tile row with the rhs (row n = c0 + bw): lane bw carries
+    // it through the factorisation as one more row below the diagonal (its own "diagonal" entry is a dummy 1)
+    const bool rhs_lane = bw < CT && c0 + bw == n && r == bw;
+    if (rhs_lane) {
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+        if (c < bw) arow[c] = S[(int64_t)n * ld + c0 + c];
+    }
+    if (r < bw) {  // LM damping (matrix.py:179-186): poses (lambda, ep); intrinsics 1e-6; rig rotations 1e-4
+      const int g = c0 + r;
+      const bool pose = g < 6 * n_free, rigrow = a.mv && g >= 6 * n_free + a.nintr;
+      const double ep = pose ? (double)prm.pose_ep : (rigrow ? 1e-4 : 1e-6);
+      const double lam = pose ? (double)prm.pose_damping : (rigrow ? 1e-4 : 1e-6);
+      const double hd = a.droid ? 0.0 : w.Hd[g];
+#pragma unroll
+      for (int c = 0; c < CT; ++c)  // compile-time indices only: a runtime index would move the row to scratch memory
+        if (c == r) arow[c] += ep + lam * (a.droid ? arow[c] : hd);
+    }
+    // Right-looking, one column per step: the pivot by readlane (compile-time lane), the finished column published to
+    // LDS and read back by every lane as BROADCAST reads (one address per instruction: no bank conflicts) - a
+    // v_readlane per (row, column) pair instead costs ~85 cycles each through the SGPR file.  Fully unrolled, so the
+    // scheduler can slide the rank-1 update of step j under the dependent pivot chain of step j + 1.
+    double* colb = &Li[0][0];  // scratch: two column buffers of 64 doubles (Li is not in use yet)
+    bool bad = false;
+    double d = readlane_f64(arow[0], 0);
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+      const bool okp = d > 0.0;
+      bad |= (j < bw) & !okp;
+      d = okp ? d : 1.0;
+      const double rl = rsqrt_seeded(d);
+      const double lj = r == j ? d * rl : (r > j ? arow[j] * rl : 0.0);
+      arow[j] = lj;
+      // the NEXT pivot only needs lane j + 1's own entry of this column: form it now, ahead of the LDS round trip that
+      // the rest of the rank-1 update waits for (the dependent chain per column is then rsqrt -> mul -> fma -> readlane)
+      if (j + 1 < CT) {
+        arow[j + 1] = __builtin_fma(-lj, readlane_f64(lj, j + 1) , arow[j + 1]);
+        d = readlane_f64(arow[j + 1], j + 1);
+      }
+      double* cb = colb + (j & 1) * CT;
+      cb[r] = lj;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = j + 2; c < CT; ++c) {
+        arow[c] = __builtin_fma(-lj, cb[c], arow[c]);
+        // at most 16 column values in flight (the row itself holds 128 VGPRs): LDS reads may not cross, everything else
+        // may - the tail of this rank-1 update is meant to slide under the next step's pivot chain
+        if (((c - j) & 15) == 0) __builtin_amdgcn_sched_barrier(0x027E);
+      }
+    }
+    if (dbg) ts1 = wall_clock64();
+    if (bad) fail = 1;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      Ls[r][c] = r < bw ? (c <= r ? arow[c] : 0.0) : (c == r ? 1.0 : 0.0);
+      if (rhs_lane && c < bw) S[(int64_t)n * ld + c0 + c] = arow[c];
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < CT * CT; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    if (r < bw && c <= r) S[(int64_t)(c0 + r) * ld + c0 + c] = Ls[r][c];
+  }
+  if (dbg) ts2 = wall_clock64();
+  // ---- inverse of the factor tile.  (1) the four 16 x 16 diagonal blocks, one thread per column: forward substitution
+  if (t < 64) {
+    const int b = t >> 4, cc = t & 15, o = 16 * b;
+    double x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      double sacc = i == cc ? 1.0 : 0.0;
+#pragma unroll
+      for (int m = 0; m < 16; ++m)
+        if (m < i) sacc = __builtin_fma(-Ls[o + i][o + m], (m >= cc ? x[m] : 0.0), sacc);
+      x[i] = i >= cc ? sacc / Ls[o + i][o + i] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Li[o + i][o + cc] = x[i];
+  }
+  for (int i = t; i < CT * CT; i += 256) {  // zero the strictly upper part and the off-diagonal blocks (filled below)
+    const int r = i >> 6, c = i & 63;
+    if ((r >> 4) != (c >> 4)) Li[r][c] = 0.0;
+  }
+  __syncthreads();
+  // (2) off-diagonal blocks by distance d = 1..3: Linv(i,j) = -Dinv_i * sum_{m=j}^{i-1} L(i,m) Linv(m,j)
+  __shared__ double Tm[3][16][17];
+  for (int d = 1; d < 4; ++d) {
+    const int nblk = 4 - d;  // blocks (i = j + d, j), j = 0..nblk-1
+    for (int e = t; e < nblk * 256; e += 256) {
+      const int bj = e >> 8, rr = (e >> 4) & 15, cc = e & 15, bi = bj + d;
+      double sacc = 0.0;
+      for (int m = 16 * bj; m < 16 * bi; ++m) sacc = __builtin_fma(Ls[16 * bi + rr][m], Li[m][16 * bj + cc], sacc);
+      Tm[bj][rr][cc] = sacc;
+    }
+    __syncthreads();
+    for (int e = t; e < nblk * 256; e += 256) {
+      const int bj = e >> 8, rr = (e >> 4) & 15, cc = e & 15, bi = bj + d;
+      double sacc = 0.0;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) sacc = __builtin_fma(Li[16 * bi + rr][16 * bi + m], Tm[bj][m][cc], sacc);
+      Li[16 * bi + rr][16 * bj + cc] = -sacc;
+    }
+    __syncthreads();
+  }
+  double* Wk = w.Wi + (int64_t)k * CT * CT;
+  for (int i = t; i < CT * CT; i += 256) Wk[i] = Li[i >> 6][i & 63];
+  if (t == 0 && fail) w.info[7] = 1;
+  if (dbg && t == 0 && k == 1) { ts3 = wall_clock64(); printf("[chol_potrf] load+factor %lld store %lld inverse %lld (x10ns)\n", ts1 - ts0, ts2 - ts1, ts3 - ts2); }
+}
+
+typedef double double4c __attribute__((ext_vector_type(4)));
+
+// X = A L^-T for the tile rows below tile k; grid = tile rows (exits beyond the matrix)
+__global__ __launch_bounds__(256) void chol_trsm_kernel(BAArgs a, int k) {
+  int n;
+  if (!chol_active(a, n)) return;
+  const int c0 = CT * k, R0 = CT * (k + 1 + blockIdx.x);
+  if (c0 >= n || R0 > n) return;
+  const BAWs& w = a.w;
+  const int ld = w.ld, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int bw = min(CT, n - c0), nr = min(CT, n + 1 - R0);  // rows R0 .. R0 + nr - 1 (row n = rhs)
+  __shared__ double As[CT][CT + 2];  // pitch 66 doubles: the 16 x 4 operand fragments of a wave spread over all banks
+  __shared__ double Ls[CT][CT + 2];
+  const double* Wk = w.Wi + (int64_t)k * CT * CT;
+  for (int i = t; i < CT * CT; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    As[r][c] = (r < nr && c < bw) ? w.S[(int64_t)(R0 + r) * ld + c0 + c] : 0.0;
+    Ls[r][c] = Wk[i];
+  }
+  __syncthreads();
+  // wave w: rows 16 w .. 16 w + 15; X[r][c] = sum_m A[r][m] Linv[c][m]
+  const int l16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int tc = 0; tc < 4; ++tc) {
+    double4c acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[16 * wave + l16][4 * s4 + kq], Ls[16 * tc + l16][4 * s4 + kq], acc, 0, 0, 0);
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int rr = 16 * wave + kq + 4 * r4, cc = 16 * tc + l16;
+      if (rr < nr && cc < bw) w.S[(int64_t)(R0 + rr) * ld + c0 + cc] = acc[r4];
+    }
+  }
+}
+
+// A_ij -= X_i X_j^T for all tile pairs k < j <= i; grid.x = pairs of the largest possible matrix (extra blocks exit)
+__global__ __launch_bounds__(256) void chol_syrk_kernel(BAArgs a, int k) {
+  int n;
+  if (!chol_active(a, n)) return;
+  const int c0 = CT * k;
+  if (c0 >= n) return;
+  int ti = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
+  while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ++ti;
+  while (ti * (ti + 1) / 2 > (int)blockIdx.x) --ti;
+  const int tj = blockIdx.x - ti * (ti + 1) / 2;
+  const int Ri = CT * (k + 1 + ti), Rj = CT * (k + 1 + tj);
+  if (Ri > n || Rj >= n) return;  // row tile must hold a row <= n, column tile a column < n
+  const BAWs& w = a.w;
+  const int ld = w.ld, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int bw = min(CT, n - c0), nri = min(CT, n + 1 - Ri), ncj = min(CT, n - Rj);
+  __shared__ double Xi[CT][CT + 2];
+  __shared__ double Xj[CT][CT + 2];
+  for (int i = t; i < CT * CT; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    Xi[r][c] = (r < nri && c < bw) ? w.S[(int64_t)(Ri + r) * ld + c0 + c] : 0.0;
+    Xj[r][c] = (r < ncj && c < bw) ? w.S[(int64_t)(Rj + r) * ld + c0 + c] : 0.0;
+  }
+  __syncthreads();
+  const int l16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int tc = 0; tc < 4; ++tc) {
+    double4c acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xi[16 * wave + l16][4 * s4 + kq], Xj[16 * tc + l16][4 * s4 + kq], acc, 0, 0, 0);
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int rr = 16 * wave + kq + 4 * r4, cc = 16 * tc + l16;
+      if (rr < nri && cc < ncj && Rj + cc <= Ri + rr) w.S[(int64_t)(Ri + rr) * ld + Rj + cc] -= acc[r4];
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void chol_backsub_kernel(BAArgs a) {
+  int n;
+  if (!chol_active(a, n)) return;
+  const BAWs& w = a.w;
+  const int ld = w.ld, t = threadIdx.x, n_free = w.info[0];
+  __shared__ double Li[2][CT][CT + 1];
+  __shared__ double xk[CT];
+  extern __shared__ __align__(16) double ys[];  // [n]: the running right-hand side stays in LDS
+  for (int i = t; i < n; i += 512) ys[i] = w.S[(int64_t)n * ld + i];
+  const int Tc = (n + CT - 1) / CT;
+  auto load_tile = [&](int k, int b) {
+    const double* Wk = w.Wi + (int64_t)k * CT * CT;
+    for (int i = t; i < CT * CT; i += 512) Li[b][i >> 6][i & 63] = Wk[i];
+  };
+  load_tile(Tc - 1, (Tc - 1) & 1);
+  __syncthreads();
+  for (int k = Tc - 1; k >= 0; --k) {
+    const int c0 = CT * k, bw = min(CT, n - c0), b = k & 1;
+    // x = L^-T y: x[c] = sum_{m >= c} Linv[m][c] y[m]; 8 lanes per column, combined by DPP-free shuffles
+    {
+      const int c = t >> 3, part = t & 7;
+      double sacc = 0.0;
+      if (c < bw)
+        for (int m = c + part; m < bw; m += 8) sacc = __builtin_fma(Li[b][m][c], ys[c0 + m], sacc);
+      sacc += __shfl_xor(sacc, 1, 8);
+      sacc += __shfl_xor(sacc, 2, 8);
+      sacc += __shfl_xor(sacc, 4, 8);
+      if (part == 0 && c < bw) xk[c] = sacc;
+    }
+    if (k > 0) load_tile(k - 1, b ^ 1);  // next tile's inverse: independent of x
+    __syncthreads();
+    if (t < bw) ys[c0 + t] = xk[t];
+    for (int c = t; c < c0; c += 512) {  // y[c] -= sum_r L[c0 + r][c] x[r]
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      const double* col = w.S + (int64_t)c0 * ld + c;
+#pragma unroll 4
+      for (int r = 0; r + 3 < bw; r += 4) {
+        s0 = __builtin_fma(col[(int64_t)r * ld], xk[r], s0);
+        s1 = __builtin_fma(col[(int64_t)(r + 1) * ld], xk[r + 1], s1);
+        s2 = __builtin_fma(col[(int64_t)(r + 2) * ld], xk[r + 2], s2);
+        s3 = __builtin_fma(col[(int64_t)(r + 3) * ld], xk[r + 3], s3);
+      }
+      for (int r = bw & ~3; r < bw; ++r) s0 = __builtin_fma(col[(int64_t)r * ld], xk[r], s0);
+      ys[c] -= (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+  }
+  const bool bad = w.info[7] != 0;
+  if (t == 0 && bad) w.info[2] += 1;
+  for (int dd = t; dd < n; dd += 512) {
+    double x = ys[dd];
+    if (bad || !(x == x)) x = 0.0;  // zero step on a failed factorisation
+    w.dx[dd] = (float)x;
+  }
+  __syncthreads();
+  apply_retraction(a, t, 512, n_free);
+}
+
+// host side: the launches of one tiled solve, sized for the largest system the workspace can hold (blocks beyond the
+// actual n exit at once; n itself lives on the device)
+inline void launch_tiled_cholesky(const BAArgs& a, hipStream_t s) {
+  const int nmax = a.w.ld - 1;
+  if (nmax <= CT_MIN_N || nmax > 8000) return;  // (the back substitution keeps the rhs, up to 8000 doubles, in LDS)
+  const int T = (nmax + 1 + CT - 1) / CT;  // tile rows incl. the rhs row
+  const int Tc = (nmax + CT - 1) / CT;
+  for (int k = 0; k < Tc; ++k) {
+    chol_potrf_kernel<<<1, 256, 0, s>>>(a, k, getenv("VIPE_BA_DEBUG_TIMING") ? 1 : 0);
+    const int m = T - 1 - k;
+    if (m > 0) {
+      chol_trsm_kernel<<<m, 256, 0, s>>>(a, k);
+      chol_syrk_kernel<<<m * (m + 1) / 2, 256, 0, s>>>(a, k);
+    }
+  }
+  chol_backsub_kernel<<<1, 512, sizeof(double) * (size_t)(nmax + 8), s>>>(a);
+}
+
 // ------------------------------------------------------------------------------------------------ retract
 
 template <int F>
@@ -2738,6 +3065,7 @@ int run_iters(const BAArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)ba_solve_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ba_solve_dense_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)chol_backsub_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   }
   (void)hipFuncSetAttribute((const void*)ba_accum_mfma_kernel<CAM, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_mfma_lds());
   (void)hipFuncSetAttribute((const void*)ba_walk_kernel<CAM, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds());
@@ -2757,6 +3085,7 @@ int run_iters(const BAArgs& a, hipStream_t s) {
       ba_walk_rig_kernel<CAM><<<dim3(tiles, a.nF), TILE, walk_rig_lds(), s>>>(a);
       ba_schur_kernel<0><<<dim3(SC_GRID, a.nF), TILE, 0, s>>>(a);
       ba_solve_kernel<<<1, SOLVE_T, solve_lds, s>>>(a, panel_cap, nullptr);
+      launch_tiled_cholesky(a, s);
       if (!a.p.motion_only) ba_retract_kernel<0><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
       continue;
     }
@@ -2770,7 +3099,10 @@ int run_iters(const BAArgs& a, hipStream_t s) {
     if (a.force_simple == 1) ba_accum_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
     if (!(hint & 8)) ba_solve_band_kernel<<<1, BAND_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)));
     if (!(hint & 16)) ba_solve_dense_kernel<<<1, DN_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)), getenv("VIPE_BA_DEBUG_TIMING") ? 1 : 0);
-    if (!(hint & 4)) ba_solve_kernel<<<1, SOLVE_T, solve_lds, s>>>(a, panel_cap, getenv("VIPE_BA_DEBUG_TIMING") ? (long long*)(a.w.Hd + nmax) : nullptr);
+    if (!(hint & 4)) {
+      ba_solve_kernel<<<1, SOLVE_T, solve_lds, s>>>(a, panel_cap, getenv("VIPE_BA_DEBUG_TIMING") ? (long long*)(a.w.Hd + nmax) : nullptr);
+      launch_tiled_cholesky(a, s);
+    }
     if (!a.p.motion_only) ba_retract_kernel<F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
   }
   return vipe_launch_status();

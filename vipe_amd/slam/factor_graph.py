@@ -456,78 +456,97 @@ class FactorGraph:
         # first pass and kept for the others while all of them fit VIPE_AMD_BACKEND_VOLUME_GB (default 160 of 288 GB).
         vol_bytes = self.ii.shape[0] * V * (self.ht * self.wd) ** 2 * 2 * (1 + 1 / 4 + 1 / 16 + 1 / 64)
         keep_vols = use_volume and steps > 1 and vol_bytes <= float(os.environ.get("VIPE_AMD_BACKEND_VOLUME_GB", "160")) * 2**30
+        # The reference walks the source keyframes in groups of 8 (factor_graph.py:337-343) to bound memory.  The
+        # operator couples edges only through GraphAgg's per-source-frame mean, so ANY partition that keeps every
+        # source frame's edges together gives the same result: with 288 GB of HBM the groups are merged until a
+        # chunk holds up to VIPE_AMD_BACKEND_CHUNK_EDGES edges (default 1024, ~34 GB of pyramids) - normally one chunk.
+        # Edge indices come from the host mirror; chunks are selected with index vectors, not masks.
+        h_ = self.host_edges()
+        ii_np, jj_np = h_["ii"], h_["jj"]
+        assert jj_np.max() >= ii_np.max()
+        E_all = ii_np.shape[0]
+        max_edges = int(os.environ.get("VIPE_AMD_BACKEND_CHUNK_EDGES", "1024"))
+        cnt = np.bincount(ii_np)
+        groups, cur, cur_n = [], [], 0
+        for g0 in range(0, len(cnt), 8):  # the reference's groups of 8 source frames are the merge unit
+            n8 = int(cnt[g0:g0 + 8].sum())
+            if n8 == 0:
+                continue
+            if cur and cur_n + n8 > max_edges:
+                groups.append(cur)
+                cur, cur_n = [], 0
+            cur.append(g0)
+            cur_n += n8
+        if cur:
+            groups.append(cur)
+        # Everything about a chunk that does not change during the `steps` passes is prepared once: index vectors, the
+        # source-node CSR, the frame masks, the context features in the operator's input buffer and - like the
+        # frontend does per edge - the context-feature part of the GRU gates (19 % of the operator's FLOPs per pass)
+        chunks = {}
+
+        def chunk(gi):
+            c = chunks.get(gi)
+            if c is not None:
+                return c
+            sel = np.flatnonzero(np.isin(ii_np // 8 * 8, groups[gi]))
+            c = dict(whole=sel.shape[0] == E_all)
+            if c["whole"]:
+                iis, jjs = self.ii, self.jj
+                c["idx_x"] = None
+            else:
+                idx = upload(sel, self.device)
+                c["idx_x"] = (idx[:, None] * V + torch.arange(V, device=self.device)).view(-1) if V > 1 else idx
+                iis, jjs = self.ii[idx], self.jj[idx]
+            pis, qis, dis, pjs, qjs, djs = buf.expand_edge_multiview(iis, jjs)
+            dis_np = (ii_np[sel][:, None] * V + np.arange(V)).reshape(-1)
+            du_np, dixs_np = np.unique(dis_np, return_inverse=True)
+            c.update(pis=pis, qis=qis, dis=dis, pjs=pjs, qjs=qjs, djs=djs, n=sel.shape[0] * V, n_src=int(du_np.shape[0]),
+                     du=upload(du_np, self.device), dixs=upload(dixs_np.astype(np.int64), self.device),
+                     mask=buf.masks[pis, qis].contiguous())
+            order_h = np.argsort(dixs_np, kind="stable").astype(np.int32)
+            rowptr_h = np.concatenate([[0], np.cumsum(np.bincount(dixs_np, minlength=c["n_src"]))]).astype(np.int32)
+            c["csr"] = (upload(order_h, self.device, torch.int32), upload(rowptr_h, self.device, torch.int32))
+            xb = torch.empty((c["n"], self.ht, self.wd, 320), dtype=torch.half, device=self.device)
+            xb[..., 0:128] = buf.inps[pis, qis].permute(0, 2, 3, 1)
+            c["xb"] = xb
+            c["pgate"] = eng.gate_context(xb) if eng.supports_gate_split(self.ht, self.wd) else None
+            chunks[gi] = c
+            return c
+
         vols = {}
         for _ in range(steps):
             coords1, motn = slam_ext.reproject_motion_nhwc(buf.poses, buf.flattened_disps, buf.intrinsics, buf.rig,
                                                            P["pi"], P["qi"], P["pj"], P["qj"], P["di"],
                                                            self.target[0].contiguous(), camera=buf.camera_type)
-            # The reference walks the source keyframes in groups of 8 (factor_graph.py:337-343) to bound memory.  The
-            # operator couples edges only through GraphAgg's per-source-frame mean, so ANY partition that keeps every
-            # source frame's edges together gives the same result: with 288 GB of HBM the groups are merged until a
-            # chunk holds up to VIPE_AMD_BACKEND_CHUNK_EDGES edges (default 1024, ~34 GB of pyramids) - normally one chunk.
-            # Edge indices come from ONE read-back of (ii, jj); chunks are selected with index vectors, not masks.
-            ii_np, jj_np = self.ii.cpu().numpy(), self.jj.cpu().numpy()
-            assert jj_np.max() >= ii_np.max()
-            E_all = ii_np.shape[0]
-            max_edges = int(os.environ.get("VIPE_AMD_BACKEND_CHUNK_EDGES", "1024"))
-            cnt = np.bincount(ii_np)
-            groups, cur, cur_n = [], [], 0
-            for g0 in range(0, len(cnt), 8):  # the reference's groups of 8 source frames are the merge unit
-                n8 = int(cnt[g0:g0 + 8].sum())
-                if n8 == 0:
-                    continue
-                if cur and cur_n + n8 > max_edges:
-                    groups.append(cur)
-                    cur, cur_n = [], 0
-                cur.append(g0)
-                cur_n += n8
-            if cur:
-                groups.append(cur)
-            for gi, grp in enumerate(groups):
-                sel = np.flatnonzero(np.isin(ii_np // 8 * 8, grp))
-                whole = sel.shape[0] == E_all
-                if whole:
-                    iis, jjs = self.ii, self.jj
-                    take = lambda x, dim=0: x  # noqa: E731
-                else:
-                    idx = upload(sel, self.device)
-                    idx_x = (idx[:, None] * V + torch.arange(V, device=self.device)).view(-1) if V > 1 else idx
-                    iis, jjs = self.ii[idx], self.jj[idx]
-                    take = lambda x, dim=0: x.index_select(dim, idx_x)  # noqa: E731
-                pis, qis, dis, pjs, qjs, djs = buf.expand_edge_multiview(iis, jjs)
-                dis_np = (ii_np[sel][:, None] * V + np.arange(V)).reshape(-1)
-                du_np, dixs_np = np.unique(dis_np, return_inverse=True)
-                du = upload(du_np, self.device)
-                dixs = upload(dixs_np.astype(np.int64), self.device)
-                n = sel.shape[0] * V
+            for gi in range(len(groups)):
+                c = chunk(gi)
+                whole, idx_x, n = c["whole"], c["idx_x"], c["n"]
+                take = (lambda x: x) if whole else (lambda x: x.index_select(0, idx_x))  # noqa: E731
                 c1 = take(coords1)
                 if use_volume:
                     vol = vols.get(gi)
                     if vol is None:
-                        vol = CorrBlock.from_buffer(buf.flattened_fmaps, pis * V + qis, pjs * V + qjs)
+                        vol = CorrBlock.from_buffer(buf.flattened_fmaps, c["pis"] * V + c["qis"], c["pjs"] * V + c["qjs"])
                         if keep_vols:
                             vols[gi] = vol
                     corr_n = vol.lookup_deferred(c1)
-                    corr1 = None
                 else:
-                    corr1 = corr_op(c1[None], dis, djs)  # [1,n,196,h,w] fp32
+                    corr1 = corr_op(c1[None], c["dis"], c["djs"])  # [1,n,196,h,w] fp32
                     corr_n = torch.zeros((n, self.ht, self.wd, 200), dtype=torch.half, device=self.device)
                     corr_n[..., :196] = corr1[0].permute(0, 2, 3, 1)
-                xb = torch.empty((n, self.ht, self.wd, 320), dtype=torch.half, device=self.device)
-                xb[..., 0:128] = buf.inps[pis, qis].permute(0, 2, 3, 1)
-                net, dw, eta, _ = eng.forward_nhwc(take(self.net_n).contiguous(), xb, corr_n, take(motn).contiguous(),
-                                                   ix=dixs, n_src=int(du_np.shape[0]))
-                delta, weight = dw[..., 0:2], dw[..., 2:4].clone()
-                weight = weight.masked_fill(buf.masks[pis, qis].unsqueeze(-1), 0.0)
+                net, dw, eta, _ = eng.forward_nhwc(take(self.net_n).contiguous(), c["xb"], corr_n, take(motn).contiguous(),
+                                                   ix=c["dixs"], n_src=c["n_src"], csr=c["csr"], pgate=c["pgate"])
                 if whole:
                     self.net_n = net if net.data_ptr() != self.net_n.data_ptr() else net.clone()
-                    self.target[0] = c1 + delta
-                    self.weight[0] = weight
+                    if not self.weight.is_contiguous() or not self.target.is_contiguous():
+                        self.weight, self.target = self.weight.contiguous(), self.target.contiguous()
+                    slam_ext.update_finish(c1, dw, c["mask"], self.target, self.weight, eta, c["du"], self.damping)
                 else:
+                    weight = dw[..., 2:4].masked_fill(c["mask"].unsqueeze(-1), 0.0)
                     self.net_n[idx_x] = net
-                    self.target[0, idx_x] = c1 + delta
+                    self.target[0, idx_x] = c1 + dw[..., 0:2]
                     self.weight[0, idx_x] = weight
-                self.damping[du] = eta
+                    self.damping[c["du"]] = eta
             E = self.target.shape[1]
             buf.bundle_adjustment(self.target.view(E, -1, 2), self.weight.view(E, -1, 2), self.damping, self.ii, self.jj,
                                   1, t, itrs, 1e-5, 1e-2, False, False, optimize_intrinsics, optimize_rig_rotation,
