@@ -1954,7 +1954,7 @@ __device__ __forceinline__ void band_solve_body(const BAArgs& a, int lds_doubles
     for (int j = 0; j < 6; ++j) {
       double d = A[j][j];
 #pragma unroll
-      for (int m = 0; m < j; ++m) d -= A[j][m] * A[j][m];
+      for (int m = 0; m < j; ++m) d = __builtin_fma(-(A[j][m]), A[j][m], d);
       if (!(d > 0.0)) { *failp = 1; d = 1.0; }
       const double rl = rsqrt_nr(d);
       A[j][j] = d * rl;
@@ -1964,7 +1964,7 @@ __device__ __forceinline__ void band_solve_body(const BAArgs& a, int lds_doubles
       for (int i = j + 1; i < 6; ++i) {
         double sacc = A[i][j];
 #pragma unroll
-        for (int m = 0; m < j; ++m) sacc -= A[i][m] * A[j][m];
+        for (int m = 0; m < j; ++m) sacc = __builtin_fma(-(A[i][m]), A[j][m], sacc);
         A[i][j] = sacc * rl;
       }
     }
@@ -1989,7 +1989,7 @@ __device__ __forceinline__ void band_solve_body(const BAArgs& a, int lds_doubles
       for (int j = 0; j < 6; ++j) {
         double sacc = row[j];
 #pragma unroll
-        for (int m = 0; m < j; ++m) sacc -= x[m] * blk[j * 7 + m];
+        for (int m = 0; m < j; ++m) sacc = __builtin_fma(-(x[m]), blk[j * 7 + m], sacc);
         x[j] = sacc * rd[j];
       }
 #pragma unroll
@@ -2004,7 +2004,7 @@ __device__ __forceinline__ void band_solve_body(const BAArgs& a, int lds_doubles
         const double* pb = L + uB[sl] + kb * sB[sl];
         double sacc = 0.0;
 #pragma unroll
-        for (int m = 0; m < 6; ++m) sacc += pa[m] * pb[m];
+        for (int m = 0; m < 6; ++m) sacc = __builtin_fma(pa[m], pb[m], sacc);
         L[uD[sl] + kb * sD[sl]] -= sacc;
       }
     }
@@ -2079,7 +2079,7 @@ __device__ __forceinline__ void band_solve_body(const BAArgs& a, int lds_doubles
       for (int j = 5; j >= 0; --j) {
         double sacc = y[j0 + j];
 #pragma unroll
-        for (int m = 5; m > j; --m) sacc -= Lk[m][j] * x[m];
+        for (int m = 5; m > j; --m) sacc = __builtin_fma(-(Lk[m][j]), x[m], sacc);
         x[j] = sacc * rp[j];
       }
       if (t < 6) {
@@ -2091,13 +2091,13 @@ __device__ __forceinline__ void band_solve_body(const BAArgs& a, int lds_doubles
       if (upd) {
         double sacc = lc[0] * x[0];
 #pragma unroll
-        for (int j = 1; j < 6; ++j) sacc += lc[j] * x[j];
+        for (int j = 1; j < 6; ++j) sacc = __builtin_fma(lc[j], x[j], sacc);
         y[rt] -= sacc;
       }
       if (TWO && upd2) {
         double sacc = lc2[0] * x[0];
 #pragma unroll
-        for (int j = 1; j < 6; ++j) sacc += lc2[j] * x[j];
+        for (int j = 1; j < 6; ++j) sacc = __builtin_fma(lc2[j], x[j], sacc);
         y[rt2] -= sacc;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
