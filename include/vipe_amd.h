@@ -301,6 +301,15 @@ int vipe_corr_sampler_backward(const void* d_in1, const void* d_in2, const void*
                                int padH, int padW, int dilH, int dilW, int dil_patchH, int dil_patchW, int dH,
                                int dW, int dtype, void* stream);
 
+/* The same two operators over HOST memory (float32), for CPU tensors: the reference dispatches those to its CPU
+ * implementation (correlation_sampler.cpp:44-58, correlation_cpu.cpp).  grad1 / grad2 are accumulated into. */
+int vipe_corr_sampler_forward_host(const float* h_in1, const float* h_in2, float* h_out, int B, int C, int H, int W, int kH,
+                                   int kW, int patchH, int patchW, int padH, int padW, int dilH, int dilW, int dil_patchH,
+                                   int dil_patchW, int dH, int dW);
+int vipe_corr_sampler_backward_host(const float* h_in1, const float* h_in2, const float* h_grad_out, float* h_grad1,
+                                    float* h_grad2, int B, int C, int H, int W, int kH, int kW, int patchH, int patchW,
+                                    int padH, int padW, int dilH, int dilW, int dil_patchH, int dil_patchW, int dH, int dW);
+
 /* ---------------------------------------------------------------------------------------------
  * [fused] flow-update operator convolutions (UpdateModule, droid_net.py:432-499): NHWC fp16
  * implicit-GEMM convolution on MFMA, fp32 accumulate, fused bias + activation.

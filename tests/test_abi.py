@@ -93,3 +93,26 @@ def test_scatter_host_path_and_autograd():
     import pytest
     with pytest.raises(_lib.VipeError):
         scatter.scatter_sum(src.detach(), idx + 100, 1, None, 6)  # out-of-range index is an error, not a stray write
+
+
+def test_corr_ext_host_path_against_torch_autograd():
+    """corr_ext on CPU tensors (the reference has a CPU implementation, correlation_sampler.cpp:44-58): forward vs an
+    explicit torch formulation of the sampler, backward vs autograd of that formulation."""
+    import torch.nn.functional as F
+    from vipe_amd.ext import corr_ext
+    torch.manual_seed(0)
+    B, C, H, W = 2, 5, 9, 11
+    a = torch.randn(B, C, H, W, requires_grad=True)
+    b = torch.randn(B, C, H, W, requires_grad=True)
+    args = dict(kH=1, kW=1, patchH=5, patchW=5, padH=0, padW=0, dilH=1, dilW=1, dil_patchH=2, dil_patchW=1, dH=1, dW=1)
+    out = corr_ext.forward(a.detach(), b.detach(), *args.values())
+    rH, rW = args["dil_patchH"] * (args["patchH"] - 1) // 2, args["dil_patchW"] * (args["patchW"] - 1) // 2
+    bp = F.pad(b, (rW, rW, rH, rH))
+    ref = torch.stack([torch.stack([(a * bp[:, :, ph * args["dil_patchH"]:ph * args["dil_patchH"] + H,
+                                              pw * args["dil_patchW"]:pw * args["dil_patchW"] + W]).sum(1)
+                                    for pw in range(args["patchW"])], 1) for ph in range(args["patchH"])], 1)
+    assert out.shape == ref.shape == (B, 5, 5, H, W) and torch.allclose(out, ref, atol=1e-5)
+    go = torch.randn_like(ref)
+    g1, g2 = corr_ext.backward(a.detach(), b.detach(), go, *args.values())
+    r1, r2 = torch.autograd.grad(ref, (a, b), go)
+    assert torch.allclose(g1, r1, atol=1e-5) and torch.allclose(g2, r2, atol=1e-5)

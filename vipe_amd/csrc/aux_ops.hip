@@ -410,3 +410,72 @@ VIPE_EXPORT int vipe_corr_sampler_backward(const void* d_in1, const void* d_in2,
       oW, kH, kW, patchH, patchW, padH, padW, dilH, dilW, dil_patchH, dil_patchW, dH, dW);
   return vipe_launch_status();
 }
+
+// Host-memory twins of the correlation sampler for CPU tensors (the reference dispatches them to correlation_cpu.cpp:
+// correlation_sampler.cpp:44-58).  The same index arithmetic and accumulation order as the kernels above, one output
+// (forward) / one gradient sample (backward) after the other - float32 only.
+VIPE_EXPORT int vipe_corr_sampler_forward_host(const float* h_in1, const float* h_in2, float* h_out, int B, int C, int H, int W,
+                                               int kH, int kW, int patchH, int patchW, int padH, int padW, int dilH, int dilW,
+                                               int dil_patchH, int dil_patchW, int dH, int dW) {
+  VIPE_CHECK_ARG(B >= 0 && C > 0 && H > 0 && W > 0 && kH > 0 && kW > 0 && patchH > 0 && patchW > 0 && dH > 0 && dW > 0);
+  const int oH = (H + 2 * padH - ((kH - 1) * dilH + 1)) / dH + 1, oW = (W + 2 * padW - ((kW - 1) * dilW + 1)) / dW + 1;
+  const int64_t total = (int64_t)B * patchH * patchW * oH * oW;
+  if (total <= 0) return VIPE_OK;
+  VIPE_CHECK_ARG(h_in1 && h_in2 && h_out);
+  const int radH = dil_patchH * (patchH - 1) / 2, radW = dil_patchW * (patchW - 1) / 2;
+  for (int64_t i = 0; i < total; ++i) {
+    const int w = (int)(i % oW), h = (int)((i / oW) % oH);
+    const int pw = (int)((i / ((int64_t)oW * oH)) % patchW), ph = (int)((i / ((int64_t)oW * oH * patchW)) % patchH);
+    const int n = (int)(i / ((int64_t)oW * oH * patchW * patchH));
+    const int si = -padH + h * dH, sj = -padW + w * dW;
+    const int phd = ph * dil_patchH - radH, pwd = pw * dil_patchW - radW;
+    float s = 0.0f;
+    for (int a = 0; a < kH; ++a) {
+      const int i1 = si + a * dilH, i2 = i1 + phd;
+      if (i1 < 0 || i1 >= H || i2 < 0 || i2 >= H) continue;
+      for (int bq = 0; bq < kW; ++bq) {
+        const int j1 = sj + bq * dilW, j2 = j1 + pwd;
+        if (j1 < 0 || j1 >= W || j2 < 0 || j2 >= W) continue;
+        for (int c = 0; c < C; ++c)
+          s += h_in1[(((int64_t)n * C + c) * H + i1) * W + j1] * h_in2[(((int64_t)n * C + c) * H + i2) * W + j2];
+      }
+    }
+    h_out[i] = s;
+  }
+  return VIPE_OK;
+}
+
+VIPE_EXPORT int vipe_corr_sampler_backward_host(const float* h_in1, const float* h_in2, const float* h_grad_out, float* h_grad1,
+                                                float* h_grad2, int B, int C, int H, int W, int kH, int kW, int patchH,
+                                                int patchW, int padH, int padW, int dilH, int dilW, int dil_patchH,
+                                                int dil_patchW, int dH, int dW) {
+  VIPE_CHECK_ARG(B >= 0 && C > 0 && H > 0 && W > 0 && kH > 0 && kW > 0 && patchH > 0 && patchW > 0 && dH > 0 && dW > 0);
+  const int oH = (H + 2 * padH - ((kH - 1) * dilH + 1)) / dH + 1, oW = (W + 2 * padW - ((kW - 1) * dilW + 1)) / dW + 1;
+  const int64_t total = (int64_t)B * patchH * patchW * oH * oW;
+  if (total <= 0) return VIPE_OK;
+  VIPE_CHECK_ARG(h_in1 && h_in2 && h_grad_out && h_grad1 && h_grad2);  // gradients are accumulated into: caller zeroes
+  const int radH = dil_patchH * (patchH - 1) / 2, radW = dil_patchW * (patchW - 1) / 2;
+  for (int64_t i = 0; i < total; ++i) {
+    const int w = (int)(i % oW), h = (int)((i / oW) % oH);
+    const int pw = (int)((i / ((int64_t)oW * oH)) % patchW), ph = (int)((i / ((int64_t)oW * oH * patchW)) % patchH);
+    const int n = (int)(i / ((int64_t)oW * oH * patchW * patchH));
+    const int si = -padH + h * dH, sj = -padW + w * dW;
+    const int phd = ph * dil_patchH - radH, pwd = pw * dil_patchW - radW;
+    const float g = h_grad_out[i];
+    for (int a = 0; a < kH; ++a) {
+      const int i1 = si + a * dilH, i2 = i1 + phd;
+      if (i1 < 0 || i1 >= H || i2 < 0 || i2 >= H) continue;
+      for (int bq = 0; bq < kW; ++bq) {
+        const int j1 = sj + bq * dilW, j2 = j1 + pwd;
+        if (j1 < 0 || j1 >= W || j2 < 0 || j2 >= W) continue;
+        for (int c = 0; c < C; ++c) {
+          const int64_t o1 = (((int64_t)n * C + c) * H + i1) * W + j1, o2 = (((int64_t)n * C + c) * H + i2) * W + j2;
+          h_grad1[o1] += g * h_in2[o2];
+          h_grad2[o2] += g * h_in1[o1];
+        }
+      }
+    }
+  }
+  return VIPE_OK;
+}
+

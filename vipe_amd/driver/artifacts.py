@@ -4,8 +4,11 @@ compared with / consumed like the reference's outputs.  SURVEY 8(f) row 4.
   pose/<name>.npz        data [F,4,4] float32 OpenCV cam2world matrices, inds [F] frame indices (io.py:144-162)
   intrinsics/<name>.npz  data [F,4|5] float32 [fx,fy,cx,cy(,k1)], inds [F]                       (io.py:181-203)
   intrinsics/<name>_camera.txt   "<frame_idx>: <CAMERA_TYPE>" per line                            (io.py:205-214)
-Depth maps (zipped half-float EXR, io.py:250-277) need OpenEXR, which this image does not have."""
+  depth/<name>.zip       one `<frame_idx:05d>.exr` per frame: a single HALF channel `Z` (metric depth), ZIP_DEFLATED
+                         archive (io.py:250-277).  The OpenEXR bindings are absent here: the container is written and
+                         read by `vipe_amd/driver/exr.py` from the published file layout (parity unpinned)."""
 import os
+import zipfile
 
 import numpy as np
 import torch
@@ -53,6 +56,37 @@ def read_intrinsics_artifacts(path, camera_path=None):
     else:
         types = [line.split(":")[1].strip() for line in open(camera_path)]
     return inds, data, types
+
+
+def save_depth_artifacts(path, depths, inds=None):
+    """io.py:250-277: metric depth maps [F,H,W] (or an iterable of [H,W], None entries skipped) -> zipped EXR files"""
+    from .exr import write_exr_half
+    items = [(i if inds is None else int(inds[i]), d) for i, d in enumerate(depths) if d is not None]
+    if not items:
+        return
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with zipfile.ZipFile(path, "w", zipfile.ZIP_DEFLATED) as z:
+        for frame_idx, d in items:
+            d = d.detach().cpu().numpy() if torch.is_tensor(d) else np.asarray(d)
+            z.writestr(f"{frame_idx:05d}.exr", write_exr_half(d))
+
+
+def read_depth_artifacts(path):
+    """io.py:279-310 -> iterator of (frame_idx, float32 [H,W] tensor); an unreadable member yields an all-NaN map of the
+    last good size, as the reference does"""
+    from .exr import read_exr_half
+    shape = None
+    with zipfile.ZipFile(path, "r") as z:
+        for name in sorted(z.namelist()):
+            frame_idx = int(name.split(".")[0])
+            try:
+                d = read_exr_half(z.read(name))
+            except (OSError, KeyError, ValueError, zipfile.BadZipFile):
+                assert shape is not None
+                yield frame_idx, torch.full(shape, float("nan"), dtype=torch.float32)
+                continue
+            shape = d.shape
+            yield frame_idx, torch.from_numpy(d.astype(np.float32))
 
 
 def save_clip_results(out_dir, results, name_of=lambda r: f"clip_{r.clip_id:05d}"):

@@ -1,0 +1,126 @@
+"""Minimal OpenEXR scan-line codec for single-channel half-float depth maps - what ViPE's depth artifacts are
+(vipe/utils/io.py:250-300: one `Z` channel of `Imath.PixelType.HALF` per frame, written through the OpenEXR bindings
+and zipped).  The OpenEXR Python module is not available in this image, so the container format is written out here
+from the published file layout (openexr.com "OpenEXR File Layout"): magic 20000630, version 2, attribute list, one
+offset per chunk, chunks of (y, size, data).
+
+  write_exr_half: NO_COMPRESSION (1 scan line per chunk) or ZIP_COMPRESSION (16 scan lines per chunk: byte
+                  interleave + delta predictor + zlib deflate - the bindings' default) - both are standard and read by
+                  any OpenEXR implementation;
+  read_exr_half:  NONE / ZIPS / ZIP scan-line files with a HALF (or FLOAT) channel named Z.
+**Parity unpinned**: no OpenEXR implementation and no reference-written file exist here to cross-check against; the
+tests are round trips plus a byte-level check of the header fields against the layout document."""
+import struct
+import zlib
+
+import numpy as np
+
+MAGIC = 20000630
+NO_COMPRESSION, ZIPS_COMPRESSION, ZIP_COMPRESSION = 0, 2, 3
+_LINES = {NO_COMPRESSION: 1, ZIPS_COMPRESSION: 1, ZIP_COMPRESSION: 16}
+
+
+def _attr(name, typ, payload):
+    return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(payload)) + payload
+
+
+def _zip_encode(raw):
+    """OpenEXR ZIP: reorder bytes into (even | odd) halves, delta-predict, deflate"""
+    b = np.frombuffer(raw, dtype=np.uint8)
+    t = np.concatenate([b[0::2], b[1::2]]).astype(np.int16)
+    d = t.copy()
+    d[1:] = t[1:] - t[:-1] + 128
+    out = zlib.compress((d & 0xFF).astype(np.uint8).tobytes())
+    return out if len(out) < len(raw) else raw  # the format stores a chunk uncompressed when deflate does not help
+
+
+def _zip_decode(data, size):
+    if len(data) == size:
+        return data
+    d = np.frombuffer(zlib.decompress(data), dtype=np.uint8).astype(np.int64)
+    t = d.copy()
+    t[1:] = d[1:] - 128
+    t = (np.cumsum(t) & 0xFF).astype(np.uint8)
+    half = (size + 1) // 2
+    out = np.empty(size, dtype=np.uint8)
+    out[0::2] = t[:half]
+    out[1::2] = t[half:]
+    return out.tobytes()
+
+
+def write_exr_half(depth, compression=ZIP_COMPRESSION):
+    """depth [H,W] -> bytes of an OpenEXR file with one HALF channel `Z` (io.py:262-270)"""
+    z = np.ascontiguousarray(np.asarray(depth, dtype=np.float16))
+    h, w = z.shape
+    chlist = b"Z\0" + struct.pack("<iB3xii", 1, 0, 1, 1) + b"\0"  # HALF, pLinear 0, sampling 1 x 1
+    box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
+    head = struct.pack("<ii", MAGIC, 2)
+    head += _attr("channels", "chlist", chlist)
+    head += _attr("compression", "compression", struct.pack("<B", compression))
+    head += _attr("dataWindow", "box2i", box)
+    head += _attr("displayWindow", "box2i", box)
+    head += _attr("lineOrder", "lineOrder", struct.pack("<B", 0))  # increasing y
+    head += _attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+    head += _attr("screenWindowCenter", "v2f", struct.pack("<ff", 0.0, 0.0))
+    head += _attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
+    head += b"\0"
+    lines = _LINES[compression]
+    chunks = []
+    for y0 in range(0, h, lines):
+        raw = z[y0:y0 + lines].tobytes()
+        data = raw if compression == NO_COMPRESSION else _zip_encode(raw)
+        chunks.append(struct.pack("<ii", y0, len(data)) + data)
+    pos = len(head) + 8 * len(chunks)
+    table = b""
+    for c in chunks:
+        table += struct.pack("<Q", pos)
+        pos += len(c)
+    return head + table + b"".join(chunks)
+
+
+def read_exr_half(blob):
+    """bytes of a single-part scan-line OpenEXR file with a channel `Z` (HALF or FLOAT) -> float16 / float32 [H,W]"""
+    magic, version = struct.unpack_from("<ii", blob, 0)
+    if magic != MAGIC or (version & 0xFF) != 2 or (version & 0x1E00):
+        raise OSError("not a single-part scan-line OpenEXR file")
+    pos, attrs = 8, {}
+    while blob[pos] != 0:
+        e = blob.index(b"\0", pos)
+        name = blob[pos:e].decode()
+        e2 = blob.index(b"\0", e + 1)
+        typ = blob[e + 1:e2].decode()
+        (size,) = struct.unpack_from("<i", blob, e2 + 1)
+        attrs[name] = (typ, blob[e2 + 5:e2 + 5 + size])
+        pos = e2 + 5 + size
+    pos += 1
+    x0, y0, x1, y1 = struct.unpack("<iiii", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    comp = attrs["compression"][1][0]
+    if comp not in _LINES:
+        raise OSError(f"unsupported EXR compression {comp}")
+    channels, p, cl = [], 0, attrs["channels"][1]
+    while cl[p] != 0:
+        e = cl.index(b"\0", p)
+        ptype, = struct.unpack_from("<i", cl, e + 1)
+        channels.append((cl[p:e].decode(), ptype))
+        p = e + 1 + 16
+    channels.sort()
+    sizes = {0: 4, 1: 2, 2: 4}
+    zi = [c[0] for c in channels].index("Z")
+    ztype = channels[zi][1]
+    dtype = {1: np.float16, 2: np.float32}[ztype]
+    line_bytes = sum(sizes[t] * w for _, t in channels)
+    z_off = sum(sizes[t] * w for _, t in channels[:zi])
+    lines = _LINES[comp]
+    n_chunks = (h + lines - 1) // lines
+    out = np.empty((h, w), dtype=dtype)
+    for off in struct.unpack_from(f"<{n_chunks}Q", blob, pos):
+        cy, size = struct.unpack_from("<ii", blob, off)
+        nl = min(lines, y1 + 1 - cy)
+        raw = blob[off + 8:off + 8 + size]
+        if comp != NO_COMPRESSION:
+            raw = _zip_decode(raw, nl * line_bytes)
+        for li in range(nl):  # within a chunk: scan line by scan line, channels in alphabetical order
+            s = li * line_bytes + z_off
+            out[cy - y0 + li] = np.frombuffer(raw, dtype=dtype, count=w, offset=s)
+    return out
