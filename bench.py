@@ -578,11 +578,15 @@ def update_mode(args, D):
     # the launch stream; achieved = (algorithmic flops of those launches) / (their summed duration).
     eng = graph.update_op.engine(device)
     rec = []
+    recording = False
     orig = eng._conv
 
     def timed_conv(pk, x0, x0_coff, B, H, W, *a, **k):
         cin = k.get("cin") or pk.cin
-        if pk.cout > 64 and pk.kh == 3:
+        # the dominant instantiation only (conv_halo32_kernel<128, 3, true, 0>): the z|r convolution that starts from the
+        # staged fp32 partial sums is its own instantiation (<..., 1>) and rocprof row
+        staged = k.get("accinit") is not None and k["accinit"].dtype == torch.float32
+        if recording and pk.cout > 64 and pk.kh == 3 and not staged:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             orig(pk, x0, x0_coff, B, H, W, *a, **k)
@@ -595,6 +599,12 @@ def update_mode(args, D):
     # by one from Python (forward_nhwc(native=False)) so that single launches can be bracketed by events
     fwd = eng.forward_nhwc
     eng._conv, eng.forward_nhwc = timed_conv, (lambda *a, **k: fwd(*a, **dict(k, native=False)))
+    # three unrecorded steps first: the gather / host work after the timed region lets the clocks fall, and the first
+    # kernels after an idle gap run 10-50 % slower than in the timed region (kernel trace of this very command)
+    recording = False
+    for _ in range(3 if args.prof_steps else 0):
+        step()
+    recording = True
     for _ in range(args.prof_steps):
         step()
     torch.cuda.synchronize()
@@ -612,7 +622,8 @@ def update_mode(args, D):
     traffic, traffic_src = None, None
     for name in ("r02_summary.json", "r01_summary.json"):
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", name)))["void conv_halo32_kernel<128, 3, true>"]
+            prof = json.load(open(os.path.join(ROOT, "profiles", name)))
+            prof = prof.get("void conv_halo32_kernel<128, 3, true, 0>") or prof["void conv_halo32_kernel<128, 3, true>"]
             traffic = (prof["hbm_read_MB_per_launch"] + prof["hbm_write_MB_per_launch"]) * 1e6
             traffic_src = f"profiles/{name}: builder-side rocprofv3 --pmc passes of this command, not this run"
             break
@@ -640,13 +651,17 @@ def update_mode(args, D):
                        "result_gather": {"clips": len(results), "ms": gather_ms, "inside_timed_region": True,
                                          "backend": D.dist.get_backend() if D.dist.is_initialized() else "none (1 rank)"},
                        "state_finite": finite,
+                       "gate_overlap": (f"hidden-state part of the next iteration's z|r gates + global context on a second "
+                                        f"stream under the BA ({graph.gate_overlap_mode})"
+                                        if getattr(graph, "_gate_state", None) is not None else "off"),
                        "gate_context": "context-feature part of the GRU gates computed once per edge (at add_factors, "
                                        "like the correlation volume), not per iteration"
                                        if getattr(graph, "pgate", None) is not None else "recomputed every iteration"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "conv_halo32_kernel<128, 3, true> (NHWC fp16 implicit-GEMM 3x3 conv on MFMA 16x16x32, "
-                                   "all launches with Cout >= 128 of the flow-update operator)",
+                         "kernel": "conv_halo32_kernel<128, 3, true, 0> (NHWC fp16 implicit-GEMM 3x3 conv on MFMA 16x16x32: the "
+                                   "launches with Cout >= 128 of the flow-update operator on the main stream, except the "
+                                   "z|r convolution that starts from staged fp32 partial sums = instantiation <..., 1>)",
                          "avg_launch_ms": gate_ms, "flops_per_launch": flops_per_launch,
                          "launches_per_step": len(rec) // max(1, args.prof_steps)},
         }
@@ -669,7 +684,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="update mode: skip the secondary figures (all-gate-work it/s, E=768 it/s, video frames/s)")
-    ap.add_argument("--prof-steps", type=int, default=2)
+    ap.add_argument("--prof-steps", type=int, default=4)
     ap.add_argument("--mode", default="update", choices=["update", "video", "backend", "plumbing"],
                     help="update: the headline metric (update iterations/s on the 48-keyframe graph); video: frames/s "
                          "of independent synthetic clips through the keyframe frontend, clip-sharded over the ranks "

@@ -199,6 +199,16 @@ int vipe_reproject_motion_nhwc(const float* d_poses, const float* d_disps, const
  *   d_workspace: vipe_dense_ba_workspace_bytes(...) bytes, contents need not be initialised.
  *   d_info (optional, 8 ints): [n_free_poses, n_free_disp_frames, cholesky_failures, n_regular_unknowns,
  *   band width in 6x6 blocks, 1 if the LDS band solver solved the last iteration, largest source-frame degree, 0]. */
+/* Co-scheduling hook of vipe_dense_ba (optional).  Most of a Gauss-Newton iteration is the reduced-system solve: ONE
+ * workgroup busy on a 256-CU part.  A caller with independent work (FactorGraph.update: the hidden-state part of the next
+ * iteration's GRU gates, vipe_update_gate_state_piece) hands it over in `n_pieces = max(n_iters, 1)` pieces: piece k is
+ * enqueued on `overlap_stream` behind an event recorded after iteration k's accumulate kernels and a few microseconds
+ * of delay, i.e. it starts once the solve of iteration k owns its CU and fills the other 255.  overlap_fn is called on
+ * the host, from inside vipe_dense_ba, exactly n_pieces times (also when the BA has nothing to do); it must only enqueue
+ * work on the stream it is given and return VIPE_OK.  The caller orders overlap_stream after its producers before the
+ * call and joins it afterwards. */
+typedef int (*vipe_overlap_fn)(void* user, int piece, int n_pieces, void* stream);
+
 typedef struct {
   int n_poses;       /* rows of poses; disps has n_poses*n_views frames */
   int n_views;
@@ -226,6 +236,9 @@ typedef struct {
                         not made: bit 0 source degree <= 6 (matrix-core accumulate), bit 1 degree > 6 (walk + Schur),
                         bit 2 an LDS solver takes the system (the global-memory Cholesky is not launched), bit 3 the LDS
                         band solver does not take it, bit 4 the LDS dense solver does not take it. */
+  void* overlap_stream;        /* co-scheduling hook (see vipe_overlap_fn); NULL / NULL: none */
+  vipe_overlap_fn overlap_fn;
+  void* overlap_user;
 } vipe_ba_params;
 
 int64_t vipe_dense_ba_workspace_bytes(const vipe_ba_params* p);
@@ -340,7 +353,15 @@ int vipe_conv_packed_dims(int Cout, int Cin, int KH, int KW, int* cout_pad, int*
  *   3 Q       Cout = 128: y = (1 - z) * net + z * tanh(conv + bias + extra)                   (:397-399)
  *   4 HEADS   Cout = 4: fout[pixel] = (delta_x, delta_y, sigmoid(w_x), sigmoid(w_y)) as float (:486-490)
  *   5 ETA     Cout = 1: fout[pixel] = 0.01 * softplus(conv + bias)                            (:410,429)
+ *   6 PARTIAL fout[pixel, y_coff + c] (f32, row pitch y_ctot floats) = accinit + conv: the raw fp32 accumulators, no
+ *             bias / extra / activation - a partial sum over THESE input channels that a later launch over the other
+ *             channels starts from (d_accinit of that launch, mode | VIPE_CONV_ACCINIT_F32).  Cout % 4 == 0; same shape
+ *             support as d_accinit.  Used to compute the hidden-state part of the z|r gates of the NEXT update
+ *             iteration on a side stream while the dense BA of the current one leaves the chip idle.
+ * mode may be OR-ed with VIPE_CONV_ACCINIT_F32: d_accinit is then float32 [B*H*W, ai_ctot] instead of fp16.
  */
+#define VIPE_CONV_PARTIAL 6
+#define VIPE_CONV_ACCINIT_F32 0x100
 /* d_accinit (optional, fp16 [B*H*W, ai_ctot], channels [ai_coff, ai_coff + Cout)): initial value of the accumulators,
  * i.e. a precomputed partial sum over OTHER input channels (convolution is linear in its input channels).  Used to
  * hoist the context-feature part of the GRU gates, constant per edge, out of the update iteration.  Supported for
@@ -358,6 +379,8 @@ int vipe_conv2d_fused(const void* d_x0, int x0_ctot, int x0_coff, const void* d_
  * All tensors channels-last fp16 unless noted; the weight descriptors are `vipe_conv_pack_weights` outputs + fp32 biases. */
 typedef struct {
   const void *corr0_w, *corr2_w, *flow0_w, *flow2_w, *gw_w, *zr_w, *q_w, *zr_s_w, *q_s_w, *heads0_w, *heads2_w, *agg2_w, *eta_w;
+  const void *zr_n_w, *zr_x_w; /* z|r gate weights over the hidden state only [256 <- 128] and over (corr | flow) only
+                                  [256 <- 192]: the two halves of zr_s_w (vipe_update_gate_state) */
   const float *corr0_b, *corr2_b, *flow0_b, *flow2_b, *gw_b, *zr_b, *q_b, *heads0_b, *heads2_b, *agg2_b, *eta_b;
   const float* glo_wT; /* [128,384] f32: (convz_glo | convr_glo | convq_glo) weights transposed */
   const float* glo_b;  /* [384] */
@@ -382,8 +405,34 @@ typedef struct {
   const int *order, *rowptr; /* CSR of the edges by source node (vipe_segment_mean_nhwc_f16) */
   void *agg, *a2;            /* scratch [n_src,H,W,128] */
   float* eta;                /* out [n_src,H,W] f32 */
+  float* pzr;                /* optional [E,H,W,256] f32: hidden-state part of the z|r gates (vipe_update_gate_state) */
+  int gate_state;            /* 1: `extra` and `pzr` already hold the hidden-state part of the gates for `net`
+                                (vipe_update_gate_state ran on it): the operator skips the global-context stage and the
+                                z|r convolution runs over (corr | flow) only, its accumulators starting from pzr */
 } vipe_update_buffers;
 int vipe_update_operator(const vipe_update_weights* weights, const vipe_update_buffers* buffers, void* stream);
+
+/* Everything of the ConvGRU gates that depends on the hidden state ALONE, for hidden state d_net [E,H,W,128]:
+ *   extra[E,384] = the three *_glo terms (droid_net.py:392-399; uses buffers->glo as scratch),
+ *   pzr[E,H,W,256] (f32) = pgate[..., 0:256] + conv3x3(d_net; W_{z|r}[:, 0:128])   (no bias).
+ * Convolution is linear in its input channels, so the next vipe_update_operator call with gate_state = 1 gives the
+ * result of the unsplit operator up to fp32 summation order.  The point: d_net is final as soon as the operator has
+ * run, while the dense BA that follows it in an update iteration keeps one workgroup busy - issued on a second stream
+ * this stage (18 % of the operator's FLOPs) runs in the BA's shadow.  Needs buffers->pgate and buffers->pzr.
+ * parts: 1 = the global-context terms, 2 = the z|r partial sums, 3 = both. */
+int vipe_update_gate_state(const vipe_update_weights* weights, const vipe_update_buffers* buffers, const void* d_net,
+                           int parts, void* stream);
+/* The z|r partial sums (parts = 2) in pieces, with the signature of vipe_overlap_fn: piece k of n covers edges
+ * [bounds[k], bounds[k+1]) (bounds: n + 1 ascending ints from 0 to E; NULL: [E k / n, E (k+1) / n)).
+ * `user` points to a vipe_gate_state_job. */
+typedef struct {
+  const vipe_update_weights* weights;
+  const vipe_update_buffers* buffers;
+  const void* net;
+  const int* bounds;
+  int n_bounds;      /* entries of bounds (= pieces + 1); a call with another piece count falls back to the even split */
+} vipe_gate_state_job;
+int vipe_update_gate_state_piece(void* user, int piece, int n_pieces, void* stream);
 
 /* the ConvGRU's three global-context 1x1 convolutions on the pooled vector (droid_net.py:392-399):
  * extra[E,384] = bias + (glo_sum[E,128] / hw) @ wT[128,384]   (all f32) */

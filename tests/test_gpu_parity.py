@@ -1083,6 +1083,86 @@ def test_gate_context_hoisting_equals_full_gate_convolutions():
     assert (outs[0][2] - outs[1][2]).abs().max().item() < 1e-3
 
 
+def test_staged_hidden_gate_state_equals_unsplit_gates():
+    """`UpdateEngine.hidden_gate_state` (global-context terms + the hidden-state third of the z|r convolution as raw
+    fp32 accumulators, VIPE_CONV_PARTIAL) followed by the operator with `gate_state=` (z|r over the corr | flow
+    channels, accumulators starting from the fp32 partial sums) against the unsplit operator: the same sums in another
+    fp32 order, so new state, heads and eta agree to fp16 rounding of a last-bit difference; natively sequenced and
+    Python sequenced forms are bit-identical; a stale gate state (other hidden state) is ignored."""
+    from vipe_amd.slam.networks import UpdateModule
+    from vipe_amd.slam.update_engine import segment_csr
+
+    torch.manual_seed(0)
+    eng = UpdateModule().eval().engine(dev())
+    gen = torch.Generator().manual_seed(33)
+    E, H, W = 5, 8, 64
+    net = torch.randn(E, H, W, 128, generator=gen).tanh().half().to(dev())
+    xbuf = torch.zeros(E, H, W, 320, dtype=torch.float16, device=dev())
+    xbuf[..., :128] = torch.randn(E, H, W, 128, generator=gen).relu().half().to(dev())
+    corr = torch.zeros(E, H, W, 200, dtype=torch.float16, device=dev())
+    corr[..., :196] = (torch.randn(E, H, W, 196, generator=gen) * 0.5).half().to(dev())
+    motn = (torch.randn(E, H, W, 4, generator=gen) * 2).half().to(dev())
+    ix = torch.tensor([0, 0, 1, 2, 2], device=dev())
+    csr = segment_csr(ix, 3)
+    pg = eng.gate_context(xbuf)
+    ref = eng.forward_nhwc(net, xbuf.clone(), corr, motn, ix=ix, n_src=3, csr=csr, pgate=pg)
+    ref = [t.clone() for t in ref[:3]]
+    outs = {}
+    for native in (True, False):
+        gs = eng.hidden_gate_state(net, pg, native=native)
+        assert eng.gate_state_matches(gs, net, pg)
+        pzr = gs["pzr"].clone()
+        o = eng.forward_nhwc(net, xbuf.clone(), corr, motn, ix=ix, n_src=3, csr=csr, pgate=pg, gate_state=gs, native=native)
+        outs[native] = [t.clone() for t in o[:3]] + [pzr]
+    for a, b_ in zip(outs[True], outs[False]):
+        assert torch.equal(a, b_)
+    # the partial sums themselves: fp32 conv of the hidden state + the hoisted context part
+    w = torch.cat([eng.m.gru.convz.weight, eng.m.gru.convr.weight], 0)[:, 0:128].detach().half().float().to(dev())
+    want = torch.nn.functional.conv2d(net.float().permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1) + pg[..., :256].float()
+    assert (outs[True][3] - want).abs().max().item() < 2e-3 * max(1.0, want.abs().max().item())
+    assert (outs[True][0].float() - ref[0].float()).abs().max().item() < 2e-3   # new hidden state (fp16 ulp at |x| <= 1)
+    assert (outs[True][1] - ref[1]).abs().max().item() < 1e-2                   # heads (delta in pixels, fp16)
+    assert (outs[True][2] - ref[2]).abs().max().item() < 1e-4                   # eta
+    # a gate state of another hidden state must not be used
+    gs = eng.hidden_gate_state(net, pg)
+    other = net.flip(0).contiguous()
+    a = eng.forward_nhwc(other, xbuf.clone(), corr, motn, ix=ix, n_src=3, csr=csr, pgate=pg, gate_state=gs)
+    a = [t.clone() for t in a[:3]]
+    b_ = eng.forward_nhwc(other, xbuf.clone(), corr, motn, ix=ix, n_src=3, csr=csr, pgate=pg)
+    for x, y in zip(a, b_[:3]):
+        assert torch.equal(x, y)
+
+
+def test_update_with_gate_state_on_side_stream_matches_serial_update():
+    """`FactorGraph.update` with the next iteration's hidden-state gate part issued on a second stream under the BA
+    (the default for >= 64 active edges) against the same three iterations without it: same poses / disparities /
+    targets up to the fp32 summation order of the split z|r convolution; edge-set changes drop the staged state."""
+    import bench
+    res = {}
+    for overlap in ("gated", "free", False):
+        g, buf, graph = bench.build_problem(dev(), 10, 128, 512, 3, 0, seed=77)
+        graph.gate_overlap_min_edges = 1 if overlap else 10 ** 9
+        graph.gate_overlap_mode = overlap or "gated"
+        for _ in range(3):
+            graph.update(t0=1, t1=10, itrs=2)
+        assert (graph._gate_state is not None) == bool(overlap)
+        torch.cuda.synchronize()
+        res[overlap] = (buf.poses[:10].clone(), buf.disps[:10].clone(), graph.target.clone(), graph.net_n.clone())
+        if overlap:  # removing edges invalidates the staged state; the next update recomputes in line and stages anew
+            graph.rm_factors(graph.ii == 0, store=False)
+            assert graph._gate_state is None
+            graph.update(t0=1, t1=10, itrs=2)
+            assert graph._gate_state is not None and torch.isfinite(buf.poses[:10]).all()
+    # the same kernels on the same data, released differently (not bit-identical: the pooled global-context sum is
+    # accumulated with float atomics in workgroup order)
+    assert (res["gated"][0] - res["free"][0]).abs().max().item() < 1e-5
+    assert (res["gated"][3].float() - res["free"][3].float()).abs().max().item() < 2e-3
+    assert (res["gated"][3].float() - res[False][3].float()).abs().max().item() < 1e-2
+    assert (res["gated"][2] - res[False][2]).abs().max().item() < 5e-2
+    assert (res["gated"][0] - res[False][0]).abs().max().item() < 1e-4
+    assert (res["gated"][1] - res[False][1]).abs().max().item() < 1e-4
+
+
 @pytest.mark.parametrize("case", ["full", "motion_only", "prior_stereo_t0"])
 def test_slam_ext_ba_droid_signature_against_restatement(case):
     """Row a13: `slam_ext.ba` (DROID signature, geom_kernels.cu:1273-1404; dormant in the reference).  PARITY UNPINNED:

@@ -19,19 +19,6 @@ DTYPE_CODE = {torch.float16: F16, torch.float32: F32, torch.float64: F64}
 CAMERA_CODE = {"pinhole": 0, "mei": 1}
 
 
-class BAParams(ctypes.Structure):
-    """vipe_ba_params (include/vipe_amd.h)."""
-
-    _fields_ = [
-        ("n_poses", ctypes.c_int), ("n_views", ctypes.c_int), ("ht", ctypes.c_int), ("wd", ctypes.c_int),
-        ("M", ctypes.c_int), ("t0", ctypes.c_int), ("t1", ctypes.c_int), ("n_iters", ctypes.c_int),
-        ("pose_damping", ctypes.c_float), ("pose_ep", ctypes.c_float), ("motion_only", ctypes.c_int),
-        ("limited_disp", ctypes.c_int), ("optimize_intrinsics", ctypes.c_int),
-        ("optimize_rig_rotation", ctypes.c_int), ("camera", ctypes.c_int), ("alpha", ctypes.c_float),
-        ("weight_scale", ctypes.c_float), ("intr_factor", ctypes.c_float), ("reuse_plan", ctypes.c_int), ("path_hint", ctypes.c_int),
-    ]
-
-
 def parse_struct(name, path=HEADER):
     """ctypes.Structure mirroring `typedef struct { ... } name;` of the header (int / float scalars, pointers of any type
     as addresses, fixed-size pointer arrays) - field order and types come from the header itself."""
@@ -52,11 +39,15 @@ def parse_struct(name, path=HEADER):
         scalar = {"int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "int64_t": ctypes.c_int64}
         for is_ptr, nm in names:
             arr = re.match(r"(\w+)\[(\d+)\]", nm)
-            ctype = ctypes.c_void_p if is_ptr else scalar[[b for b in base if b != "const"][0]]
+            # anything that is not a scalar of the table (function-pointer typedefs) travels as an address
+            ctype = ctypes.c_void_p if is_ptr else scalar.get([b for b in base if b != "const"][0], ctypes.c_void_p)
             if arr:
                 nm, ctype = arr.group(1), ctype * int(arr.group(2))
             fields.append((nm, ctype))
     return type(name, (ctypes.Structure,), {"_fields_": fields})
+
+
+BAParams = parse_struct("vipe_ba_params")  # include/vipe_amd.h: field order / types come from the header itself
 
 
 _SCALARS = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "double": ctypes.c_double}

@@ -682,7 +682,11 @@ __global__ __launch_bounds__(TILE) void ba_accum_kernel(BAArgs a) {
 constexpr int AM_ROWS = 48;             // R2 row capacity: 6 (AM_DMAX + 1) + F + 1 <= 48
 constexpr int AM_P1 = 130;              // float pitch of the R1 tile [16][128]   (= 2 mod 32: conflict-free b32 reads)
 constexpr int AM_P2 = 66;               // float pitch of the R2 image [48][64]
-constexpr int AM_WBUF = AM_ROWS * AM_P2;  // 3168 floats per wave (R1 tile: 16 * 130 = 2080)
+constexpr int AM_P2H = 34;              // float pitch of HALF the R2 image [48][32]: the fused kernel reduces the wave's
+                                        // 64 pixels in two passes of 32 (34 = 2 + 32 mod 64: lanes (row l16, pixel kq) of an
+                                        // MFMA operand read hit 64 distinct banks)
+constexpr int AM_WBUF = 16 * AM_P1;     // 2080 floats per wave: the R1 tile (R2 half image: 48 * 34 = 1632)
+static_assert(AM_ROWS * AM_P2H <= AM_WBUF, "R2 half image must fit the wave buffer");
 constexpr int AM_SP = AM_ROWS + 1;
 
 struct TermGeomM {
@@ -714,7 +718,7 @@ __device__ unsigned long long* g_ba_stamps = nullptr;
 #endif
 
 template <int CAM, int F>
-__global__ __launch_bounds__(TILE) void ba_accum_mfma_kernel(BAArgs a) {
+__global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) void ba_accum_mfma_kernel(BAArgs a) {
   constexpr int FF = F > 0 ? F : 1;
   constexpr int RPT = F > 0 ? 16 : 8;  // R1 rows per term: 6 J, r, F Jf (padded)
   constexpr int TPT = 16 / RPT;        // terms per R1 tile
@@ -903,48 +907,72 @@ __global__ __launch_bounds__(TILE) void ba_accum_mfma_kernel(BAArgs a) {
       }
       sq = __builtin_amdgcn_rsqf(C);  // sqrt(Q), Q = 1 / C
     }
-    // R2 rows, scaled by sqrt(Q)
-    float* col = wbuf + lane;
+    // R2 rows, scaled by sqrt(Q).  The wave's 64 pixels are reduced in two passes of 32 (lanes 0-31, then 32-63, put
+    // their rows into the [48][32] image; the Gram chains continue across the passes): the wave buffer then is the
+    // 8 KiB of the R1 tile instead of 12.4 KiB, three workgroups instead of two fit a CU and the 576 workgroups of the
+    // 48-keyframe graph are resident at once instead of in two rounds.
+    // all E_j rows of this pixel in flight at once (a per-term loop serialises one L2 round trip per term)
+    float ej[AM_DMAX][6];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) col[q * AM_P2] = fi ? Ei[q] * sq : 0.0f;
-    {
-      // all E_j rows of this pixel in flight at once (a per-term loop serialises one L2 round trip per term)
-      float ej[AM_DMAX][6];
+    for (int t = 0; t < AM_DMAX; ++t) {
+      const bool on = t < deg && tg[min(t, deg - 1)].g.sj >= 0 && inb;
+      const int64_t eb = (int64_t)tg[min(t, deg - 1)].g.e * 6 * P + p;
 #pragma unroll
-      for (int t = 0; t < AM_DMAX; ++t) {
-        const bool on = t < deg && tg[min(t, deg - 1)].g.sj >= 0 && inb;
-        const int64_t eb = (int64_t)tg[min(t, deg - 1)].g.e * 6 * P + p;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) ej[t][q] = on ? w.Ej[eb + (int64_t)q * P] : 0.0f;
-      }
-#pragma unroll
-      for (int t = 0; t < AM_DMAX; ++t) {
-        if (t < deg) {
-#pragma unroll
-          for (int q = 0; q < 6; ++q) col[(6 * (t + 1) + q) * AM_P2] = ej[t][q] * sq;
-        }
-      }
+      for (int q = 0; q < 6; ++q) ej[t][q] = on ? w.Ej[eb + (int64_t)q * P] : 0.0f;
     }
-    if constexpr (F > 0) {
+    constexpr int NPAIR = 6;  // lower-triangle 16 x 16 tile pairs of up to 48 rows
+    float4m g4[NPAIR];
 #pragma unroll
-      for (int f = 0; f < F; ++f) col[(6 * (deg + 1) + f) * AM_P2] = Efr[f] * sq;
-    }
-    col[(NR - 1) * AM_P2] = wz * sq;
-    for (int r = NR; r < ((NR + 15) & ~15); ++r) col[r * AM_P2] = 0.0f;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    for (int i = 0; i < NPAIR; ++i) g4[i] = float4m{0.f, 0.f, 0.f, 0.f};
     const int RT = (NR + 15) >> 4;
-    for (int ta = 0; ta < RT; ++ta)
-      for (int tb = 0; tb <= ta; ++tb) {
-        float4m g4 = {0.f, 0.f, 0.f, 0.f};
-        const float* ar = wbuf + (16 * ta + l16) * AM_P2 + kq;
-        const float* br = wbuf + (16 * tb + l16) * AM_P2 + kq;
-#pragma unroll 8
-        for (int s = 0; s < 16; ++s) g4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[4 * s], br[4 * s], g4, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * ta + 4 * kq + r, cc = 16 * tb + l16;
-          if (row < NR && cc <= row) atomicAdd(&accS[row * AM_SP + cc], g4[r]);
+    for (int half = 0; half < 2; ++half) {
+      if ((lane >> 5) == half) {
+        float* col = wbuf + (lane & 31);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) col[q * AM_P2H] = fi ? Ei[q] * sq : 0.0f;
+#pragma unroll
+        for (int t = 0; t < AM_DMAX; ++t) {
+          if (t < deg) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) col[(6 * (t + 1) + q) * AM_P2H] = ej[t][q] * sq;
+          }
+        }
+        if constexpr (F > 0) {
+#pragma unroll
+          for (int f = 0; f < F; ++f) col[(6 * (deg + 1) + f) * AM_P2H] = Efr[f] * sq;
+        }
+        col[(NR - 1) * AM_P2H] = wz * sq;
+        for (int r = NR; r < ((NR + 15) & ~15); ++r) col[r * AM_P2H] = 0.0f;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ta = 0; ta < 3; ++ta)
+#pragma unroll
+        for (int tb = 0; tb <= ta; ++tb) {
+          if (ta < RT) {  // wave-uniform
+            const float* ar = wbuf + (16 * ta + l16) * AM_P2H + kq;
+            const float* br = wbuf + (16 * tb + l16) * AM_P2H + kq;
+            float4m acc = g4[ta * (ta + 1) / 2 + tb];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[4 * s], br[4 * s], acc, 0, 0, 0);
+            g4[ta * (ta + 1) / 2 + tb] = acc;
+          }
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // the second half overwrites the image the chains above have read
+    }
+#pragma unroll
+    for (int ta = 0; ta < 3; ++ta)
+#pragma unroll
+      for (int tb = 0; tb <= ta; ++tb) {
+        if (ta < RT) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * ta + 4 * kq + r, cc = 16 * tb + l16;
+            if (row < NR && cc <= row) atomicAdd(&accS[row * AM_SP + cc], g4[ta * (ta + 1) / 2 + tb][r]);
+          }
         }
       }
   }
@@ -3049,8 +3077,36 @@ __global__ void clamp_min_kernel(float* __restrict__ x, int64_t n, float lo) {
     x[i] = fmaxf(x[i], lo);  // NaN stays NaN? fmaxf(NaN, lo) = lo; torch.clamp keeps NaN - disparities are finite here
 }
 
+// a few microseconds on one wave: head start for the solve kernel on the BA stream before a piece of the caller's
+// independent work fills the chip (vipe_overlap_fn)
+__global__ void overlap_delay_kernel(int ticks) {
+  const uint64_t t0 = wall_clock64();  // 100 MHz
+  while (wall_clock64() - t0 < (uint64_t)ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+// Event `after the accumulate kernels of this iteration` on the BA stream; see overlap_piece
+hipEvent_t overlap_event() {
+  static thread_local hipEvent_t ev[64] = {};
+  int d = 0;
+  (void)hipGetDevice(&d);
+  hipEvent_t& e = ev[d & 63];
+  if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+  return e;
+}
+
+// vipe_overlap_fn protocol: piece `it` goes to the caller's stream behind (event after this iteration's accumulate
+// kernels) + a short delay, so that it starts when the single-workgroup solve already owns a CU
+int overlap_piece(const vipe_ba_params& p, hipEvent_t ev, int piece, int n_pieces, bool gated) {
+  hipStream_t side = (hipStream_t)p.overlap_stream;
+  if (gated && ev) {
+    if (hipStreamWaitEvent(side, ev, 0) != hipSuccess) return VIPE_EINVAL;
+    overlap_delay_kernel<<<1, 64, 0, side>>>(400);
+  }
+  return p.overlap_fn(p.overlap_user, piece, n_pieces, p.overlap_stream);
+}
+
 template <int CAM, int F>
-int run_iters(const BAArgs& a, hipStream_t s) {
+int run_iters(const BAArgs& a, hipStream_t s, int* pieces_done) {
   const int tiles = (a.P + TILE - 1) / TILE;
   const size_t sbytes = sizeof(double) * (size_t)a.w.ld * a.w.ld;
   const size_t nmax = (size_t)a.w.ld - 1;
@@ -3074,6 +3130,8 @@ int run_iters(const BAArgs& a, hipStream_t s) {
   // also across calls when the caller vouches for the workspace (reuse_plan: same key, hence the same motion_only), else
   // by memsets
   const bool retract_clears = !a.p.motion_only;
+  const bool overlap = a.p.overlap_stream && a.p.overlap_fn;
+  hipEvent_t ev = overlap ? overlap_event() : nullptr;
   for (int it = 0; it < a.p.n_iters; ++it) {
     if (!(retract_clears && (it > 0 || a.p.reuse_plan))) {
       hipError_t e1 = hipMemsetAsync(a.w.S, 0, sbytes, s);
@@ -3084,8 +3142,14 @@ int run_iters(const BAArgs& a, hipStream_t s) {
       // multi-view rigs: local-block walk, Schur Gram over the stacked E rows, global-memory Cholesky with the dense tail
       ba_walk_rig_kernel<CAM><<<dim3(tiles, a.nF), TILE, walk_rig_lds(), s>>>(a);
       ba_schur_kernel<0><<<dim3(SC_GRID, a.nF), TILE, 0, s>>>(a);
+      if (ev && hipEventRecord(ev, s) != hipSuccess) return VIPE_EINVAL;
       ba_solve_kernel<<<1, SOLVE_T, solve_lds, s>>>(a, panel_cap, nullptr);
       launch_tiled_cholesky(a, s);
+      if (overlap) {
+        const int rc = overlap_piece(a.p, ev, it, a.p.n_iters, true);
+        if (rc != VIPE_OK) return rc;
+        ++*pieces_done;
+      }
       if (!a.p.motion_only) ba_retract_kernel<0><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
       continue;
     }
@@ -3097,11 +3161,17 @@ int run_iters(const BAArgs& a, hipStream_t s) {
       ba_schur_kernel<F><<<dim3(SC_GRID, a.nF), TILE, 0, s>>>(a);
     }
     if (a.force_simple == 1) ba_accum_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
+    if (ev && hipEventRecord(ev, s) != hipSuccess) return VIPE_EINVAL;
     if (!(hint & 8)) ba_solve_band_kernel<<<1, BAND_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)));
     if (!(hint & 16)) ba_solve_dense_kernel<<<1, DN_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)), getenv("VIPE_BA_DEBUG_TIMING") ? 1 : 0);
     if (!(hint & 4)) {
       ba_solve_kernel<<<1, SOLVE_T, solve_lds, s>>>(a, panel_cap, getenv("VIPE_BA_DEBUG_TIMING") ? (long long*)(a.w.Hd + nmax) : nullptr);
       launch_tiled_cholesky(a, s);
+    }
+    if (overlap) {
+      const int rc = overlap_piece(a.p, ev, it, a.p.n_iters, true);
+      if (rc != VIPE_OK) return rc;
+      ++*pieces_done;
     }
     if (!a.p.motion_only) ba_retract_kernel<F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
   }
@@ -3150,17 +3220,25 @@ VIPE_EXPORT int vipe_dense_ba(const vipe_ba_params* p, float* d_poses, float* d_
   a.droid = 0;
   a.dz_out = nullptr;
   hipStream_t s = as_stream(stream);
-  int rc = VIPE_OK;
+  int rc = VIPE_OK, pieces_done = 0;
   if (p->M > 0 && p->n_iters > 0) {
     ba_sens_kernel<<<a.nF, 256, 0, s>>>(d_disps_sens, a.w.sens_sum, a.P, a.w.info);
     if (!p->reuse_plan) ba_plan_kernel<<<1, 1024, 0, s>>>(a);
     const int F = p->optimize_intrinsics ? 1 + a.D : 0;
-    if (p->camera == VIPE_CAM_PINHOLE) rc = F ? run_iters<VIPE_CAM_PINHOLE, 1>(a, s) : run_iters<VIPE_CAM_PINHOLE, 0>(a, s);
-    else rc = F ? run_iters<VIPE_CAM_MEI, 2>(a, s) : run_iters<VIPE_CAM_MEI, 0>(a, s);
+    if (p->camera == VIPE_CAM_PINHOLE) rc = F ? run_iters<VIPE_CAM_PINHOLE, 1>(a, s, &pieces_done) : run_iters<VIPE_CAM_PINHOLE, 0>(a, s, &pieces_done);
+    else rc = F ? run_iters<VIPE_CAM_MEI, 2>(a, s, &pieces_done) : run_iters<VIPE_CAM_MEI, 0>(a, s, &pieces_done);
     if (rc != VIPE_OK) return rc;
     if (d_info) {
       hipError_t e = hipMemcpyAsync(d_info, a.w.info, 8 * sizeof(int), hipMemcpyDeviceToDevice, s);
       if (e != hipSuccess) return (int)e;
+    }
+  }
+  // vipe_overlap_fn: exactly max(n_iters, 1) pieces, also when there was nothing to optimise
+  if (p->overlap_stream && p->overlap_fn) {
+    const int n_pieces = p->n_iters > 0 ? p->n_iters : 1;
+    for (; pieces_done < n_pieces; ++pieces_done) {
+      rc = overlap_piece(*p, nullptr, pieces_done, n_pieces, false);
+      if (rc != VIPE_OK) return rc;
     }
   }
   // buffer.py:525: disps.clamp_(min=1e-3) over the whole buffer handed in
@@ -3225,7 +3303,8 @@ VIPE_EXPORT int vipe_ba(float* d_poses, float* d_disps, const float* d_intrinsic
   if (iterations == 0 || t1 == t0) return VIPE_OK;
   ba_sens_kernel<<<a.nF, 256, 0, s>>>(d_disps_sens, a.w.sens_sum, a.P, a.w.info);
   ba_plan_kernel<<<1, 1024, 0, s>>>(a);
-  const int rc = run_iters<VIPE_CAM_PINHOLE, 0>(a, s);
+  int pieces_done = 0;
+  const int rc = run_iters<VIPE_CAM_PINHOLE, 0>(a, s, &pieces_done);
   if (rc != VIPE_OK) return rc;
   hipError_t e4 = hipMemcpyAsync(d_dx, a.w.dx, sizeof(float) * 6 * (size_t)(t1 - t0), hipMemcpyDeviceToDevice, s);
   return e4 == hipSuccess ? vipe_launch_status() : (int)e4;

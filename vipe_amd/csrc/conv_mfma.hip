@@ -30,7 +30,7 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
-enum Epi { EPI_PLAIN = 0, EPI_GLO = 1, EPI_ZR = 2, EPI_Q = 3, EPI_HEADS = 4, EPI_ETA = 5 };
+enum Epi { EPI_PLAIN = 0, EPI_GLO = 1, EPI_ZR = 2, EPI_Q = 3, EPI_HEADS = 4, EPI_ETA = 5, EPI_PARTIAL = 6 };
 
 struct ConvArgs {
   const half_t* x0; int x0_ctot, x0_coff;  // input channels [0, split)
@@ -49,6 +49,7 @@ struct ConvArgs {
   half_t* y2; int y2_ctot, y2_coff;            // second output (ZR: r*net)
   float* fout;                                 // GLO: glo_sum [B,Cout]; HEADS: [M,4]; ETA: [M]
   const half_t* accinit; int ai_ctot, ai_coff;  // optional initial accumulator [M, ai_ctot] (a partial conv sum)
+  int ai_f32;                                   // ... held as fp32 (the output of an EPI_PARTIAL launch) instead of fp16
 };
 
 constexpr int BNP = 128;  // pixels per tile
@@ -422,7 +423,9 @@ __device__ __forceinline__ int swz32(int row, int c) { return row * 64 + ((c ^ s
 
 constexpr size_t halo32_lds_bytes(int bmc) { return 3 * (size_t)bmc * 64 + 2 * H32_XBYTES + 1024; }
 
-template <int BMC, int KS, bool M16>
+// VAR: 0 = the general kernel; 1 = initial accumulators held as fp32 (a.ai_f32); 2 = EPI_PARTIAL (raw fp32 accumulators
+// out).  Separate instantiations: folded into the general one as run-time branches they cost it 75 spilled VGPRs.
+template <int BMC, int KS, bool M16, int VAR = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_halo32_kernel(ConvArgs a, int gy) {
   // M16: v_mfma_f32_16x16x32_f16 (one instruction per 32-channel step and 16 x 16 tile; the chip holds a higher
   // clock on this shape, MI355X_MICROARCH.md 'DVFS give-back' (7)); otherwise 32x32x16.
@@ -512,8 +515,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
           for (int i = 0; i < MI; ++i) {
             const int cg = cout0 + wm * (MI * 16) + i * 16 + 4 * (lane >> 4);
-            const half4 v = *reinterpret_cast<const half4*>(a.accinit + m * a.ai_ctot + a.ai_coff + cg);
-            acc16[i][j] = float4v{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+            if constexpr (VAR == 1) {
+              const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.accinit) + m * a.ai_ctot +
+                                                                a.ai_coff + cg);
+              acc16[i][j] = float4v{v.x, v.y, v.z, v.w};
+            } else {
+              const half4 v = *reinterpret_cast<const half4*>(a.accinit + m * a.ai_ctot + a.ai_coff + cg);
+              acc16[i][j] = float4v{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+            }
           }
         }
       }
@@ -656,6 +665,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   constexpr int NIT = BP * CPP / 512, PSTEP = 512 / CPP;
   const int ch = (tid % CPP) * 8, co = cout0 + ch, pl0 = tid / CPP;
   if constexpr (BMC >= 64) {
+    if constexpr (M16 && VAR == 2) {
+      {
+        // raw fp32 accumulators (no bias, no activation) for a later launch to start from: lanes lk = 0..3 of a pixel
+        // cover 16 consecutive channels = one 64-byte sector per store instruction and pixel
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int64_t m = pix_of(wn * 64 + j * 16 + l16);
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            const int cg = cout0 + wm * (MI * 16) + i * 16 + 4 * lk;
+            if (cg + 4 <= a.Cout)
+              *reinterpret_cast<float4*>(a.fout + m * a.y_ctot + a.y_coff + cg) =
+                  make_float4(acc16[i][j][0], acc16[i][j][1], acc16[i][j][2], acc16[i][j][3]);
+          }
+        }
+        return;
+      }
+    }
     constexpr int PITCH = BMC + 8;  // halves per staged pixel
     half_t* stage = reinterpret_cast<half_t*>(lds);
     auto stage_all = [&](auto ACTC) {
@@ -1215,9 +1242,11 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
   const bool halo = glds && a.W % HALO_TW == 0 && a.H % HALO_TH == 0 && a.KH == a.KW && (a.KH == 1 || a.KH == 3) &&
                     (int64_t)a.B * a.H * a.W * (a.x0_ctot > a.x1_ctot ? a.x0_ctot : a.x1_ctot) * 2 < (1ll << 32) &&
                     getenv("VIPE_AMD_CONV_NOHALO") == nullptr;
-  if (a.accinit) {
-    // initial accumulators are implemented by the 32-channel halo kernel with >= 64 output channels only
-    const bool ok = halo && cp >= 64 && (a.split >= a.Cin || a.split % H32_BK == 0) && !(a.KH == 3 && a.Cout <= 16);
+  if (a.accinit || a.epi == EPI_PARTIAL || a.ai_f32) {
+    // initial accumulators / raw partial sums are implemented by the 32-channel halo kernel (16x16x32 fragments) with
+    // >= 64 output channels only (fp32 initial accumulators and partial sums: 3x3, >= 128 output channels)
+    const bool ok = halo && cp >= 64 && (a.split >= a.Cin || a.split % H32_BK == 0) && !(a.KH == 3 && a.Cout <= 16) &&
+                    !(a.epi == EPI_PARTIAL && a.Cout % 4 != 0) && !(a.ai_f32 && !a.accinit);
     if (!ok) return VIPE_EUNSUPPORTED;
   }
   if (a.epi == EPI_GLO && a.KH == 1 && a.KW == 1 && a.Cin == 128 && a.Cout == 128 && cp == 128 && a.split >= a.Cin &&
@@ -1261,6 +1290,18 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<128, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(128));
         (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<128, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(128));
       }
+    }
+    if (a.ai_f32 || a.epi == EPI_PARTIAL) {
+      // the two variants of the staged z|r gates (vipe_update_gate_state): 3x3, >= 128 output channels
+      if (!(a.KH == 3 && bmc == 128 && !m32 && !(a.ai_f32 && a.epi == EPI_PARTIAL))) return VIPE_EUNSUPPORTED;
+      static std::atomic<uint64_t> av{0};  // bit d: set on device d
+      if (vipe_first_on_device(av)) {
+        (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<128, 3, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(128));
+        (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<128, 3, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(128));
+      }
+      if (a.ai_f32) conv_halo32_kernel<128, 3, true, 1><<<grid, 512, lds, s>>>(a, gy);
+      else conv_halo32_kernel<128, 3, true, 2><<<grid, 512, lds, s>>>(a, gy);
+      return vipe_launch_status();
     }
     if (a.KH == 3) {
       if (bmc == 128 && m32) conv_halo32_kernel<128, 3, false><<<grid, 512, lds, s>>>(a, gy);
@@ -1346,7 +1387,10 @@ VIPE_EXPORT int vipe_conv2d_fused(const void* d_x0, int x0_ctot, int x0_coff, co
     VIPE_CHECK_ARG(Cin % 8 == 0 && x0_ctot % 8 == 0 && x0_coff % 8 == 0);
     VIPE_CHECK_ARG(split >= Cin || (split % 64 == 0 && d_x1 && x1_ctot % 8 == 0 && x1_coff % 8 == 0));
   }
-  VIPE_CHECK_ARG(mode >= EPI_PLAIN && mode <= EPI_ETA);
+  const int ai_f32 = (mode & VIPE_CONV_ACCINIT_F32) != 0;
+  mode &= ~VIPE_CONV_ACCINIT_F32;
+  VIPE_CHECK_ARG(mode >= EPI_PLAIN && mode <= EPI_PARTIAL);
+  if (mode == EPI_PARTIAL) VIPE_CHECK_ARG(d_fout && y_ctot % 4 == 0 && y_coff % 4 == 0 && y_coff + Cout <= y_ctot && !d_extra);
   if (mode == EPI_PLAIN) VIPE_CHECK_ARG(d_y && y_ctot % 4 == 0 && y_coff % 4 == 0);
   if (mode == EPI_GLO) VIPE_CHECK_ARG(d_net && d_fout);
   if (mode == EPI_ZR) VIPE_CHECK_ARG(d_y && d_y2 && d_net && Cout == 256);
@@ -1362,7 +1406,7 @@ VIPE_EXPORT int vipe_conv2d_fused(const void* d_x0, int x0_ctot, int x0_coff, co
   a.y2 = (half_t*)d_y2; a.y2_ctot = y2_ctot; a.y2_coff = y2_coff;
   a.net = (const half_t*)d_net; a.net_ctot = net_ctot; a.net_coff = net_coff;
   a.zbuf = (const half_t*)d_z; a.fout = d_fout;
-  a.accinit = (const half_t*)d_accinit; a.ai_ctot = ai_ctot; a.ai_coff = ai_coff;
+  a.accinit = (const half_t*)d_accinit; a.ai_ctot = ai_ctot; a.ai_coff = ai_coff; a.ai_f32 = ai_f32;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW;
   a.act = act; a.epi = mode;
   return launch_conv(a, as_stream(stream));

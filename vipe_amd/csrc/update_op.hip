@@ -71,13 +71,24 @@ VIPE_EXPORT int vipe_update_operator(const vipe_update_weights* wt, const vipe_u
                         nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, E, H, W, 4, 128, 7, 7, VIPE_ACT_RELU, 0, stream));
   RUN(vipe_conv2d_fused(b->f1, 128, 0, nullptr, 0, 0, 128, wt->flow2_w, wt->flow2_b, nullptr, 0, 0, b->xbuf, 320, 256, nullptr,
                         0, 0, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, E, H, W, 128, 64, 3, 3, VIPE_ACT_RELU, 0, stream));
-  // global context (droid_net.py:392-393) and its three 1x1s
-  if (hipMemsetAsync(b->glo, 0, sizeof(float) * 128 * (size_t)E, s) != hipSuccess) return VIPE_EINVAL;
-  RUN(vipe_conv2d_fused(b->net, 128, 0, nullptr, 0, 0, 128, wt->gw_w, wt->gw_b, nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, 0,
-                        b->net, 128, 0, nullptr, b->glo, nullptr, 0, 0, E, H, W, 128, 128, 1, 1, VIPE_ACT_NONE, 1, stream));
-  glo_gemm_kernel<<<E, 384, 0, s>>>(b->glo, wt->glo_wT, wt->glo_b, b->extra, 1.0f / (float)(H * W));
+  const bool staged = b->gate_state != 0;  // hidden-state part of the gates computed ahead (vipe_update_gate_state)
+  if (staged) VIPE_CHECK_ARG(b->pgate && b->pzr && wt->zr_x_w);
+  if (!staged) {
+    // global context (droid_net.py:392-393) and its three 1x1s
+    if (hipMemsetAsync(b->glo, 0, sizeof(float) * 128 * (size_t)E, s) != hipSuccess) return VIPE_EINVAL;
+    RUN(vipe_conv2d_fused(b->net, 128, 0, nullptr, 0, 0, 128, wt->gw_w, wt->gw_b, nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, 0,
+                          b->net, 128, 0, nullptr, b->glo, nullptr, 0, 0, E, H, W, 128, 128, 1, 1, VIPE_ACT_NONE, 1, stream));
+    glo_gemm_kernel<<<E, 384, 0, s>>>(b->glo, wt->glo_wT, wt->glo_b, b->extra, 1.0f / (float)(H * W));
+  }
   // gates (droid_net.py:395-399); with pgate the context-feature part is the accumulators' initial value
-  if (b->pgate) {
+  if (staged) {
+    RUN(vipe_conv2d_fused(b->xbuf, 320, 128, nullptr, 0, 0, 192, wt->zr_x_w, wt->zr_b, b->extra, 384, 0, b->zb, 128, 0, b->rnet,
+                          128, 0, b->net, 128, 0, nullptr, nullptr, b->pzr, 256, 0, E, H, W, 192, 256, 3, 3, VIPE_ACT_NONE,
+                          2 | VIPE_CONV_ACCINIT_F32, stream));
+    RUN(vipe_conv2d_fused(b->rnet, 128, 0, b->xbuf, 320, 128, 128, wt->q_s_w, wt->q_b, b->extra, 384, 256, b->net_out, 128, 0,
+                          nullptr, 0, 0, b->net, 128, 0, b->zb, nullptr, b->pgate, 384, 256, E, H, W, 320, 128, 3, 3,
+                          VIPE_ACT_NONE, 3, stream));
+  } else if (b->pgate) {
     RUN(vipe_conv2d_fused(b->net, 128, 0, b->xbuf, 320, 128, 128, wt->zr_s_w, wt->zr_b, b->extra, 384, 0, b->zb, 128, 0, b->rnet,
                           128, 0, b->net, 128, 0, nullptr, nullptr, b->pgate, 384, 0, E, H, W, 320, 256, 3, 3, VIPE_ACT_NONE, 2,
                           stream));
@@ -108,6 +119,50 @@ VIPE_EXPORT int vipe_update_operator(const vipe_update_weights* wt, const vipe_u
   }
 #undef RUN
   return vipe_launch_status();
+}
+
+VIPE_EXPORT int vipe_update_gate_state(const vipe_update_weights* wt, const vipe_update_buffers* b, const void* d_net,
+                                       int parts, void* stream) {
+  VIPE_CHECK_ARG(wt && b && b->E >= 0 && b->H > 0 && b->W > 0 && parts >= 1 && parts <= 3);
+  if (b->E == 0) return VIPE_OK;
+  VIPE_CHECK_ARG(d_net && (!(parts & 1) || (b->glo && b->extra)) && (!(parts & 2) || (b->pgate && b->pzr && wt->zr_n_w)));
+  const int E = b->E, H = b->H, W = b->W;
+  hipStream_t s = as_stream(stream);
+  int rc;
+  if (parts & 1) {
+    if (hipMemsetAsync(b->glo, 0, sizeof(float) * 128 * (size_t)E, s) != hipSuccess) return VIPE_EINVAL;
+    rc = vipe_conv2d_fused(d_net, 128, 0, nullptr, 0, 0, 128, wt->gw_w, wt->gw_b, nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, 0,
+                           d_net, 128, 0, nullptr, b->glo, nullptr, 0, 0, E, H, W, 128, 128, 1, 1, VIPE_ACT_NONE, 1, stream);
+    if (rc != VIPE_OK) return rc;
+    glo_gemm_kernel<<<E, 384, 0, s>>>(b->glo, wt->glo_wT, wt->glo_b, b->extra, 1.0f / (float)(H * W));
+  }
+  if (parts & 2) {
+    rc = vipe_conv2d_fused(d_net, 128, 0, nullptr, 0, 0, 128, wt->zr_n_w, wt->zr_b, nullptr, 0, 0, nullptr, 256, 0, nullptr, 0,
+                           0, nullptr, 0, 0, nullptr, b->pzr, b->pgate, 384, 0, E, H, W, 128, 256, 3, 3, VIPE_ACT_NONE,
+                           VIPE_CONV_PARTIAL, stream);
+    if (rc != VIPE_OK) return rc;
+  }
+  return vipe_launch_status();
+}
+
+VIPE_EXPORT int vipe_update_gate_state_piece(void* user, int piece, int n_pieces, void* stream) {
+  const vipe_gate_state_job* j = (const vipe_gate_state_job*)user;
+  VIPE_CHECK_ARG(j && j->weights && j->buffers && j->net && n_pieces > 0 && piece >= 0 && piece < n_pieces);
+  const vipe_update_buffers* b = j->buffers;
+  VIPE_CHECK_ARG(b->E >= 0 && b->H > 0 && b->W > 0 && b->pgate && b->pzr);
+  int64_t e0 = (int64_t)b->E * piece / n_pieces, e1 = (int64_t)b->E * (piece + 1) / n_pieces;
+  if (j->bounds && j->n_bounds == n_pieces + 1) {
+    e0 = j->bounds[piece];
+    e1 = j->bounds[piece + 1];
+    VIPE_CHECK_ARG(j->bounds[0] == 0 && j->bounds[n_pieces] == b->E && e0 >= 0 && e0 <= e1 && e1 <= b->E);
+  }
+  if (e1 <= e0) return VIPE_OK;
+  const int64_t px = (int64_t)b->H * b->W;
+  vipe_update_buffers sub = *b;
+  sub.E = (int)(e1 - e0);
+  sub.pgate = (const char*)b->pgate + e0 * px * 384 * 2;
+  sub.pzr = b->pzr + e0 * px * 256;
+  return vipe_update_gate_state(j->weights, &sub, (const char*)j->net + e0 * px * 128 * 2, 2, stream);
 }
 
 VIPE_EXPORT int vipe_glo_context(const float* d_glo_sum, const float* d_wT, const float* d_bias, float* d_extra, int E, int hw,

@@ -91,8 +91,12 @@ def update_finish(coords1, dw, mask, target, weight, eta, du, damping):
 def dense_ba(poses, disps, disps_sens, intrinsics, rig, target, weight, disp_damping, pi, qi, pj, qj, di, t0, t1,
              n_iters, pose_damping, pose_ep, motion_only=False, limited_disp=False, optimize_intrinsics=False,
              optimize_rig_rotation=False, camera="pinhole", alpha=0.001, n_poses=None, want_info=False, state=None,
-             plan_key=None):
+             plan_key=None, overlap=None):
     """Live dense BA (GraphBuffer.bundle_adjustment, buffer.py:373-525), IN PLACE on poses / disps / intrinsics.
+
+    `overlap` = (stream address, vipe_overlap_fn address, user address) or None: independent work of the caller that the
+    library enqueues on that stream in max(n_iters, 1) pieces, each behind the start of a Gauss-Newton iteration's
+    single-workgroup solve (include/vipe_amd.h, vipe_overlap_fn).
 
     poses [>=n_poses,7]; disps, disps_sens, disp_damping [>=n_poses*V,ht,wd] (flattened views);
     target, weight [M,ht*wd,2]; pi..di [M] int64.  `n_poses` bounds the pose/frame indices that occur
@@ -111,6 +115,8 @@ def dense_ba(poses, disps, disps_sens, intrinsics, rig, target, weight, disp_dam
                  limited_disp=int(limited_disp), optimize_intrinsics=int(optimize_intrinsics),
                  optimize_rig_rotation=int(optimize_rig_rotation), camera=CAMERA_CODE[camera], alpha=float(alpha),
                  weight_scale=0.001, intr_factor=8.0, reuse_plan=0, path_hint=0)
+    if overlap is not None:
+        p.overlap_stream, p.overlap_fn, p.overlap_user = overlap
     L = lib()
     nbytes = L.vipe_dense_ba_workspace_bytes(ctypes.byref(p))
     require(nbytes > 0, "bad BA parameters")

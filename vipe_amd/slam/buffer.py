@@ -95,7 +95,7 @@ class GraphBuffer:
 
     def bundle_adjustment(self, target, weight, disp_damping, ii, jj, t0, t1, n_iters, pose_damping, pose_ep,
                           motion_only, limited_disp, optimize_intrinsics, optimize_rig_rotation, verbose=False,
-                          plan=None, ba_state=None, plan_key=None):
+                          plan=None, ba_state=None, plan_key=None, overlap=None):
         """buffer.py:373-525, in place on self.poses / self.disps (/ self.intrinsics).  `plan` = (pi, qi, di, pj, qj)
         of `expand_edge_multiview(ii, jj)` when the caller already holds it (the reference re-expands every call)."""
         assert t0 <= t1
@@ -116,7 +116,7 @@ class GraphBuffer:
             max(int(t0) - base, 0), max(int(t1) - base, 0), n_iters,
             pose_damping, pose_ep, motion_only, limited_disp, optimize_intrinsics, optimize_rig_rotation,
             camera=self.camera_type, alpha=self.ba_config.dense_disp_alpha, n_poses=n_poses, want_info=verbose,
-            state=ba_state, plan_key=plan_key)
+            state=ba_state, plan_key=plan_key, overlap=overlap)
 
     def reproject_dense_disp(self, ii, jj):
         """buffer.py:527-548 -> coords [M,ht,wd,2], valid [M,ht,wd,1]."""

@@ -36,6 +36,13 @@ class FactorGraph:
         # channels-last state of the flow-update operator: hidden state [E,h,w,128] and [inp | corr | flow] features
         self.corr, self.net_n, self.xbuf = None, None, None
         self.pgate = None  # [E,h,w,384]: context-feature part of the GRU gates, computed once per edge
+        # hidden-state part of the gates for the CURRENT net_n (UpdateEngine.hidden_gate_state), computed on a second
+        # stream in the shadow of the previous iteration's BA; None whenever net_n / the edge set changed since
+        self._gate_state = None
+        self._side = None
+        self.gate_overlap_min_edges = int(os.environ.get("VIPE_AMD_GATE_OVERLAP_MIN_EDGES", "64"))
+        self.gate_overlap_mode = os.environ.get("VIPE_AMD_GATE_OVERLAP", "gated")  # "gated" | "free" (A/B)
+        self.gate_overlap_fractions = [float(x) for x in os.environ.get("VIPE_AMD_GATE_OVERLAP_FRACTIONS", "0.4,0.4,0.2").split(",")]
         self.ii_inac = torch.as_tensor([], dtype=torch.long, device=device)
         self.jj_inac = torch.as_tensor([], dtype=torch.long, device=device)
         self.target_inac = torch.zeros([1, 0, ht, wd, 2], device=device, dtype=torch.float)
@@ -130,6 +137,7 @@ class FactorGraph:
         self.age = torch.cat([self.age, torch.zeros_like(ii)], 0)
         net = self.buffer.nets[pi, qi].permute(0, 2, 3, 1).contiguous()
         self.net_n = net if self.net_n is None else torch.cat([self.net_n, net], 0)
+        self._gate_state = None
         self.target = torch.cat([self.target, target], 1)
         self.weight = torch.cat([self.weight, torch.zeros_like(target)], 1)
         self._plan = None
@@ -161,6 +169,7 @@ class FactorGraph:
         self.ii, self.jj, self.age = self.ii[keep], self.jj[keep], self.age[keep]
         if self.corr is not None:
             self.corr = self.corr[keep_x_np]  # host-side index: the pool only edits its slot vector
+        self._gate_state = None
         if self.net_n is not None:
             self.net_n = self.net_n[keep_x]
         if self.xbuf is not None:
@@ -379,7 +388,34 @@ class FactorGraph:
         # whole operator is one natively sequenced library call
         corr = self.corr.lookup_deferred(coords1)
         self.net_n, dw, eta, _ = eng.forward_nhwc(self.net_n, self.xbuf, corr, motn, ix=P["dix"], n_src=P["n_src"],
-                                                  net_out=self._net_spare(), csr=P["csr"], pgate=self.pgate)
+                                                  net_out=self._net_spare(), csr=P["csr"], pgate=self.pgate,
+                                                  gate_state=self._gate_state)
+        self._gate_state = None
+        # The new hidden state is final here, and the dense BA below keeps ONE workgroup busy for most of its time
+        # (band Cholesky): everything of the next iteration's gates that depends on the hidden state alone - the
+        # global-context terms and the hidden-state third of the z|r convolution, 18 % of the operator's FLOPs - is
+        # issued on a second stream now and joins after the BA.  Speculative: wasted (off the critical path) when the
+        # edge set changes before the next call.  Small edge sets are launch bound, not compute bound: not worth it.
+        overlap = self.pgate is not None and E_act >= self.gate_overlap_min_edges
+        ba_overlap = None
+        if overlap:
+            main = torch.cuda.current_stream(self.device)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            self._side.wait_stream(main)
+            if self.gate_overlap_mode == "gated":
+                # handed to the BA, which releases it in one piece per Gauss-Newton iteration, each behind the start of
+                # that iteration's solve (vipe_overlap_fn): the solve needs a whole CU's LDS and would otherwise queue
+                # behind the convolution's workgroups
+                with torch.cuda.stream(self._side):  # the small global-context part at once, next to the first accumulate
+                    eng.hidden_gate_state(self.net_n, self.pgate, parts=1)
+                # the last piece has nothing after its solve to hide behind: it is the smallest
+                fr = self.gate_overlap_fractions if len(self.gate_overlap_fractions) == itrs else None
+                gate_state, ov = eng.gate_state_job(self.net_n, self.pgate, fractions=fr)
+                ba_overlap = ov(self._side)
+            else:  # "free": launched at once, competes with every BA kernel
+                with torch.cuda.stream(self._side):
+                    gate_state = eng.hidden_gate_state(self.net_n, self.pgate)
         # factor_graph.py:270-276 in one launch: target = coords1 + delta, weight with masked frames zeroed
         # (`weight[:, masks[pi, qi]] = 0` without the host sync of a boolean-mask assignment), damping[du] = eta.
         # target / weight are rewritten IN PLACE: their addresses only change with the edge set, so consecutive
@@ -430,7 +466,10 @@ class FactorGraph:
         E = target.shape[1]
         buf.bundle_adjustment(target.view(E, -1, 2), weight.view(E, -1, 2), self.damping, ii, jj, t0,
                               t1 if not fixed_motion else t0, itrs, 1e-3, 0.1, motion_only, limited_disp, False, False,
-                              plan=plan, ba_state=getattr(self, "_ba_state", None), plan_key=plan_key)
+                              plan=plan, ba_state=getattr(self, "_ba_state", None), plan_key=plan_key, overlap=ba_overlap)
+        if overlap:
+            main.wait_stream(self._side)
+            self._gate_state = gate_state
         self._age_lag += 1
         if getattr(self, "_h", None) is not None and self._h["age"].shape[0] == self._age.shape[0]:
             self._h["age"] += 1
@@ -536,6 +575,7 @@ class FactorGraph:
                     corr_n[..., :196] = corr1[0].permute(0, 2, 3, 1)
                 net, dw, eta, _ = eng.forward_nhwc(take(self.net_n).contiguous(), c["xb"], corr_n, take(motn).contiguous(),
                                                    ix=c["dixs"], n_src=c["n_src"], csr=c["csr"], pgate=c["pgate"])
+                self._gate_state = None
                 if whole:
                     self.net_n = net if net.data_ptr() != self.net_n.data_ptr() else net.clone()
                     if not self.weight.is_contiguous() or not self.target.is_contiguous():

@@ -29,9 +29,11 @@ from .._lib import check, lib, parse_struct, ptr, stream_ptr
 
 UpdateWeights = parse_struct("vipe_update_weights")   # include/vipe_amd.h: field order / types come from the header
 UpdateBuffers = parse_struct("vipe_update_buffers")
+GateStateJob = parse_struct("vipe_gate_state_job")
 
 ACT = {"none": 0, "relu": 1, "sigmoid": 2, "tanh": 3}
-EPI = {"plain": 0, "glo": 1, "zr": 2, "q": 3, "heads": 4, "eta": 5}
+EPI = {"plain": 0, "glo": 1, "zr": 2, "q": 3, "heads": 4, "eta": 5, "partial": 6}
+ACCINIT_F32 = 0x100  # VIPE_CONV_ACCINIT_F32
 CORR_CH = 200  # 196 correlation channels padded to a multiple of 8 (zeros)
 
 
@@ -93,6 +95,9 @@ class UpdateEngine:
         self.zr_s = _Packed(torch.cat([wz, wr], 0)[:, rest].contiguous(), torch.cat([bz, br], 0), d)
         self.q_s = _Packed(wq[:, rest].contiguous(), bq, d)
         self.gates_inp = _Packed(torch.cat([wz, wr, wq], 0)[:, 128:256].contiguous(), torch.zeros(384, device=d), d)
+        # ... and z|r once more split into its hidden-state part and its (corr | flow) part (hidden_gate_state)
+        self.zr_n = _Packed(torch.cat([wz, wr], 0)[:, 0:128].contiguous(), torch.cat([bz, br], 0), d)
+        self.zr_x = _Packed(torch.cat([wz, wr], 0)[:, 256:448].contiguous(), torch.cat([bz, br], 0), d)
         wd0, bd0 = wb(m.delta[0])
         ww0, bw0 = wb(m.weight[0])
         wa1, ba1 = wb(m.agg.conv1)
@@ -118,6 +123,7 @@ class UpdateEngine:
             setattr(wd_, name + "_w", pk.packed.data_ptr())
             setattr(wd_, name + "_b", pk.bias.data_ptr())
         wd_.zr_s_w, wd_.q_s_w = self.zr_s.packed.data_ptr(), self.q_s.packed.data_ptr()
+        wd_.zr_n_w, wd_.zr_x_w = self.zr_n.packed.data_ptr(), self.zr_x.packed.data_ptr()
         wd_.glo_wT, wd_.glo_b = self.glo_w.data_ptr(), self.glo_b.data_ptr()
         self._wdesc = wd_
         self._bdesc = {}
@@ -131,10 +137,13 @@ class UpdateEngine:
         check(lib().vipe_conv2d_fused(
             ptr(x0), x0.shape[-1], x0_coff, ptr(x1), x1.shape[-1] if x1 is not None else 0, x1_coff, split,
             ptr(pk.packed), ptr(pk.bias), ptr(extra), extra.shape[-1] if extra is not None else 0, extra_off,
-            ptr(y), y.shape[-1] if y is not None else 0, y_coff, ptr(y2), y2.shape[-1] if y2 is not None else 0, y2_coff,
+            ptr(y), (y if y is not None else fout).shape[-1] if (y is not None or mode == "partial") else 0, y_coff,
+            ptr(y2), y2.shape[-1] if y2 is not None else 0, y2_coff,
             ptr(net), net.shape[-1] if net is not None else 0, net_coff, ptr(z), ptr(fout), ptr(accinit),
             accinit.shape[-1] if accinit is not None else 0, ai_coff, B, H, W, cin, pk.cout,
-            pk.kh, pk.kw, ACT[act], EPI[mode], stream_ptr(x0)), "conv2d_fused")
+            pk.kh, pk.kw, ACT[act],
+            EPI[mode] | (ACCINIT_F32 if accinit is not None and accinit.dtype == torch.float32 else 0),
+            stream_ptr(x0)), "conv2d_fused")
 
     @staticmethod
     def supports_gate_split(ht, wd):
@@ -151,6 +160,68 @@ class UpdateEngine:
         self._conv(self.gates_inp, xbuf, 0, E, H, W, y=pg, act="none", cin=128)
         return pg
 
+    @torch.no_grad()
+    def hidden_gate_state(self, net, pgate, native=True, parts=3):
+        """Everything of the GRU gates that depends on the hidden state `net` [E,h,w,128] alone, on the CURRENT stream:
+        the three global-context terms (`extra` [E,384]) and pzr [E,h,w,256] f32 = pgate[..., :256] +
+        conv3x3(net; W_{z|r}[:, 0:128]).  `forward_nhwc(net, ..., gate_state=<the returned dict>)` then skips the
+        global-context stage and runs the z|r convolution over the (corr | flow) channels only - same result up to
+        fp32 summation order.  `FactorGraph.update` issues this for the NEW hidden state on a second stream right after
+        the operator, so that it runs while the dense BA (one busy workgroup for most of its time) has the chip."""
+        E, H, W, _ = net.shape
+        glo = self._buf("glo", (E, 128), torch.float32)
+        extra = self._buf("extra", (E, 384), torch.float32)
+        pzr = self._buf("pzr", (E, H, W, 256), torch.float32)
+        if native:
+            b = UpdateBuffers()
+            b.E, b.H, b.W = E, H, W
+            b.pgate, b.pzr, b.glo, b.extra = pgate.data_ptr(), pzr.data_ptr(), glo.data_ptr(), extra.data_ptr()
+            check(lib().vipe_update_gate_state(ctypes.addressof(self._wdesc), ctypes.addressof(b), ptr(net), parts,
+                                               stream_ptr(net)), "update_gate_state")
+        else:
+            if parts & 1:
+                glo.zero_()
+                self._conv(self.gw, net, 0, E, H, W, mode="glo", net=net, fout=glo)
+                check(lib().vipe_glo_context(ptr(glo), ptr(self.glo_w), ptr(self.glo_b), ptr(extra), E, H * W,
+                                             stream_ptr(glo)), "glo_context")
+            if parts & 2:
+                self._conv(self.zr_n, net, 0, E, H, W, mode="partial", fout=pzr, accinit=pgate, ai_coff=0)
+        return dict(net_ptr=net.data_ptr(), pgate_ptr=pgate.data_ptr(), shape=tuple(net.shape), pzr=pzr, extra=extra)
+
+    def gate_state_job(self, net, pgate, fractions=None):
+        """The z|r part of `hidden_gate_state(net, pgate)` (parts = 2), not launched: (gate_state dict, overlap triple) for
+        `slam_ext.dense_ba(overlap=...)` / `GraphBuffer.bundle_adjustment(overlap=...)` - the library enqueues it in
+        pieces (`vipe_update_gate_state_piece`) on the given stream while the BA's solve kernels run; `fractions`:
+        share of the edges per piece (default: even).  The dict is valid once that BA call has returned, the stream has
+        been joined AND `hidden_gate_state(net, pgate, parts=1)` has run; it keeps the descriptors alive."""
+        E, H, W, _ = net.shape
+        glo = self._buf("glo", (E, 128), torch.float32)
+        extra = self._buf("extra", (E, 384), torch.float32)
+        pzr = self._buf("pzr", (E, H, W, 256), torch.float32)
+        b = UpdateBuffers()
+        b.E, b.H, b.W = E, H, W
+        b.pgate, b.pzr, b.glo, b.extra = pgate.data_ptr(), pzr.data_ptr(), glo.data_ptr(), extra.data_ptr()
+        job = GateStateJob()
+        job.weights, job.buffers, job.net = ctypes.addressof(self._wdesc), ctypes.addressof(b), net.data_ptr()
+        bounds = None
+        if fractions:
+            cum, acc = [0], 0.0
+            for f in fractions[:-1]:
+                acc += f
+                cum.append(min(E, int(round(E * acc / sum(fractions)))))
+            cum.append(E)
+            bounds = (ctypes.c_int * len(cum))(*cum)
+            job.bounds, job.n_bounds = ctypes.addressof(bounds), len(cum)
+        fn = ctypes.cast(lib().vipe_update_gate_state_piece, ctypes.c_void_p).value
+        gs = dict(net_ptr=net.data_ptr(), pgate_ptr=pgate.data_ptr(), shape=tuple(net.shape), pzr=pzr, extra=extra,
+                  keep=(b, job, bounds))
+        return gs, (lambda stream: (stream.cuda_stream, fn, ctypes.addressof(job)))
+
+    @staticmethod
+    def gate_state_matches(gs, net, pgate):
+        return (gs is not None and pgate is not None and gs["net_ptr"] == net.data_ptr() and
+                gs["pgate_ptr"] == pgate.data_ptr() and gs["shape"] == tuple(net.shape))
+
     def _buf(self, name, shape, dtype=torch.float16):
         t = self._bufs.get(name)
         if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
@@ -160,7 +231,7 @@ class UpdateEngine:
 
     @torch.no_grad()
     def forward_nhwc(self, net, xbuf, corr, motn, ix=None, n_src=None, net_out=None, want_upmask=False, csr=None,
-                     pgate=None, native=True):
+                     pgate=None, native=True, gate_state=None):
         """The operator on channels-last state.
 
         net  [E,h,w,128] f16 hidden state;  xbuf [E,h,w,320] f16 with the context features `inp` in channels
@@ -170,8 +241,11 @@ class UpdateEngine:
 
         `native` (default): ONE library call sequences the whole operator (`vipe_update_operator`); native=False issues
         the same kernels one by one from here - the instrumentable form (bench.py brackets single launches with events),
-        checked equal to the native one by tests/test_gpu_parity.py."""
+        checked equal to the native one by tests/test_gpu_parity.py.  `gate_state`: result of
+        `hidden_gate_state(net, pgate)` for exactly this `net` (ignored when it does not match)."""
         E, H, W, _ = net.shape
+        if not self.gate_state_matches(gate_state, net, pgate):
+            gate_state = None
         c1 = self._buf("c1", (E, H, W, 128))
         f1 = self._buf("f1", (E, H, W, 128))
         zb = self._buf("z", (E, H, W, 128))
@@ -183,7 +257,7 @@ class UpdateEngine:
             net_out = torch.empty_like(net)
         if native:
             return self._forward_native(net, xbuf, corr, motn, ix, n_src, net_out, want_upmask, csr, pgate,
-                                        (c1, f1, zb, rnet, hbuf, dw, glo))
+                                        (c1, f1, zb, rnet, hbuf, dw, glo), gate_state)
         # encoders (droid_net.py:481-482).  `corr` may be a deferred lookup ("lookup", levels, coords): lookup and the
         # first 1x1 convolution then run as ONE kernel and the [E,h,w,200] tensor never exists
         if isinstance(corr, tuple):
@@ -196,13 +270,19 @@ class UpdateEngine:
         self._conv(self.flow0, motn, 0, E, H, W, y=f1, act="relu")
         self._conv(self.flow2, f1, 0, E, H, W, y=xbuf, y_coff=256, act="relu")
         # global context (droid_net.py:392-393) and its three 1x1s (a [E,128] x [128,384] product)
-        glo.zero_()
-        self._conv(self.gw, net, 0, E, H, W, mode="glo", net=net, fout=glo)
         extra = self._buf("extra", (E, 384), torch.float32)
-        check(lib().vipe_glo_context(ptr(glo), ptr(self.glo_w), ptr(self.glo_b), ptr(extra), E, H * W, stream_ptr(glo)),
-              "glo_context")  # [E,128] x [128,384] + bias, / HW
+        if gate_state is None:
+            glo.zero_()
+            self._conv(self.gw, net, 0, E, H, W, mode="glo", net=net, fout=glo)
+            check(lib().vipe_glo_context(ptr(glo), ptr(self.glo_w), ptr(self.glo_b), ptr(extra), E, H * W, stream_ptr(glo)),
+                  "glo_context")  # [E,128] x [128,384] + bias, / HW
         # gates (droid_net.py:395-399)
-        if pgate is not None:  # context part precomputed (gate_context): 320 input channels, accumulators start at it
+        if gate_state is not None:  # hidden-state part precomputed as well (hidden_gate_state): 192 channels left for z|r
+            self._conv(self.zr_x, xbuf, 128, E, H, W, y=zb, y2=rnet, net=net, mode="zr", extra=extra,
+                       accinit=gate_state["pzr"], ai_coff=0, cin=192)
+            self._conv(self.q_s, rnet, 0, E, H, W, x1=xbuf, x1_coff=128, split=128, y=net_out, net=net, z=zb, mode="q",
+                       extra=extra, extra_off=256, accinit=pgate, ai_coff=256)
+        elif pgate is not None:  # context part precomputed (gate_context): 320 input channels, accumulators start at it
             self._conv(self.zr_s, net, 0, E, H, W, x1=xbuf, x1_coff=128, split=128, y=zb, y2=rnet, net=net, mode="zr",
                        extra=extra, accinit=pgate, ai_coff=0)
             self._conv(self.q_s, rnet, 0, E, H, W, x1=xbuf, x1_coff=128, split=128, y=net_out, net=net, z=zb, mode="q",
@@ -235,7 +315,8 @@ class UpdateEngine:
                 self._conv(self.upmask, a2, 0, n_src, H, W, y=upmask)
         return net_out, dw, eta, upmask
 
-    def _forward_native(self, net, xbuf, corr, motn, ix, n_src, net_out, want_upmask, csr, pgate, scratch):
+    def _forward_native(self, net, xbuf, corr, motn, ix, n_src, net_out, want_upmask, csr, pgate, scratch,
+                        gate_state=None):
         c1, f1, zb, rnet, hbuf, dw, glo = scratch
         E, H, W, _ = net.shape
         extra = self._buf("extra", (E, 384), torch.float32)
@@ -252,7 +333,9 @@ class UpdateEngine:
         lookup = isinstance(corr, tuple)
         tensors = (net, net_out, xbuf, motn, pgate, c1, f1, zb, rnet, hbuf, dw, glo, extra, order, rowptr, agg, a2, eta) + \
             ((tuple(corr[1]) + (corr[2],) + ((corr[3],) if len(corr) > 3 else ())) if lookup else (corr,))
-        key = tuple(0 if t is None else t.data_ptr() for t in tensors) + (E, H, W, n_src or 0)
+        pzr = gate_state["pzr"] if gate_state is not None else None
+        key = tuple(0 if t is None else t.data_ptr() for t in tensors) + (E, H, W, n_src or 0,
+                                                                         0 if pzr is None else pzr.data_ptr())
         b = self._bdesc.get(key)
         if b is None:
             if len(self._bdesc) > 16:
@@ -273,6 +356,8 @@ class UpdateEngine:
                                 hbuf=hbuf, dw=dw, glo=glo, extra=extra, order=order, rowptr=rowptr, agg=agg, a2=a2,
                                 eta=eta).items():
                 setattr(b, name, None if t is None else t.data_ptr())
+            if pzr is not None:
+                b.pzr, b.gate_state = pzr.data_ptr(), 1
             self._bdesc[key] = b
         check(lib().vipe_update_operator(ctypes.addressof(self._wdesc), ctypes.addressof(b), stream_ptr(net)),
               "update_operator")
