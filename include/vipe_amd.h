@@ -405,10 +405,11 @@ typedef struct {
   const int *order, *rowptr; /* CSR of the edges by source node (vipe_segment_mean_nhwc_f16) */
   void *agg, *a2;            /* scratch [n_src,H,W,128] */
   float* eta;                /* out [n_src,H,W] f32 */
-  float* pzr;                /* optional [E,H,W,256] f32: hidden-state part of the z|r gates (vipe_update_gate_state) */
-  int gate_state;            /* 1: `extra` and `pzr` already hold the hidden-state part of the gates for `net`
-                                (vipe_update_gate_state ran on it): the operator skips the global-context stage and the
-                                z|r convolution runs over (corr | flow) only, its accumulators starting from pzr */
+  float* pzr;                /* optional [gate_state,H,W,256] f32: hidden-state part of the z|r gates (vipe_update_gate_state) */
+  int gate_state;            /* n > 0: `extra` (all edges) and `pzr` (the first n edges) already hold the hidden-state part
+                                of the gates for `net` (vipe_update_gate_state ran on it): the operator skips the
+                                global-context stage, and the z|r convolution of the first n edges runs over (corr | flow)
+                                only, its accumulators starting from pzr; edges [n, E) take the unsplit convolution */
 } vipe_update_buffers;
 int vipe_update_operator(const vipe_update_weights* weights, const vipe_update_buffers* buffers, void* stream);
 
@@ -419,7 +420,8 @@ int vipe_update_operator(const vipe_update_weights* weights, const vipe_update_b
  * result of the unsplit operator up to fp32 summation order.  The point: d_net is final as soon as the operator has
  * run, while the dense BA that follows it in an update iteration keeps one workgroup busy - issued on a second stream
  * this stage (18 % of the operator's FLOPs) runs in the BA's shadow.  Needs buffers->pgate and buffers->pzr.
- * parts: 1 = the global-context terms, 2 = the z|r partial sums, 3 = both. */
+ * parts: 1 = the global-context terms (all E edges), 2 = the z|r partial sums (all E edges of the descriptor handed
+ * in: a caller that stages only the first n edges passes a descriptor with E = n), 3 = both. */
 int vipe_update_gate_state(const vipe_update_weights* weights, const vipe_update_buffers* buffers, const void* d_net,
                            int parts, void* stream);
 /* The z|r partial sums (parts = 2) in pieces, with the signature of vipe_overlap_fn: piece k of n covers edges

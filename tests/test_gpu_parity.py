@@ -1116,6 +1116,17 @@ def test_staged_hidden_gate_state_equals_unsplit_gates():
         outs[native] = [t.clone() for t in o[:3]] + [pzr]
     for a, b_ in zip(outs[True], outs[False]):
         assert torch.equal(a, b_)
+    # staged for the first 2 of the 5 edges only: those edges as above, the others bit-identical to the unsplit operator
+    part = {}
+    for native in (True, False):
+        gs = eng.hidden_gate_state(net, pg, native=native, n_staged=2)
+        assert gs["n_staged"] == 2 and gs["pzr"].shape[0] == 2
+        o = eng.forward_nhwc(net, xbuf.clone(), corr, motn, ix=ix, n_src=3, csr=csr, pgate=pg, gate_state=gs, native=native)
+        part[native] = [t.clone() for t in o[:3]]
+    for a, b_ in zip(part[True], part[False]):
+        assert torch.equal(a, b_)
+    assert torch.equal(part[True][0][:2], outs[True][0][:2]) and torch.equal(part[True][0][2:], ref[0][2:])
+    assert torch.equal(part[True][1][:2], outs[True][1][:2]) and torch.equal(part[True][1][2:], ref[1][2:])
     # the partial sums themselves: fp32 conv of the hidden state + the hoisted context part
     w = torch.cat([eng.m.gru.convz.weight, eng.m.gru.convr.weight], 0)[:, 0:128].detach().half().float().to(dev())
     want = torch.nn.functional.conv2d(net.float().permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1) + pg[..., :256].float()

@@ -71,8 +71,9 @@ VIPE_EXPORT int vipe_update_operator(const vipe_update_weights* wt, const vipe_u
                         nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, E, H, W, 4, 128, 7, 7, VIPE_ACT_RELU, 0, stream));
   RUN(vipe_conv2d_fused(b->f1, 128, 0, nullptr, 0, 0, 128, wt->flow2_w, wt->flow2_b, nullptr, 0, 0, b->xbuf, 320, 256, nullptr,
                         0, 0, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, E, H, W, 128, 64, 3, 3, VIPE_ACT_RELU, 0, stream));
-  const bool staged = b->gate_state != 0;  // hidden-state part of the gates computed ahead (vipe_update_gate_state)
-  if (staged) VIPE_CHECK_ARG(b->pgate && b->pzr && wt->zr_x_w);
+  const int Es = b->gate_state;  // leading edges with the hidden-state part of z|r computed ahead (vipe_update_gate_state)
+  const bool staged = Es != 0;
+  if (staged) VIPE_CHECK_ARG(Es > 0 && Es <= E && b->pgate && b->pzr && wt->zr_x_w);
   if (!staged) {
     // global context (droid_net.py:392-393) and its three 1x1s
     if (hipMemsetAsync(b->glo, 0, sizeof(float) * 128 * (size_t)E, s) != hipSuccess) return VIPE_EINVAL;
@@ -83,8 +84,16 @@ VIPE_EXPORT int vipe_update_operator(const vipe_update_weights* wt, const vipe_u
   // gates (droid_net.py:395-399); with pgate the context-feature part is the accumulators' initial value
   if (staged) {
     RUN(vipe_conv2d_fused(b->xbuf, 320, 128, nullptr, 0, 0, 192, wt->zr_x_w, wt->zr_b, b->extra, 384, 0, b->zb, 128, 0, b->rnet,
-                          128, 0, b->net, 128, 0, nullptr, nullptr, b->pzr, 256, 0, E, H, W, 192, 256, 3, 3, VIPE_ACT_NONE,
+                          128, 0, b->net, 128, 0, nullptr, nullptr, b->pzr, 256, 0, Es, H, W, 192, 256, 3, 3, VIPE_ACT_NONE,
                           2 | VIPE_CONV_ACCINIT_F32, stream));
+    if (Es < E) {
+      const int64_t px = (int64_t)Es * H * W;  // first pixel of the unstaged edges
+      auto h16 = [&](const void* p, int c) { return (const void*)((const char*)p + px * c * 2); };
+      RUN(vipe_conv2d_fused(h16(b->net, 128), 128, 0, h16(b->xbuf, 320), 320, 128, 128, wt->zr_s_w, wt->zr_b,
+                            b->extra + (int64_t)Es * 384, 384, 0, (void*)h16(b->zb, 128), 128, 0, (void*)h16(b->rnet, 128), 128, 0,
+                            h16(b->net, 128), 128, 0, nullptr, nullptr, h16(b->pgate, 384), 384, 0, E - Es, H, W, 320, 256, 3, 3,
+                            VIPE_ACT_NONE, 2, stream));
+    }
     RUN(vipe_conv2d_fused(b->rnet, 128, 0, b->xbuf, 320, 128, 128, wt->q_s_w, wt->q_b, b->extra, 384, 256, b->net_out, 128, 0,
                           nullptr, 0, 0, b->net, 128, 0, b->zb, nullptr, b->pgate, 384, 256, E, H, W, 320, 128, 3, 3,
                           VIPE_ACT_NONE, 3, stream));

@@ -42,6 +42,7 @@ class FactorGraph:
         self._side = None
         self.gate_overlap_min_edges = int(os.environ.get("VIPE_AMD_GATE_OVERLAP_MIN_EDGES", "64"))
         self.gate_overlap_mode = os.environ.get("VIPE_AMD_GATE_OVERLAP", "gated")  # "gated" | "free" (A/B)
+        self.gate_overlap_share = float(os.environ.get("VIPE_AMD_GATE_OVERLAP_SHARE", "0.5"))
         self.gate_overlap_fractions = [float(x) for x in os.environ.get("VIPE_AMD_GATE_OVERLAP_FRACTIONS", "0.4,0.4,0.2").split(",")]
         self.ii_inac = torch.as_tensor([], dtype=torch.long, device=device)
         self.jj_inac = torch.as_tensor([], dtype=torch.long, device=device)
@@ -403,6 +404,9 @@ class FactorGraph:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.device)
             self._side.wait_stream(main)
+            # the BA's shadow is shorter than the whole stage: the z|r part is staged for a share of the edges only (the
+            # others keep the unsplit convolution), the small global-context part for all of them
+            n_staged = max(1, int(round(self.gate_overlap_share * E_act)))
             if self.gate_overlap_mode == "gated":
                 # handed to the BA, which releases it in one piece per Gauss-Newton iteration, each behind the start of
                 # that iteration's solve (vipe_overlap_fn): the solve needs a whole CU's LDS and would otherwise queue
@@ -411,11 +415,11 @@ class FactorGraph:
                     eng.hidden_gate_state(self.net_n, self.pgate, parts=1)
                 # the last piece has nothing after its solve to hide behind: it is the smallest
                 fr = self.gate_overlap_fractions if len(self.gate_overlap_fractions) == itrs else None
-                gate_state, ov = eng.gate_state_job(self.net_n, self.pgate, fractions=fr)
+                gate_state, ov = eng.gate_state_job(self.net_n, self.pgate, fractions=fr, n_staged=n_staged)
                 ba_overlap = ov(self._side)
             else:  # "free": launched at once, competes with every BA kernel
                 with torch.cuda.stream(self._side):
-                    gate_state = eng.hidden_gate_state(self.net_n, self.pgate)
+                    gate_state = eng.hidden_gate_state(self.net_n, self.pgate, n_staged=n_staged)
         # factor_graph.py:270-276 in one launch: target = coords1 + delta, weight with masked frames zeroed
         # (`weight[:, masks[pi, qi]] = 0` without the host sync of a boolean-mask assignment), damping[du] = eta.
         # target / weight are rewritten IN PLACE: their addresses only change with the edge set, so consecutive

@@ -161,7 +161,7 @@ class UpdateEngine:
         return pg
 
     @torch.no_grad()
-    def hidden_gate_state(self, net, pgate, native=True, parts=3):
+    def hidden_gate_state(self, net, pgate, native=True, parts=3, n_staged=None):
         """Everything of the GRU gates that depends on the hidden state `net` [E,h,w,128] alone, on the CURRENT stream:
         the three global-context terms (`extra` [E,384]) and pzr [E,h,w,256] f32 = pgate[..., :256] +
         conv3x3(net; W_{z|r}[:, 0:128]).  `forward_nhwc(net, ..., gate_state=<the returned dict>)` then skips the
@@ -169,15 +169,19 @@ class UpdateEngine:
         fp32 summation order.  `FactorGraph.update` issues this for the NEW hidden state on a second stream right after
         the operator, so that it runs while the dense BA (one busy workgroup for most of its time) has the chip."""
         E, H, W, _ = net.shape
+        Es = E if n_staged is None else max(1, min(E, int(n_staged)))  # the z|r part is staged for the first Es edges
         glo = self._buf("glo", (E, 128), torch.float32)
         extra = self._buf("extra", (E, 384), torch.float32)
-        pzr = self._buf("pzr", (E, H, W, 256), torch.float32)
+        pzr = self._buf("pzr", (Es, H, W, 256), torch.float32)
         if native:
             b = UpdateBuffers()
-            b.E, b.H, b.W = E, H, W
+            b.H, b.W = H, W
             b.pgate, b.pzr, b.glo, b.extra = pgate.data_ptr(), pzr.data_ptr(), glo.data_ptr(), extra.data_ptr()
-            check(lib().vipe_update_gate_state(ctypes.addressof(self._wdesc), ctypes.addressof(b), ptr(net), parts,
-                                               stream_ptr(net)), "update_gate_state")
+            for part, n in ((1, E), (2, Es)):
+                if parts & part:
+                    b.E = n
+                    check(lib().vipe_update_gate_state(ctypes.addressof(self._wdesc), ctypes.addressof(b), ptr(net), part,
+                                                       stream_ptr(net)), "update_gate_state")
         else:
             if parts & 1:
                 glo.zero_()
@@ -185,18 +189,20 @@ class UpdateEngine:
                 check(lib().vipe_glo_context(ptr(glo), ptr(self.glo_w), ptr(self.glo_b), ptr(extra), E, H * W,
                                              stream_ptr(glo)), "glo_context")
             if parts & 2:
-                self._conv(self.zr_n, net, 0, E, H, W, mode="partial", fout=pzr, accinit=pgate, ai_coff=0)
-        return dict(net_ptr=net.data_ptr(), pgate_ptr=pgate.data_ptr(), shape=tuple(net.shape), pzr=pzr, extra=extra)
+                self._conv(self.zr_n, net, 0, Es, H, W, mode="partial", fout=pzr, accinit=pgate, ai_coff=0)
+        return dict(net_ptr=net.data_ptr(), pgate_ptr=pgate.data_ptr(), shape=tuple(net.shape), pzr=pzr, extra=extra,
+                    n_staged=Es)
 
-    def gate_state_job(self, net, pgate, fractions=None):
+    def gate_state_job(self, net, pgate, fractions=None, n_staged=None):
         """The z|r part of `hidden_gate_state(net, pgate)` (parts = 2), not launched: (gate_state dict, overlap triple) for
         `slam_ext.dense_ba(overlap=...)` / `GraphBuffer.bundle_adjustment(overlap=...)` - the library enqueues it in
         pieces (`vipe_update_gate_state_piece`) on the given stream while the BA's solve kernels run; `fractions`:
         share of the edges per piece (default: even).  The dict is valid once that BA call has returned, the stream has
         been joined AND `hidden_gate_state(net, pgate, parts=1)` has run; it keeps the descriptors alive."""
-        E, H, W, _ = net.shape
-        glo = self._buf("glo", (E, 128), torch.float32)
-        extra = self._buf("extra", (E, 384), torch.float32)
+        E_all, H, W, _ = net.shape
+        E = E_all if n_staged is None else max(1, min(E_all, int(n_staged)))  # the job covers the first E edges
+        glo = self._buf("glo", (E_all, 128), torch.float32)
+        extra = self._buf("extra", (E_all, 384), torch.float32)
         pzr = self._buf("pzr", (E, H, W, 256), torch.float32)
         b = UpdateBuffers()
         b.E, b.H, b.W = E, H, W
@@ -214,7 +220,7 @@ class UpdateEngine:
             job.bounds, job.n_bounds = ctypes.addressof(bounds), len(cum)
         fn = ctypes.cast(lib().vipe_update_gate_state_piece, ctypes.c_void_p).value
         gs = dict(net_ptr=net.data_ptr(), pgate_ptr=pgate.data_ptr(), shape=tuple(net.shape), pzr=pzr, extra=extra,
-                  keep=(b, job, bounds))
+                  n_staged=E, keep=(b, job, bounds))
         return gs, (lambda stream: (stream.cuda_stream, fn, ctypes.addressof(job)))
 
     @staticmethod
@@ -278,8 +284,12 @@ class UpdateEngine:
                   "glo_context")  # [E,128] x [128,384] + bias, / HW
         # gates (droid_net.py:395-399)
         if gate_state is not None:  # hidden-state part precomputed as well (hidden_gate_state): 192 channels left for z|r
-            self._conv(self.zr_x, xbuf, 128, E, H, W, y=zb, y2=rnet, net=net, mode="zr", extra=extra,
+            Es = gate_state["n_staged"]
+            self._conv(self.zr_x, xbuf, 128, Es, H, W, y=zb, y2=rnet, net=net, mode="zr", extra=extra,
                        accinit=gate_state["pzr"], ai_coff=0, cin=192)
+            if Es < E:  # the edges whose z|r part was not staged: the unsplit convolution on their slice
+                self._conv(self.zr_s, net[Es:], 0, E - Es, H, W, x1=xbuf[Es:], x1_coff=128, split=128, y=zb[Es:], y2=rnet[Es:],
+                           net=net[Es:], mode="zr", extra=extra[Es:], accinit=pgate[Es:], ai_coff=0)
             self._conv(self.q_s, rnet, 0, E, H, W, x1=xbuf, x1_coff=128, split=128, y=net_out, net=net, z=zb, mode="q",
                        extra=extra, extra_off=256, accinit=pgate, ai_coff=256)
         elif pgate is not None:  # context part precomputed (gate_context): 320 input channels, accumulators start at it
@@ -335,7 +345,8 @@ class UpdateEngine:
             ((tuple(corr[1]) + (corr[2],) + ((corr[3],) if len(corr) > 3 else ())) if lookup else (corr,))
         pzr = gate_state["pzr"] if gate_state is not None else None
         key = tuple(0 if t is None else t.data_ptr() for t in tensors) + (E, H, W, n_src or 0,
-                                                                         0 if pzr is None else pzr.data_ptr())
+                                                                         0 if pzr is None else pzr.data_ptr(),
+                                                                         0 if pzr is None else int(gate_state["n_staged"]))
         b = self._bdesc.get(key)
         if b is None:
             if len(self._bdesc) > 16:
@@ -357,7 +368,7 @@ class UpdateEngine:
                                 eta=eta).items():
                 setattr(b, name, None if t is None else t.data_ptr())
             if pzr is not None:
-                b.pzr, b.gate_state = pzr.data_ptr(), 1
+                b.pzr, b.gate_state = pzr.data_ptr(), int(gate_state["n_staged"])
             self._bdesc[key] = b
         check(lib().vipe_update_operator(ctypes.addressof(self._wdesc), ctypes.addressof(b), stream_ptr(net)),
               "update_operator")
