@@ -10,7 +10,7 @@ import json
 import sys
 
 stats, fetch, write, out = sys.argv[1:5]
-steps = int(sys.argv[5]) if len(sys.argv) > 5 else 25  # bench.py default: 3 warm-up + 20 timed + 2 event-timed steps
+steps = int(sys.argv[5]) if len(sys.argv) > 5 else 30  # bench.py default: 3 warm-up + 20 timed + 3 + 4 event-timed steps
 
 
 def short(n):

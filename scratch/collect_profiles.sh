@@ -1,0 +1,23 @@
+#!/bin/bash
+# run on the GPU box (gpurun): the round's judged profiles into gpurun_out/prof/ (copied to profiles/ afterwards)
+set -e
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/prof
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o b -- python3 $R/bench.py --no-cpu-baseline --no-secondary --no-hipgraph > $O/bench.log 2>&1
+echo bench stats done
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 $R/bench.py --no-cpu-baseline --no-secondary --no-hipgraph > $O/fetch.log 2>&1
+echo fetch done
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python3 $R/bench.py --no-cpu-baseline --no-secondary --no-hipgraph > $O/write.log 2>&1
+echo write done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/video -o v -- python3 $R/bench.py --mode video --frames 200 > $O/video.log 2>&1
+echo video done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/videob -o v -- python3 $R/bench.py --mode video --frames 200 --with-backend > $O/videob.log 2>&1
+echo video+backend done
+python3 $R/bench.py > $O/bench_line.json 2> $O/bench_line.err
+echo bench line done
+find $O -name "*_kernel_trace.csv" -delete
+find $O -name "*.db" -delete
+du -sh $O
+find $O -name "*.csv" | head -40
