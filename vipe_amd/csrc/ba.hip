@@ -2704,6 +2704,7 @@ __global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_c
 // so the order is immaterial).  A dependent fp64 operation costs ~40 cycles on this part: the pivot chain alone is
 // ~0.15 us per column - the floor of any Cholesky here - which is why the diagonal tile stays in one wave's registers.
 constexpr int CT = 64;
+typedef double double4c __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double rsqrt_seeded(double x) {
   // branch free (the callers are long fully unrolled blocks): pivots of a damped normal matrix are far inside the float
@@ -2738,75 +2739,103 @@ __global__ __launch_bounds__(256) void chol_potrf_kernel(BAArgs a, int k, int db
   if (t == 0) fail = 0;
   if (k == 0 && t == 0) w.info[7] = 0;  // failure flag of this factorisation
   __syncthreads();
-  // the tile travels global <-> LDS with all 256 threads (row segments, coalesced); wave 0 then takes one row per lane
-  for (int i = t; i < CT * CT; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    Ls[r][c] = (r < bw && c <= r) ? S[(int64_t)(c0 + r) * ld + c0 + c] : (c == r ? 1.0 : 0.0);
+  // the tile travels global <-> LDS with all 256 threads (row segments, coalesced), LM damping (matrix.py:179-186: poses
+  // (lambda, ep); intrinsics 1e-6; rig rotations 1e-4) added on the way in.  The last tile column of a system with
+  // n % 64 != 0 shares its tile row with the rhs (row n = c0 + bw): row bw of the tile carries it through the
+  // factorisation as one more row below the diagonal (its own "diagonal" entry is a dummy 1).
+  const bool has_rhs = bw < CT && c0 + bw == n;
+  {
+    const int n_free = w.info[0];
+    for (int i = t; i < CT * CT; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      double v = (r < bw && c <= r) ? S[(int64_t)(c0 + r) * ld + c0 + c] : (c == r ? 1.0 : 0.0);
+      if (has_rhs && r == bw && c < bw) v = S[(int64_t)n * ld + c0 + c];
+      if (r < bw && c == r) {
+        const int g = c0 + r;
+        const bool pose = g < 6 * n_free, rigrow = a.mv && g >= 6 * n_free + a.nintr;
+        const double ep = pose ? (double)prm.pose_ep : (rigrow ? 1e-4 : 1e-6);
+        const double lam = pose ? (double)prm.pose_damping : (rigrow ? 1e-4 : 1e-6);
+        v += ep + lam * (a.droid ? v : w.Hd[g]);
+      }
+      Ls[r][c] = v;
+    }
   }
   __syncthreads();
-  if (wave == 0) {
-    const int r = lane;
-    const int n_free = w.info[0];
-    double arow[CT];
-#pragma unroll
-    for (int c = 0; c < CT; ++c) arow[c] = Ls[r][c];
-    // the last tile column of a system with n % 64 != 0 shares its tile row with the rhs (row n = c0 + bw): lane bw carries
-    // it through the factorisation as one more row below the diagonal (its own "diagonal" entry is a dummy 1)
-    const bool rhs_lane = bw < CT && c0 + bw == n && r == bw;
-    if (rhs_lane) {
-#pragma unroll
-      for (int c = 0; c < CT; ++c)
-        if (c < bw) arow[c] = S[(int64_t)n * ld + c0 + c];
-    }
-    if (r < bw) {  // LM damping (matrix.py:179-186): poses (lambda, ep); intrinsics 1e-6; rig rotations 1e-4
-      const int g = c0 + r;
-      const bool pose = g < 6 * n_free, rigrow = a.mv && g >= 6 * n_free + a.nintr;
-      const double ep = pose ? (double)prm.pose_ep : (rigrow ? 1e-4 : 1e-6);
-      const double lam = pose ? (double)prm.pose_damping : (rigrow ? 1e-4 : 1e-6);
-      const double hd = a.droid ? 0.0 : w.Hd[g];
-#pragma unroll
-      for (int c = 0; c < CT; ++c)  // compile-time indices only: a runtime index would move the row to scratch memory
-        if (c == r) arow[c] += ep + lam * (a.droid ? arow[c] : hd);
-    }
-    // Right-looking, one column per step: the pivot by readlane (compile-time lane), the finished column published to
-    // LDS and read back by every lane as BROADCAST reads (one address per instruction: no bank conflicts) - a
-    // v_readlane per (row, column) pair instead costs ~85 cycles each through the SGPR file.  Fully unrolled, so the
-    // scheduler can slide the rank-1 update of step j under the dependent pivot chain of step j + 1.
+  // Blocked right-looking factorisation, four panels of 16 columns.  Panel: wave 0, one tile row per lane, the 16 panel
+  // entries of the row in registers; per column the pivot by readlane (compile-time lane), rsqrt from an fp32 seed + two
+  // fp64 Newton steps, the finished column published to LDS and read back as BROADCAST reads for the rank-1 update of
+  // the remaining panel columns only (<= 14 fused multiply-adds per lane instead of <= 62 over the whole tile row: the
+  // dependent pivot chain, ~0.15 us per column, is what is left).  Trailing update: all four waves, 16 x 16 tiles of the
+  // lower triangle, A_ij -= P_i P_j^T on the fp64 matrix cores straight in LDS.
+  {
     double* colb = &Li[0][0];  // scratch: two column buffers of 64 doubles (Li is not in use yet)
     bool bad = false;
-    double d = readlane_f64(arow[0], 0);
+    const int l16 = lane & 15, kq = lane >> 4;
 #pragma unroll
-    for (int j = 0; j < CT; ++j) {
-      const bool okp = d > 0.0;
-      bad |= (j < bw) & !okp;
-      d = okp ? d : 1.0;
-      const double rl = rsqrt_seeded(d);
-      const double lj = r == j ? d * rl : (r > j ? arow[j] * rl : 0.0);
-      arow[j] = lj;
-      // the NEXT pivot only needs lane j + 1's own entry of this column: form it now, ahead of the LDS round trip that
-      // the rest of the rank-1 update waits for (the dependent chain per column is then rsqrt -> mul -> fma -> readlane)
-      if (j + 1 < CT) {
-        arow[j + 1] = __builtin_fma(-lj, readlane_f64(lj, j + 1) , arow[j + 1]);
-        d = readlane_f64(arow[j + 1], j + 1);
+    for (int pnl = 0; pnl < 4; ++pnl) {
+      const int p0 = 16 * pnl;
+      if (wave == 0) {
+        const int r = lane;
+        double ar[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) ar[c] = Ls[r][p0 + c];
+        double d = readlane_f64(ar[0], p0);
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+          const int j = p0 + jj;
+          const bool okp = d > 0.0;
+          bad |= (j < bw) & !okp;
+          d = okp ? d : 1.0;
+          const double rl = rsqrt_seeded(d);
+          const double lj = r == j ? d * rl : (r > j ? ar[jj] * rl : 0.0);
+          ar[jj] = lj;
+          // the NEXT pivot only needs lane j + 1's own entry of this column: form it ahead of the LDS round trip
+          if (jj + 1 < 16) {
+            ar[jj + 1] = __builtin_fma(-lj, readlane_f64(lj, j + 1), ar[jj + 1]);
+            d = readlane_f64(ar[jj + 1], j + 1);
+          }
+          if (jj + 2 < 16) {
+            double* cb = colb + (jj & 1) * CT;
+            cb[r] = lj;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = jj + 2; c < 16; ++c) ar[c] = __builtin_fma(-lj, cb[p0 + c], ar[c]);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) Ls[r][p0 + c] = ar[c];  // rows above the diagonal hold zeros in finished columns
       }
-      double* cb = colb + (j & 1) * CT;
-      cb[r] = lj;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      __syncthreads();
+      if (pnl < 3) {
+        // tiles (ti, tj), pnl < tj <= ti <= 3, numbered ti (ti + 1) / 2 + tj relative to pnl + 1
+        const int nt = (3 - pnl) * (4 - pnl) / 2;
+        for (int e = wave; e < nt; e += 4) {
+          int ti = 0;
+          while ((ti + 1) * (ti + 2) / 2 <= e) ++ti;
+          const int tj = e - ti * (ti + 1) / 2;
+          const int R = 16 * (pnl + 1 + ti), C = 16 * (pnl + 1 + tj);
+          double4c acc;
 #pragma unroll
-      for (int c = j + 2; c < CT; ++c) {
-        arow[c] = __builtin_fma(-lj, cb[c], arow[c]);
-        // at most 16 column values in flight (the row itself holds 128 VGPRs): LDS reads may not cross, everything else
-        // may - the tail of this rank-1 update is meant to slide under the next step's pivot chain
-        if (((c - j) & 15) == 0) __builtin_amdgcn_sched_barrier(0x027E);
+          for (int r4 = 0; r4 < 4; ++r4) acc[r4] = Ls[R + kq + 4 * r4][C + l16];
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ls[R + l16][p0 + 4 * s4 + kq], Ls[C + l16][p0 + 4 * s4 + kq], acc, 0, 0, 0);
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) Ls[R + kq + 4 * r4][C + l16] = acc[r4];
+        }
+        __syncthreads();
       }
     }
     if (dbg) ts1 = wall_clock64();
-    if (bad) fail = 1;
-#pragma unroll
-    for (int c = 0; c < CT; ++c) {
-      Ls[r][c] = r < bw ? (c <= r ? arow[c] : 0.0) : (c == r ? 1.0 : 0.0);
-      if (rhs_lane && c < bw) S[(int64_t)n * ld + c0 + c] = arow[c];
+    if (wave == 0 && bad) fail = 1;
+    // the rhs row leaves for the workspace; the tile itself keeps the factor only (identity beyond bw, zeros above the
+    // diagonal - the trailing updates of the diagonal 16 x 16 tiles wrote there)
+    if (has_rhs && t < bw) S[(int64_t)n * ld + c0 + t] = Ls[bw][t];
+    __syncthreads();
+    for (int i = t; i < CT * CT; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      if (r >= bw || c > r) Ls[r][c] = c == r ? 1.0 : 0.0;
     }
   }
   __syncthreads();
@@ -2815,17 +2844,20 @@ __global__ __launch_bounds__(256) void chol_potrf_kernel(BAArgs a, int k, int db
     if (r < bw && c <= r) S[(int64_t)(c0 + r) * ld + c0 + c] = Ls[r][c];
   }
   if (dbg) ts2 = wall_clock64();
-  // ---- inverse of the factor tile.  (1) the four 16 x 16 diagonal blocks, one thread per column: forward substitution
+  // ---- inverse of the factor tile.  (1) the four 16 x 16 diagonal blocks, one thread per column: forward substitution,
+  //      column oriented - as soon as x[i] is known every later row's partial sum takes its term, so the dependent chain
+  //      per step is one multiply and one fused multiply-add (a row-oriented sum is a chain of i of them)
+  __syncthreads();  // (the tile store above read Ls; Li's first rows served as column buffers)
   if (t < 64) {
     const int b = t >> 4, cc = t & 15, o = 16 * b;
-    double x[16];
+    double sv[16], x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sv[i] = i == cc ? 1.0 : 0.0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      double sacc = i == cc ? 1.0 : 0.0;
+      x[i] = i >= cc ? sv[i] / Ls[o + i][o + i] : 0.0;
 #pragma unroll
-      for (int m = 0; m < 16; ++m)
-        if (m < i) sacc = __builtin_fma(-Ls[o + i][o + m], (m >= cc ? x[m] : 0.0), sacc);
-      x[i] = i >= cc ? sacc / Ls[o + i][o + i] : 0.0;
+      for (int m = i + 1; m < 16; ++m) sv[m] = __builtin_fma(-Ls[o + m][o + i], x[i], sv[m]);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) Li[o + i][o + cc] = x[i];
@@ -2835,33 +2867,38 @@ __global__ __launch_bounds__(256) void chol_potrf_kernel(BAArgs a, int k, int db
     if ((r >> 4) != (c >> 4)) Li[r][c] = 0.0;
   }
   __syncthreads();
-  // (2) off-diagonal blocks by distance d = 1..3: Linv(i,j) = -Dinv_i * sum_{m=j}^{i-1} L(i,m) Linv(m,j)
+  // (2) off-diagonal blocks by distance d = 1..3: Linv(i,j) = -Dinv_i * sum_{m=j}^{i-1} L(i,m) Linv(m,j), one wave per
+  //     block, both products on the fp64 matrix cores (T travels through LDS between them: D layout -> B operand)
   __shared__ double Tm[3][16][17];
-  for (int d = 1; d < 4; ++d) {
-    const int nblk = 4 - d;  // blocks (i = j + d, j), j = 0..nblk-1
-    for (int e = t; e < nblk * 256; e += 256) {
-      const int bj = e >> 8, rr = (e >> 4) & 15, cc = e & 15, bi = bj + d;
-      double sacc = 0.0;
-      for (int m = 16 * bj; m < 16 * bi; ++m) sacc = __builtin_fma(Ls[16 * bi + rr][m], Li[m][16 * bj + cc], sacc);
-      Tm[bj][rr][cc] = sacc;
-    }
-    __syncthreads();
-    for (int e = t; e < nblk * 256; e += 256) {
-      const int bj = e >> 8, rr = (e >> 4) & 15, cc = e & 15, bi = bj + d;
-      double sacc = 0.0;
+  {
+    const int l16 = lane & 15, kq = lane >> 4;
+    for (int d = 1; d < 4; ++d) {
+      const int bj = wave, bi = bj + d;  // blocks (bi, bj), bj = 0 .. 3 - d
+      if (bi < 4) {
+        double4c acc = {0.0, 0.0, 0.0, 0.0};
+        for (int m = bj; m < bi; ++m)
 #pragma unroll
-      for (int m = 0; m < 16; ++m) sacc = __builtin_fma(Li[16 * bi + rr][16 * bi + m], Tm[bj][m][cc], sacc);
-      Li[16 * bi + rr][16 * bj + cc] = -sacc;
+          for (int s4 = 0; s4 < 4; ++s4)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[16 * bi + l16][16 * m + 4 * s4 + kq], Li[16 * m + 4 * s4 + kq][16 * bj + l16], acc, 0, 0, 0);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) Tm[bj][kq + 4 * r4][l16] = acc[r4];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double4c acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Li[16 * bi + l16][16 * bi + 4 * s4 + kq], Tm[bj][4 * s4 + kq][l16], acc2, 0, 0, 0);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) Li[16 * bi + kq + 4 * r4][16 * bj + l16] = acc2[r4];
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   double* Wk = w.Wi + (int64_t)k * CT * CT;
   for (int i = t; i < CT * CT; i += 256) Wk[i] = Li[i >> 6][i & 63];
   if (t == 0 && fail) w.info[7] = 1;
   if (dbg && t == 0 && k == 1) { ts3 = wall_clock64(); printf("[chol_potrf] load+factor %lld store %lld inverse %lld (x10ns)\n", ts1 - ts0, ts2 - ts1, ts3 - ts2); }
 }
-
-typedef double double4c __attribute__((ext_vector_type(4)));
 
 // X = A L^-T for the tile rows below tile k; grid = tile rows (exits beyond the matrix)
 __global__ __launch_bounds__(256) void chol_trsm_kernel(BAArgs a, int k) {
@@ -2875,10 +2912,22 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(BAArgs a, int k) {
   __shared__ double As[CT][CT + 2];  // pitch 66 doubles: the 16 x 4 operand fragments of a wave spread over all banks
   __shared__ double Ls[CT][CT + 2];
   const double* Wk = w.Wi + (int64_t)k * CT * CT;
-  for (int i = t; i < CT * CT; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    As[r][c] = (r < nr && c < bw) ? w.S[(int64_t)(R0 + r) * ld + c0 + c] : 0.0;
-    Ls[r][c] = Wk[i];
+  {
+    // all 32 loads of a thread in flight before the first LDS store (a load -> store loop is one L2 round trip per
+    // iteration: most of this kernel's 10 us)
+    double va[16], vl[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int i = t + 256 * q, r = i >> 6, c = i & 63;
+      va[q] = (r < nr && c < bw) ? w.S[(int64_t)(R0 + r) * ld + c0 + c] : 0.0;
+      vl[q] = Wk[i];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int i = t + 256 * q, r = i >> 6, c = i & 63;
+      As[r][c] = va[q];
+      Ls[r][c] = vl[q];
+    }
   }
   __syncthreads();
   // wave w: rows 16 w .. 16 w + 15; X[r][c] = sum_m A[r][m] Linv[c][m]
@@ -2914,13 +2963,34 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(BAArgs a, int k) {
   const int bw = min(CT, n - c0), nri = min(CT, n + 1 - Ri), ncj = min(CT, n - Rj);
   __shared__ double Xi[CT][CT + 2];
   __shared__ double Xj[CT][CT + 2];
-  for (int i = t; i < CT * CT; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    Xi[r][c] = (r < nri && c < bw) ? w.S[(int64_t)(Ri + r) * ld + c0 + c] : 0.0;
-    Xj[r][c] = (r < ncj && c < bw) ? w.S[(int64_t)(Rj + r) * ld + c0 + c] : 0.0;
+  const int l16 = lane & 15, kq = lane >> 4;
+  // every load of the thread - the two operand tiles and the 16 entries of A_ij it will update - is in flight before
+  // the first dependent instruction (load -> LDS store loops and the read-modify-write at the end were one L2 round
+  // trip per iteration each)
+  double aold[4][4];
+  {
+    double vi[16], vj[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int i = t + 256 * q, r = i >> 6, c = i & 63;
+      vi[q] = (r < nri && c < bw) ? w.S[(int64_t)(Ri + r) * ld + c0 + c] : 0.0;
+      vj[q] = (r < ncj && c < bw) ? w.S[(int64_t)(Rj + r) * ld + c0 + c] : 0.0;
+    }
+#pragma unroll
+    for (int tc = 0; tc < 4; ++tc)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int rr = 16 * wave + kq + 4 * r4, cc = 16 * tc + l16;
+        aold[tc][r4] = (rr < nri && cc < ncj && Rj + cc <= Ri + rr) ? w.S[(int64_t)(Ri + rr) * ld + Rj + cc] : 0.0;
+      }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int i = t + 256 * q, r = i >> 6, c = i & 63;
+      Xi[r][c] = vi[q];
+      Xj[r][c] = vj[q];
+    }
   }
   __syncthreads();
-  const int l16 = lane & 15, kq = lane >> 4;
 #pragma unroll
   for (int tc = 0; tc < 4; ++tc) {
     double4c acc = {0.0, 0.0, 0.0, 0.0};
@@ -2930,7 +3000,7 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(BAArgs a, int k) {
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
       const int rr = 16 * wave + kq + 4 * r4, cc = 16 * tc + l16;
-      if (rr < nri && cc < ncj && Rj + cc <= Ri + rr) w.S[(int64_t)(Ri + rr) * ld + Rj + cc] -= acc[r4];
+      if (rr < nri && cc < ncj && Rj + cc <= Ri + rr) w.S[(int64_t)(Ri + rr) * ld + Rj + cc] = aold[tc][r4] - acc[r4];
     }
   }
 }
@@ -2947,7 +3017,11 @@ __global__ __launch_bounds__(512) void chol_backsub_kernel(BAArgs a) {
   const int Tc = (n + CT - 1) / CT;
   auto load_tile = [&](int k, int b) {
     const double* Wk = w.Wi + (int64_t)k * CT * CT;
-    for (int i = t; i < CT * CT; i += 512) Li[b][i >> 6][i & 63] = Wk[i];
+    double v[8];  // all eight loads in flight before the first LDS store
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = Wk[t + 512 * q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) Li[b][(t + 512 * q) >> 6][(t + 512 * q) & 63] = v[q];
   };
   load_tile(Tc - 1, (Tc - 1) & 1);
   __syncthreads();
@@ -2970,14 +3044,20 @@ __global__ __launch_bounds__(512) void chol_backsub_kernel(BAArgs a) {
     for (int c = t; c < c0; c += 512) {  // y[c] -= sum_r L[c0 + r][c] x[r]
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
       const double* col = w.S + (int64_t)c0 * ld + c;
-#pragma unroll 4
-      for (int r = 0; r + 3 < bw; r += 4) {
-        s0 = __builtin_fma(col[(int64_t)r * ld], xk[r], s0);
-        s1 = __builtin_fma(col[(int64_t)(r + 1) * ld], xk[r + 1], s1);
-        s2 = __builtin_fma(col[(int64_t)(r + 2) * ld], xk[r + 2], s2);
-        s3 = __builtin_fma(col[(int64_t)(r + 3) * ld], xk[r + 3], s3);
+      int r = 0;
+      for (; r + 15 < bw; r += 16) {  // sixteen rows of the column in flight per pass (each is its own cache line)
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = col[(int64_t)(r + q) * ld];
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) {
+          s0 = __builtin_fma(v[q], xk[r + q], s0);
+          s1 = __builtin_fma(v[q + 1], xk[r + q + 1], s1);
+          s2 = __builtin_fma(v[q + 2], xk[r + q + 2], s2);
+          s3 = __builtin_fma(v[q + 3], xk[r + q + 3], s3);
+        }
       }
-      for (int r = bw & ~3; r < bw; ++r) s0 = __builtin_fma(col[(int64_t)r * ld], xk[r], s0);
+      for (; r < bw; ++r) s0 = __builtin_fma(col[(int64_t)r * ld], xk[r], s0);
       ys[c] -= (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
