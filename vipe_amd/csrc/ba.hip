@@ -2746,18 +2746,25 @@ __global__ __launch_bounds__(256) void chol_potrf_kernel(BAArgs a, int k, int db
   const bool has_rhs = bw < CT && c0 + bw == n;
   {
     const int n_free = w.info[0];
-    for (int i = t; i < CT * CT; i += 256) {
-      const int r = i >> 6, c = i & 63;
-      double v = (r < bw && c <= r) ? S[(int64_t)(c0 + r) * ld + c0 + c] : (c == r ? 1.0 : 0.0);
-      if (has_rhs && r == bw && c < bw) v = S[(int64_t)n * ld + c0 + c];
+    double v[16], hd[16];  // all loads of the thread in flight before the first LDS store
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int i = t + 256 * q, r = i >> 6, c = i & 63;
+      v[q] = (r < bw && c <= r) ? S[(int64_t)(c0 + r) * ld + c0 + c] : (c == r ? 1.0 : 0.0);
+      if (has_rhs && r == bw && c < bw) v[q] = S[(int64_t)n * ld + c0 + c];
+      hd[q] = (r < bw && c == r && !a.droid) ? w.Hd[c0 + r] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int i = t + 256 * q, r = i >> 6, c = i & 63;
       if (r < bw && c == r) {
         const int g = c0 + r;
         const bool pose = g < 6 * n_free, rigrow = a.mv && g >= 6 * n_free + a.nintr;
         const double ep = pose ? (double)prm.pose_ep : (rigrow ? 1e-4 : 1e-6);
         const double lam = pose ? (double)prm.pose_damping : (rigrow ? 1e-4 : 1e-6);
-        v += ep + lam * (a.droid ? v : w.Hd[g]);
+        v[q] += ep + lam * (a.droid ? v[q] : hd[q]);
       }
-      Ls[r][c] = v;
+      Ls[r][c] = v[q];
     }
   }
   __syncthreads();
