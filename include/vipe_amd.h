@@ -405,6 +405,10 @@ typedef struct {
   const int *order, *rowptr; /* CSR of the edges by source node (vipe_segment_mean_nhwc_f16) */
   void *agg, *a2;            /* scratch [n_src,H,W,128] */
   float* eta;                /* out [n_src,H,W] f32 */
+  void* side_stream;         /* optional second stream: the operator's two pairs of independent chains - (lookup + corr
+                                encoder) || (flow encoder), and (flow / weight heads) || (GraphAgg mean, agg conv 2, eta) -
+                                are issued on `stream` and on this one, forked and joined with events inside the call
+                                (a gather-bound kernel next to a matrix-bound one); NULL: everything on `stream` */
   float* pzr;                /* optional [gate_state,H,W,256] f32: hidden-state part of the z|r gates (vipe_update_gate_state) */
   int gate_state;            /* n > 0: `extra` (all edges) and `pzr` (the first n edges) already hold the hidden-state part
                                 of the gates for `net` (vipe_update_gate_state ran on it): the operator skips the

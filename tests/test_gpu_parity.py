@@ -1083,6 +1083,43 @@ def test_gate_context_hoisting_equals_full_gate_convolutions():
     assert (outs[0][2] - outs[1][2]).abs().max().item() < 1e-3
 
 
+def test_two_stream_operator_equals_single_stream():
+    """`vipe_update_buffers.side_stream`: the flow encoder next to the lookup + correlation encoder and the heads next to
+    the GraphAgg chain on a second stream, forked / joined with events inside the call - the same kernels on the same
+    data, so everything but the atomically pooled global-context sum is bit-identical (the hidden state inherits its
+    last-bit noise through the gates)."""
+    from vipe_amd.slam.networks import CorrBlock, UpdateModule
+    from vipe_amd.slam.update_engine import segment_csr
+    torch.manual_seed(0)
+    eng = UpdateModule().eval().engine(dev())
+    E, h, w = 6, 8, 64
+    g = torch.Generator().manual_seed(5)
+    net = torch.randn(E, h, w, 128, generator=g).tanh().half().to(dev())
+    xbuf = torch.zeros(E, h, w, 320, dtype=torch.float16, device=dev())
+    xbuf[..., :128] = torch.randn(E, h, w, 128, generator=g).relu().half().to(dev())
+    motn = (torch.randn(E, h, w, 4, generator=g) * 3).half().to(dev())
+    fm = torch.randn(4, 128, h, w, generator=g).half().to(dev())
+    i1, i2 = torch.tensor([0, 1, 2, 3, 0, 1], device=dev()), torch.tensor([1, 2, 3, 0, 2, 3], device=dev())
+    cb = CorrBlock.from_buffer(fm, i1, i2)
+    coords = (torch.rand(E, h, w, 2, generator=g) * torch.tensor([w - 1.0, h - 1.0])).to(dev())
+    ix = torch.tensor([0, 0, 1, 2, 2, 1], device=dev())
+    csr = segment_csr(ix, 3)
+    pg = eng.gate_context(xbuf)
+    outs = []
+    for min_edges in (1, 10 ** 9):
+        eng.op_side_min_edges = min_edges
+        eng._bdesc.clear()
+        xb = xbuf.clone()
+        n2, dw, eta, _ = eng.forward_nhwc(net, xb, cb.lookup_deferred(coords), motn, ix=ix, n_src=3, csr=csr, pgate=pg)
+        torch.cuda.synchronize()
+        outs.append((n2.clone(), dw.clone(), eta.clone(), xb))
+    assert eng._op_side is not None
+    assert torch.equal(outs[0][3], outs[1][3])  # encoders' outputs: bit-identical
+    assert (outs[0][0].float() - outs[1][0].float()).abs().max().item() < 2e-3
+    assert (outs[0][1] - outs[1][1]).abs().max().item() < 1e-2
+    assert (outs[0][2] - outs[1][2]).abs().max().item() < 1e-4
+
+
 def test_staged_hidden_gate_state_equals_unsplit_gates():
     """`UpdateEngine.hidden_gate_state` (global-context terms + the hidden-state third of the z|r convolution as raw
     fp32 accumulators, VIPE_CONV_PARTIAL) followed by the operator with `gate_state=` (z|r over the corr | flow

@@ -43,6 +43,19 @@ __global__ __launch_bounds__(256) void update_finish_kernel(const float* __restr
 
 }  // namespace
 
+namespace {
+// four events per (thread, device) for the fork / join of the operator's two-stream form
+hipEvent_t* operator_events() {
+  static thread_local hipEvent_t ev[64][4] = {};
+  int d = 0;
+  (void)hipGetDevice(&d);
+  hipEvent_t* e = ev[d & 63];
+  for (int i = 0; i < 4; ++i)
+    if (!e[i] && hipEventCreateWithFlags(&e[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+  return e;
+}
+}  // namespace
+
 extern "C" {
 
 VIPE_EXPORT int vipe_update_operator(const vipe_update_weights* wt, const vipe_update_buffers* b, void* stream) {
@@ -56,6 +69,21 @@ VIPE_EXPORT int vipe_update_operator(const vipe_update_weights* wt, const vipe_u
     rc = (call);               \
     if (rc != VIPE_OK) return rc; \
   } while (0)
+  // two-stream form: s2 carries the flow encoder next to the lookup + correlation encoder, and the heads next to the
+  // GraphAgg chain
+  hipStream_t s2 = (hipStream_t)b->side_stream;
+  hipEvent_t* ev = s2 ? operator_events() : nullptr;
+  if (s2 && !ev) return VIPE_EINVAL;
+  void* const stream2 = s2 ? b->side_stream : stream;
+#define FORK(i)                                                                                              \
+  do {                                                                                                       \
+    if (s2 && (hipEventRecord(ev[i], s) != hipSuccess || hipStreamWaitEvent(s2, ev[i], 0) != hipSuccess)) return VIPE_EINVAL; \
+  } while (0)
+#define JOIN(i)                                                                                              \
+  do {                                                                                                       \
+    if (s2 && (hipEventRecord(ev[i], s2) != hipSuccess || hipStreamWaitEvent(s, ev[i], 0) != hipSuccess)) return VIPE_EINVAL; \
+  } while (0)
+  FORK(0);
   // encoders (droid_net.py:481-482)
   if (b->levels[0]) {
     RUN(vipe_corr_lookup_conv1x1(b->levels, b->coords, wt->corr0_w, wt->corr0_b, b->c1, 128, 0, E, H, W, b->h2, b->w2, 128,
@@ -68,9 +96,10 @@ VIPE_EXPORT int vipe_update_operator(const vipe_update_weights* wt, const vipe_u
   RUN(vipe_conv2d_fused(b->c1, 128, 0, nullptr, 0, 0, 128, wt->corr2_w, wt->corr2_b, nullptr, 0, 0, b->xbuf, 320, 128, nullptr,
                         0, 0, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, E, H, W, 128, 128, 3, 3, VIPE_ACT_RELU, 0, stream));
   RUN(vipe_conv2d_fused(b->motn, 4, 0, nullptr, 0, 0, 4, wt->flow0_w, wt->flow0_b, nullptr, 0, 0, b->f1, 128, 0, nullptr, 0, 0,
-                        nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, E, H, W, 4, 128, 7, 7, VIPE_ACT_RELU, 0, stream));
+                        nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, E, H, W, 4, 128, 7, 7, VIPE_ACT_RELU, 0, stream2));
   RUN(vipe_conv2d_fused(b->f1, 128, 0, nullptr, 0, 0, 128, wt->flow2_w, wt->flow2_b, nullptr, 0, 0, b->xbuf, 320, 256, nullptr,
-                        0, 0, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, E, H, W, 128, 64, 3, 3, VIPE_ACT_RELU, 0, stream));
+                        0, 0, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, E, H, W, 128, 64, 3, 3, VIPE_ACT_RELU, 0, stream2));
+  JOIN(1);
   const int Es = b->gate_state;  // leading edges with the hidden-state part of z|r computed ahead (vipe_update_gate_state)
   const bool staged = Es != 0;
   if (staged) VIPE_CHECK_ARG(Es > 0 && Es <= E && b->pgate && b->pzr && wt->zr_x_w);
@@ -114,8 +143,11 @@ VIPE_EXPORT int vipe_update_operator(const vipe_update_weights* wt, const vipe_u
   RUN(vipe_conv2d_fused(b->net_out, 128, 0, nullptr, 0, 0, 128, wt->heads0_w, wt->heads0_b, nullptr, 0, 0, b->hbuf, 384, 0,
                         nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, E, H, W, 128, 384, 3, 3, VIPE_ACT_RELU, 0,
                         stream));
+  const bool two_tails = s2 && b->n_src > 0;
+  if (two_tails) FORK(2);
   RUN(vipe_conv2d_fused(b->hbuf, 384, 0, nullptr, 0, 0, 256, wt->heads2_w, wt->heads2_b, nullptr, 0, 0, nullptr, 0, 0, nullptr, 0,
-                        0, nullptr, 0, 0, nullptr, b->dw, nullptr, 0, 0, E, H, W, 256, 4, 3, 3, VIPE_ACT_NONE, 4, stream));
+                        0, nullptr, 0, 0, nullptr, b->dw, nullptr, 0, 0, E, H, W, 256, 4, 3, 3, VIPE_ACT_NONE, 4,
+                        two_tails ? stream2 : stream));
   if (b->n_src > 0) {
     // scatter_mean over the edges of each source node (droid_net.py:420-421), agg conv 2, eta (:422-429)
     VIPE_CHECK_ARG(b->order && b->rowptr && b->agg && b->a2 && b->eta);
@@ -126,6 +158,9 @@ VIPE_EXPORT int vipe_update_operator(const vipe_update_weights* wt, const vipe_u
     RUN(vipe_conv2d_fused(b->a2, 128, 0, nullptr, 0, 0, 128, wt->eta_w, wt->eta_b, nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, 0,
                           nullptr, 0, 0, nullptr, b->eta, nullptr, 0, 0, b->n_src, H, W, 128, 1, 3, 3, VIPE_ACT_NONE, 5, stream));
   }
+  if (two_tails) JOIN(3);
+#undef FORK
+#undef JOIN
 #undef RUN
   return vipe_launch_status();
 }

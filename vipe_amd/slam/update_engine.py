@@ -67,6 +67,10 @@ class UpdateEngine:
         self.device = device
         self.m = module
         self._bufs = {}
+        # second stream of the natively sequenced operator (vipe_update_buffers.side_stream): worth its four event
+        # operations only when the kernels are long enough, i.e. for large edge sets
+        self._op_side = None
+        self.op_side_min_edges = int(os.environ.get("VIPE_AMD_OP_SIDE_MIN_EDGES", "64"))
         self._pack_all()
 
     # ------------------------------------------------------------------ weights
@@ -344,7 +348,10 @@ class UpdateEngine:
         tensors = (net, net_out, xbuf, motn, pgate, c1, f1, zb, rnet, hbuf, dw, glo, extra, order, rowptr, agg, a2, eta) + \
             ((tuple(corr[1]) + (corr[2],) + ((corr[3],) if len(corr) > 3 else ())) if lookup else (corr,))
         pzr = gate_state["pzr"] if gate_state is not None else None
-        key = tuple(0 if t is None else t.data_ptr() for t in tensors) + (E, H, W, n_src or 0,
+        two_streams = E >= self.op_side_min_edges
+        if two_streams and self._op_side is None:
+            self._op_side = torch.cuda.Stream(device=self.device)
+        key = tuple(0 if t is None else t.data_ptr() for t in tensors) + (E, H, W, n_src or 0, two_streams,
                                                                          0 if pzr is None else pzr.data_ptr(),
                                                                          0 if pzr is None else int(gate_state["n_staged"]))
         b = self._bdesc.get(key)
@@ -369,6 +376,8 @@ class UpdateEngine:
                 setattr(b, name, None if t is None else t.data_ptr())
             if pzr is not None:
                 b.pzr, b.gate_state = pzr.data_ptr(), int(gate_state["n_staged"])
+            if two_streams:
+                b.side_stream = self._op_side.cuda_stream
             self._bdesc[key] = b
         check(lib().vipe_update_operator(ctypes.addressof(self._wdesc), ctypes.addressof(b), stream_ptr(net)),
               "update_operator")
