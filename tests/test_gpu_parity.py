@@ -1333,6 +1333,27 @@ def test_frontend_mirror_runs_and_keeps_graph_state_consistent():
     assert bool((buf.disps[:14] >= 1e-3).all())
 
 
+def test_clip_pipeline_at_bench_resolution_from_rgb():
+    """BASELINE configs[1]-shaped run at the bench resolution (512 x 384, 48 x 64 grid - the shapes every fast kernel
+    is specialised for): RGB frames -> motion filter (feature / context encoders, one operator application) on the side
+    stream -> keyframe frontend (proximity edges, pyramids into the pooled store, 4 + 2 update iterations with inactive
+    edges in the BA) -> the two global-BA passes, exactly as `bench.py --mode video --with-backend` runs it; pipelined
+    and serial forms of the driver must agree on the bookkeeping and produce close trajectories (the atomically pooled
+    global-context sums make them differ in the last bits)."""
+    import bench
+    res = {}
+    for pipelined in (True, False):
+        run_clip = bench.make_clip_runner(dev(), pipelined=pipelined)
+        res[pipelined] = run_clip(seed=3, n_frames=14, with_backend=True)
+    for r in res.values():
+        assert r["finite"] and r["keyframes"] == 14 and r["update_iterations"] == 8 + 6 * 6
+        assert 0 < r["edges_final"] <= 48 + 2 * 3 and r["backend_edges"] > r["edges_final"]
+        q = r["poses"][:, 3:]
+        assert (q.norm(dim=-1) - 1.0).abs().max().item() < 1e-4  # unit quaternions after every retraction
+    assert res[True]["edges_final"] == res[False]["edges_final"] and res[True]["backend_edges"] == res[False]["backend_edges"]
+    assert (res[True]["poses"] - res[False]["poses"]).abs().max().item() < 5e-2
+
+
 def test_frontend_prefetched_frame_distances_change_nothing():
     """The frontend launches the frame-distance kernel for the NEXT keyframe's edge proposal at the end of each step and
     reads the result from pinned memory one step later (no stream drain).  Same kernel, same inputs: the edge lists must
