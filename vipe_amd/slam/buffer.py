@@ -79,6 +79,16 @@ class GraphBuffer:
     def expand_edge_multiview(self, ii, jj, cross=True, view_offset=0):
         """buffer.py:318-361 -> pi, qi, di, pj, qj, dj (each [M * n_views])."""
         V = self.n_views
+        if V == 1:
+            # one view: pose index = frame index, view index 0 - no device arithmetic at all (the general form below is
+            # 14 small launches, three times per keyframe in the frontend).  The zeros are views of one cached buffer:
+            # callers only read these index vectors
+            ii_d, jj_d = ii.reshape(-1).to(self.device).contiguous(), jj.reshape(-1).to(self.device).contiguous()
+            z = getattr(self, "_zeros_i64", None)
+            n = max(int(ii_d.shape[0]), int(jj_d.shape[0]))
+            if z is None or z.shape[0] < n or z.device != ii_d.device:
+                z = self._zeros_i64 = torch.zeros(max(2 * n, 1024), dtype=torch.long, device=self.device)
+            return ii_d, z[:ii_d.shape[0]], ii_d, jj_d, z[:jj_d.shape[0]], jj_d
         qi = torch.arange(V, device=self.device).reshape(1, -1).repeat(ii.shape[0], 1)
         pi = ii.reshape(-1, 1).repeat(1, V).to(self.device)
         qj = torch.arange(V, device=self.device).reshape(1, -1).repeat(jj.shape[0], 1)
