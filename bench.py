@@ -506,6 +506,8 @@ def update_mode(args, D):
     # clip sharding: rank r owns clip r (seed differs per rank), no exchange during compute
     g, buf, graph = build_problem(device, args.keyframes, 384, 512, 3, args.extra_edges, seed=1234 + rank)
     E = int(graph.ii.numel())
+    if args.serial_operator:  # profiling aid: every kernel of the operator on ONE stream (per-kernel durations then are
+        graph.update_op.engine(device).op_side_min_edges = 10 ** 9  # those of the kernel running alone)
 
     def step():
         graph.update(t0=1, t1=args.keyframes, itrs=3)
@@ -654,6 +656,7 @@ def update_mode(args, D):
                        "gate_overlap": (f"hidden-state part of the next iteration's z|r gates + global context on a second "
                                         f"stream under the BA ({graph.gate_overlap_mode})"
                                         if getattr(graph, "_gate_state", None) is not None else "off"),
+                       "operator_streams": 1 if args.serial_operator or E < graph.update_op.engine(device).op_side_min_edges else 2,
                        "gate_context": "context-feature part of the GRU gates computed once per edge (at add_factors, "
                                        "like the correlation volume), not per iteration"
                                        if getattr(graph, "pgate", None) is not None else "recomputed every iteration"},
@@ -685,6 +688,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="update mode: skip the secondary figures (all-gate-work it/s, E=768 it/s, video frames/s)")
     ap.add_argument("--prof-steps", type=int, default=4)
+    ap.add_argument("--serial-operator", action="store_true",
+                    help="do not use the operator's second stream (vipe_update_buffers.side_stream): for kernel-stats profiles")
     ap.add_argument("--mode", default="update", choices=["update", "video", "backend", "plumbing"],
                     help="update: the headline metric (update iterations/s on the 48-keyframe graph); video: frames/s "
                          "of independent synthetic clips through the keyframe frontend, clip-sharded over the ranks "

@@ -5,11 +5,13 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o b -- python3 $R/bench.py --no-cpu-baseline --no-secondary --no-hipgraph > $O/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o b -- python3 $R/bench.py --no-cpu-baseline --no-secondary --no-hipgraph --serial-operator > $O/bench.log 2>&1
 echo bench stats done
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 $R/bench.py --no-cpu-baseline --no-secondary --no-hipgraph > $O/fetch.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench2 -o b -- python3 $R/bench.py --no-cpu-baseline --no-secondary --no-hipgraph > $O/bench2.log 2>&1
+echo bench two-stream stats done
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 $R/bench.py --no-cpu-baseline --no-secondary --no-hipgraph --serial-operator > $O/fetch.log 2>&1
 echo fetch done
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python3 $R/bench.py --no-cpu-baseline --no-secondary --no-hipgraph > $O/write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python3 $R/bench.py --no-cpu-baseline --no-secondary --no-hipgraph --serial-operator > $O/write.log 2>&1
 echo write done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/video -o v -- python3 $R/bench.py --mode video --frames 200 > $O/video.log 2>&1
 echo video done
