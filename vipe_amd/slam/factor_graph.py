@@ -16,6 +16,47 @@ from ..ext import slam_ext
 from .networks import AltCorrBlock, CorrBlock, CorrPool
 
 
+class _Growable:
+    """Per-edge state with spare capacity: `append` writes the new rows behind the live ones (the reference concatenates,
+    i.e. copies the whole tensor, on every `add_factors`: factor_graph.py:160-170 - 4.4 MB per edge for the operator's
+    input buffer and the hoisted gate context), `select` gathers the surviving rows into the OTHER of two backing buffers.
+    `view` is what the rest of the code sees: an ordinary contiguous tensor [n, ...]."""
+
+    def __init__(self):
+        self.bufs = [None, None]
+        self.cur = 0
+        self.n = 0
+
+    @property
+    def view(self):
+        return None if self.bufs[self.cur] is None else self.bufs[self.cur][:self.n]
+
+    def _room(self, which, rows, like):
+        b = self.bufs[which]
+        if b is None or b.shape[0] < rows or b.shape[1:] != like.shape[1:] or b.dtype != like.dtype or b.device != like.device:
+            # 25 % spare: the frontend's window oscillates by a few edges; the backend's graphs (tens of GB) must not double
+            nb = torch.empty((max(rows + rows // 4, 64),) + tuple(like.shape[1:]), dtype=like.dtype, device=like.device)
+            if b is not None and which == self.cur and self.n:
+                nb[:self.n] = b[:self.n]
+            self.bufs[which] = nb
+        return self.bufs[which]
+
+    def append(self, x):
+        b = self._room(self.cur, self.n + x.shape[0], x)
+        b[self.n:self.n + x.shape[0]] = x
+        self.n += x.shape[0]
+        return self.view
+
+    def select(self, idx):
+        src = self.view
+        other = self.cur ^ 1
+        dst = self._room(other, max(int(idx.shape[0]), 1), src)
+        if idx.shape[0]:
+            torch.index_select(src, 0, idx, out=dst[:idx.shape[0]])
+        self.cur, self.n = other, int(idx.shape[0])
+        return self.view
+
+
 class FactorGraph:
     def __init__(self, update_module, buffer, device, max_factors=48, incremental=True, cross_view=False):
         self.update_op = update_module
@@ -36,6 +77,7 @@ class FactorGraph:
         # channels-last state of the flow-update operator: hidden state [E,h,w,128] and [inp | corr | flow] features
         self.corr, self.net_n, self.xbuf = None, None, None
         self.pgate = None  # [E,h,w,384]: context-feature part of the GRU gates, computed once per edge
+        self._xbuf_store, self._pgate_store = _Growable(), _Growable()  # backing stores of xbuf / pgate (spare capacity)
         # hidden-state part of the gates for the CURRENT net_n (UpdateEngine.hidden_gate_state), computed on a second
         # stream in the shadow of the previous iteration's BA; None whenever net_n / the edge set changed since
         self._gate_state = None
@@ -122,11 +164,10 @@ class FactorGraph:
             xb = torch.zeros((ii.shape[0] * self.buffer.n_views, self.ht, self.wd, 320), dtype=torch.half,
                              device=self.device)
             xb[..., 0:128] = self.buffer.inps[pi, qi].permute(0, 2, 3, 1)
-            self.xbuf = xb if self.xbuf is None else torch.cat([self.xbuf, xb], 0)
+            self.xbuf = self._xbuf_store.append(xb)
             eng = self.update_op.engine(self.device)
             if eng.supports_gate_split(self.ht, self.wd):
-                pg = eng.gate_context(xb)
-                self.pgate = pg if self.pgate is None else torch.cat([self.pgate, pg], 0)
+                self.pgate = self._pgate_store.append(eng.gate_context(xb))
         target, _ = self.buffer.reproject_dense_disp(ii, jj)
         target = target[None]
         h = self.host_edges()
@@ -174,9 +215,9 @@ class FactorGraph:
         if self.net_n is not None:
             self.net_n = self.net_n[keep_x]
         if self.xbuf is not None:
-            self.xbuf = self.xbuf[keep_x]
+            self.xbuf = self._xbuf_store.select(keep_x)
         if self.pgate is not None:
-            self.pgate = self.pgate[keep_x]
+            self.pgate = self._pgate_store.select(keep_x)
         self.target = self.target[:, keep_x]
         self.weight = self.weight[:, keep_x]
         self._plan = None
