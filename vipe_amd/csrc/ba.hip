@@ -1706,7 +1706,13 @@ __global__ __launch_bounds__(TILE) void ba_schur_kernel(BAArgs a) {
   };
   const float* Ck = w.C + (int64_t)k * P;
   const int nchunks = (P + 63) / 64;
-  for (int pid = blockIdx.x; pid < npairs; pid += gridDim.x) {
+  // A frame with few tile pairs (the keyframe frontend: <= 28) leaves most of the grid's blocks without one: the pixel
+  // range of every pair is then cut into `slices` pieces, one workgroup each (the partial Grams meet in the fp64 atomics
+  // below) - a workgroup's 12 dependent chunk iterations per wave were the kernel's whole duration (42 us)
+  const int slices = max(1, min((int)gridDim.x / npairs, nchunks / NWAVE));
+  for (int item = blockIdx.x; item < npairs * slices; item += gridDim.x) {
+    const int pid = item / slices, slc = item % slices;
+    const int ch0 = (int)((int64_t)nchunks * slc / slices), ch1 = (int)((int64_t)nchunks * (slc + 1) / slices);
     int ta = 0;
     while ((ta + 1) * (ta + 2) / 2 <= pid) ++ta;
     const int tb = pid - ta * (ta + 1) / 2;
@@ -1738,11 +1744,11 @@ __global__ __launch_bounds__(TILE) void ba_schur_kernel(BAArgs a) {
         db[r] *= sq * rowm[16 + r];
       }
     };
-    if (wave < nchunks) fetch(wave, na, nb);
-    for (int ch = wave; ch < nchunks; ch += NWAVE) {
+    if (ch0 + wave < ch1) fetch(ch0 + wave, na, nb);
+    for (int ch = ch0 + wave; ch < ch1; ch += NWAVE) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { va[r] = na[r]; vb[r] = nb[r]; }
-      if (ch + NWAVE < nchunks) fetch(ch + NWAVE, na, nb);
+      if (ch + NWAVE < ch1) fetch(ch + NWAVE, na, nb);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         tile[wave][0][r * AM_P2 + lane] = va[r];
