@@ -2223,43 +2223,55 @@ __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_
     }
   }
   const int nblk = n_free + (F > 0 ? 1 : 0);
-  // factor the diagonal block of step kb (bw columns) in registers; publish L, blk, rd
+  // factor the diagonal block of step kb (bw columns); publish L, blk, rd.  Executed by the whole of wave 0: lane i < 6
+  // holds row i of the block, the pivot and the column entries other rows need travel by v_readlane (compile-time
+  // lanes) - per pivot the dependent chain is rsqrt -> multiply -> readlane -> fused multiply-add -> readlane instead
+  // of one lane walking all 21 entries: 71 -> 67 us per solve on the frontend's windows (a v_readlane round trip
+  // through the scalar file costs ~85 cycles, so the chain is hardly shorter: in the band solver the same change
+  // measured no gain and was not kept).  Same fused multiply-adds in the same order: bit-identical factors.
   auto factor_diag = [&](int kb) {
     const int j0 = 6 * kb, bw = min(6, n - j0);
-    double A[6][6];
+    const int i = t;  // lane = row of the block (lanes >= 6 run along and store nothing)
+    const int ic = i < 6 ? i : 5;
+    double A[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int c = 0; c < 6; ++c) A[c] = (ic < bw && c <= ic) ? L[off(j0 + ic) + j0 + c] : (c == ic ? 1.0 : 0.0);
+    double d = readlane_f64(A[0], 0);
+    bool bad = false;
 #pragma unroll
-      for (int j = 0; j <= i; ++j) A[i][j] = (i < bw) ? L[off(j0 + i) + j0 + j] : (i == j ? 1.0 : 0.0);
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      double d = A[j][j];
-#pragma unroll
-      for (int m = 0; m < j; ++m) d = __builtin_fma(-A[j][m], A[j][m], d);
-      if (!(d > 0.0)) { *failp = 1; d = 1.0; }
+    for (int c = 0; c < 6; ++c) {
+      const bool okp = d > 0.0;
+      bad |= (c < bw) & !okp;
+      d = okp ? d : 1.0;
       const double rl = rsqrt_nr(d);
-      A[j][j] = d * rl;
-      rd[j] = rl;
-      if (j < bw) rdall[j0 + j] = rl;
+      const double lj = ic == c ? d * rl : (ic > c ? A[c] * rl : 0.0);
+      A[c] = lj;
+      if (i == 0) {
+        rd[c] = rl;
+        if (c < bw) rdall[j0 + c] = rl;
+      }
+      if (c + 1 < 6) {
+        // the next pivot first (lane c + 1's own diagonal entry), then the rest of the rank-1 update
+        A[c + 1] = __builtin_fma(-lj, readlane_f64(lj, c + 1), A[c + 1]);
+        d = readlane_f64(A[c + 1], c + 1);
 #pragma unroll
-      for (int i = j + 1; i < 6; ++i) {
-        double sacc = A[i][j];
-#pragma unroll
-        for (int m = 0; m < j; ++m) sacc = __builtin_fma(-A[i][m], A[j][m], sacc);
-        A[i][j] = sacc * rl;
+        for (int m = c + 2; m < 6; ++m) A[m] = __builtin_fma(-lj, readlane_f64(lj, m), A[m]);
       }
     }
+    if (i == 0 && bad) *failp = 1;
+    if (i < 6) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int j = 0; j <= i; ++j) {
-        if (i < bw) L[off(j0 + i) + j0 + j] = A[i][j];
-        blk[i * 7 + j] = A[i][j];
+      for (int c = 0; c < 6; ++c) {
+        if (c <= i) {
+          if (i < bw) L[off(j0 + i) + j0 + c] = A[c];
+          blk[i * 7 + c] = A[c];
+        }
       }
+    }
   };
   __syncthreads();
   DN_STAMP(0)
-  if (t == 0) factor_diag(0);
+  if (t < 64) factor_diag(0);
   __syncthreads();
   DN_STAMP(1)
   for (int kb = 0; kb < nblk; ++kb) {
@@ -2301,7 +2313,7 @@ __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if (t == 0 && kb + 1 < nblk) factor_diag(kb + 1);
+      if (kb + 1 < nblk) factor_diag(kb + 1);
       DN_STAMP(5)
     } else {
       // waves 1..7: rows r >= R0 + nbw (the rows of the next diagonal block belong to wave 0), columns R0 <= c <= min(r, n - 1).
