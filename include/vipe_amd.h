@@ -48,7 +48,7 @@ extern "C" {
 
 /* library / build identification ("gfx950", ABI version) */
 const char* vipe_amd_version(void);
-int vipe_amd_abi_version(void);
+int vipe_amd_abi_version(void); /* 2 since round 2 (struct layouts of vipe_ba_params / vipe_update_buffers grew) */
 
 /* ---------------------------------------------------------------------------------------------
  * droid_net_ext  (csrc/droid_net_ext/droid.cpp:57-63)
