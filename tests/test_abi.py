@@ -116,3 +116,25 @@ def test_corr_ext_host_path_against_torch_autograd():
     g1, g2 = corr_ext.backward(a.detach(), b.detach(), go, *args.values())
     r1, r2 = torch.autograd.grad(ref, (a, b), go)
     assert torch.allclose(g1, r1, atol=1e-5) and torch.allclose(g2, r2, atol=1e-5)
+
+
+def test_gate_state_piece_validates_its_job_without_a_gpu():
+    """`vipe_update_gate_state_piece` (the vipe_overlap_fn the BA calls): argument checks happen before any launch."""
+    import ctypes
+    from vipe_amd import _lib
+    L = _lib.lib()
+    Job = _lib.parse_struct("vipe_gate_state_job")
+    Buf = _lib.parse_struct("vipe_update_buffers")
+    Wt = _lib.parse_struct("vipe_update_weights")
+    assert L.vipe_update_gate_state_piece(None, 0, 1, None) == -1
+    job, buf, wt = Job(), Buf(), Wt()
+    buf.E, buf.H, buf.W = 6, 8, 64
+    buf.pgate = buf.pzr = 0x1000
+    job.weights, job.buffers, job.net = ctypes.addressof(wt), ctypes.addressof(buf), 0x1000
+    assert L.vipe_update_gate_state_piece(ctypes.addressof(job), 3, 3, None) == -1   # piece out of range
+    bounds = (ctypes.c_int * 3)(0, 7, 6)                                              # not ascending / beyond E
+    job.bounds, job.n_bounds = ctypes.addressof(bounds), 3
+    assert L.vipe_update_gate_state_piece(ctypes.addressof(job), 0, 2, None) == -1
+    bounds2 = (ctypes.c_int * 3)(0, 6, 6)                                             # empty second piece: nothing to do
+    job.bounds = ctypes.addressof(bounds2)
+    assert L.vipe_update_gate_state_piece(ctypes.addressof(job), 1, 2, None) == 0

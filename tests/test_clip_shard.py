@@ -276,3 +276,26 @@ def test_depth_artifacts_round_trip_and_exr_layout(tmp_path):
         z.writestr("00003.exr", b"not an exr file")
     got = list(artifacts.read_depth_artifacts(str(p)))
     assert got[2][0] == 3 and got[2][1].shape == (37, 53) and bool(torch.isnan(got[2][1]).all())
+
+
+def test_growable_store_append_and_select_match_cat_and_index():
+    """`factor_graph._Growable` (backing store of the operator's per-edge input buffer and hoisted gate context): appends
+    behind the live rows, compaction into the other buffer - always the tensor `torch.cat` / `x[idx]` would give."""
+    import torch
+    from vipe_amd.slam.factor_graph import _Growable
+
+    g = torch.Generator().manual_seed(0)
+    st, ref = _Growable(), None
+    assert st.view is None
+    for step in range(12):
+        x = torch.randn(int(torch.randint(1, 9, (1,), generator=g)), 3, 5, generator=g).half()
+        ref = x if ref is None else torch.cat([ref, x], 0)
+        v = st.append(x)
+        assert v.is_contiguous() and torch.equal(v, ref)
+        if step % 3 == 2:  # drop a few rows (keep order), as rm_factors does
+            keep = torch.nonzero(torch.rand(ref.shape[0], generator=g) > 0.3).reshape(-1)
+            ref = ref[keep]
+            v = st.select(keep)
+            assert v.is_contiguous() and torch.equal(v, ref)
+    v = st.select(torch.zeros(0, dtype=torch.long))  # everything removed
+    assert v.shape[0] == 0 and st.append(torch.ones(2, 3, 5).half()).shape[0] == 2
