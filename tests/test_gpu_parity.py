@@ -1354,6 +1354,76 @@ def test_clip_pipeline_at_bench_resolution_from_rgb():
     assert (res[True]["poses"] - res[False]["poses"]).abs().max().item() < 5e-2
 
 
+def test_backend_depth_prior_branch_with_a_pluggable_depth_model():
+    """`SLAMBackend.run` with a depth model (backend.py:45-63): half of the passes with `optimize_intrinsics`, then
+    `GraphBuffer.update_disps_sens` for the intrinsics found so far - the focal-ratio rescale for "metric_depth" models,
+    per-frame re-estimation otherwise - then the rest with the intrinsics held.  The model is a stand-in (the reference's
+    monocular depth networks are outside the path): what is checked is the control flow and the bookkeeping."""
+    import bench
+    from types import SimpleNamespace
+    from vipe_amd.slam.backend import BackendArgs, SLAMBackend
+
+    class FakeDepth:
+        def __init__(self, kind):
+            self.depth_type, self.calls, self.focals = kind, 0, []
+
+        def estimate(self, inp):
+            self.calls += 1
+            self.focals.append(inp.focal_length)
+            V, H, W, _ = inp.rgb.shape
+            return SimpleNamespace(metric_depth=torch.full((V, H, W), 2.0, device=inp.rgb.device))
+
+    for kind in ("metric_depth", "model_space"):
+        g, buf, graph = bench.build_problem(dev(), 8, 128, 512, 3, 0, seed=31)
+        buf.images[:8] = 0.5
+        model = FakeDepth(kind)
+        for f in range(8):  # what SLAMSystem does per keyframe (system.py:162)
+            buf.update_disps_sens(model, frame_idx=f)
+        assert model.calls == 8 and torch.allclose(buf.disps_sens[:8], torch.full_like(buf.disps_sens[:8], 0.5))
+        f0 = buf.intrinsics[0, 0].item()
+        be = SLAMBackend(graph.update_op, buf, BackendArgs(optimize_intrinsics=True), dev())
+        be.depth_model = model
+        gb = be.run(4)
+        torch.cuda.synchronize()
+        f1 = buf.intrinsics[0, 0].item()
+        assert gb.ii.numel() > 0 and f1 != f0 and bool(torch.isfinite(buf.poses[:8]).all()) and bool(buf.dirty[:8].all())
+        assert torch.allclose(buf.last_depth_intrinsics, buf.intrinsics) == (kind != "metric_depth")
+        if kind == "metric_depth":   # no re-estimation: the prior is rescaled by the focal ratio at the half-way point
+            assert model.calls == 8
+            assert float((buf.disps_sens[:8] - 0.5).abs().max()) > 0 and float(buf.disps_sens[:8].std()) < 1e-6
+        else:                        # re-estimated for all frames with the focal found by the first half
+            assert model.calls == 16 and all(abs(x - f0) < 1e-6 for x in model.focals[:8]) and model.focals[8] != f0
+
+
+def test_adaptive_cross_view_indices_on_a_two_view_rig():
+    """`GraphBuffer.build_adaptive_cross_view_idx` (buffer.py:270-301): every (keyframe, view) gets the (keyframe, other
+    view) of smallest one-directional reprojection distance when that is below the threshold, else keeps its partner -
+    against the same selection written out with explicit loops over the distance tensor."""
+    from vipe_amd.slam.buffer import GraphBuffer
+    torch.manual_seed(5)
+    n, V = 5, 2
+    buf = GraphBuffer(96, 128, n_views=V, buffer_size=8, device=dev())
+    buf.n_frames = n
+    buf.intrinsics[:] = torch.tensor([100.0, 100.0, 64.0, 48.0], device=dev())
+    buf.poses[:n, 0] = 0.1 * torch.arange(n, device=dev())
+    buf.rig[1, 0] = 0.05
+    buf.disps[:n] = 0.5 + 0.1 * torch.rand(n, V, 12, 16, device=dev())
+    old = buf.cross_view_idx[:n].clone()
+    ix = torch.arange(n, device=dev())
+    ii, jj = [t.reshape(-1) for t in torch.meshgrid(ix, ix, indexing="ij")]
+    d = buf.frame_distance_dense_disp(ii, jj, beta=1.0, view_offset=1, bidirectional=False).reshape(n, n, V).cpu()
+    thresh = float(d.median())
+    buf.build_adaptive_cross_view_idx(valid_thresh=thresh)
+    got = buf.cross_view_idx[:n].cpu()
+    for s in range(n):
+        for v in range(V):
+            t_best = int(torch.argmin(d[s, :, v]))
+            if d[s, t_best, v] < thresh:
+                assert got[s, v].tolist() == [t_best, (v + 1) % V]
+            else:
+                assert got[s, v].tolist() == old[s, v].cpu().tolist()
+
+
 def test_frontend_prefetched_frame_distances_change_nothing():
     """The frontend launches the frame-distance kernel for the NEXT keyframe's edge proposal at the end of each step and
     reads the result from pinned memory one step later (no stream drain).  Same kernel, same inputs: the edge lists must

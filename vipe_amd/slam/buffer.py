@@ -49,6 +49,10 @@ class GraphBuffer:
         self.cross_view_idx = torch.zeros(buffer_size, n_views, 2, device=device, dtype=torch.long)
         self.cross_view_idx[..., 0] = torch.arange(buffer_size, device=device)[:, None]
         self.cross_view_idx[..., 1] = torch.tensor(cross_view_idx, device=device).long()[None]
+        # buffer.py:106: frames changed since the last visualisation dump.  Only host code ever reads it: kept on the host
+        # (the reference's device tensor costs a launch - and in the frontend an `ii.min()` read-back - per keyframe)
+        self.dirty = torch.zeros(buffer_size, dtype=torch.bool)
+        self.last_depth_intrinsics = None  # intrinsics the sensor disparities were last estimated with (buffer.py:233-268)
 
     def touch(self):
         """Declare that poses / disps / intrinsics / rig changed.  Results derived from them and kept across calls (the
@@ -155,6 +159,55 @@ class GraphBuffer:
         if getattr(self, "dirty", None) is not None:
             self.dirty[ix] = True
         self.n_frames -= 1
+
+    def update_disps_sens(self, depth_model, frame_idx=None):
+        """buffer.py:233-268: refresh the sensor-depth prior from a monocular depth model (one frame for the frontend, all
+        frames for the backend after the intrinsics moved).  The model is the caller's (the reference's networks are
+        outside the path): anything with `.depth_type` (str or enum whose value is "metric_depth" for models whose depth
+        scales with the focal length) and `.estimate(inp) -> obj.metric_depth [V,H,W]`, where `inp` carries
+        `rgb [V,H,W,3]` float 0-1 and `focal_length`."""
+        from types import SimpleNamespace
+        if depth_model is None:
+            return
+        if frame_idx is not None:
+            frames = [int(frame_idx)]
+        else:
+            assert self.last_depth_intrinsics is not None
+            if torch.allclose(self.last_depth_intrinsics, self.intrinsics):
+                return
+            dt = getattr(depth_model, "depth_type", None)
+            if getattr(dt, "value", dt) == "metric_depth":  # depth already estimated: only the scale moves with the focal
+                # (as the reference: `last_depth_intrinsics` is NOT advanced here, buffer.py:246-251 - a second call
+                # rescales by the ratio to the focal of the original estimate again)
+                self.disps_sens[: self.n_frames] *= self.last_depth_intrinsics[0][0].item() / self.intrinsics[0][0].item()
+                return
+            frames = range(self.n_frames)
+        assert self.n_views == 1
+        for f in frames:
+            inp = SimpleNamespace(rgb=self.images[f].movedim(1, -1).float(), focal_length=self.intrinsics[0][0].item())
+            disp = depth_model.estimate(inp).metric_depth[:, 3::8, 3::8]
+            self.disps_sens[f] = torch.where(disp > 0, disp.reciprocal(), disp)
+        self.last_depth_intrinsics = self.intrinsics.clone()
+
+    def build_adaptive_cross_view_idx(self, valid_thresh=400.0):
+        """buffer.py:270-301: for every (keyframe, view) the (keyframe, other view) with the smallest one-directional
+        reprojection distance becomes its cross-view partner, where that distance is below `valid_thresh`."""
+        if self.n_views == 1 or self.n_frames < 2:
+            return
+        n, V = self.n_frames, self.n_views
+        ix = torch.arange(n, device=self.device)
+        ii, jj = torch.meshgrid(ix, ix, indexing="ij")
+        ii, jj = ii.reshape(-1), jj.reshape(-1)
+        ds = [self.frame_distance_dense_disp(ii, jj, beta=1.0, view_offset=off, bidirectional=False)
+              .reshape(n, n, -1).permute(0, 2, 1) for off in range(1, V)]  # (source frame, view, target frame)
+        d_total = torch.stack(ds, dim=-1).reshape(n, V, -1)
+        d_min, inds_best = torch.min(d_total, dim=-1)
+        t_best, off_best = inds_best // len(ds), inds_best % len(ds)
+        tgt_view_best = (off_best + 1 + torch.arange(V, device=self.device)) % V
+        new_inds = torch.stack([t_best, tgt_view_best], dim=-1)
+        keep_old = ~(d_min < valid_thresh)
+        new_inds[keep_old] = self.cross_view_idx[:n][keep_old]
+        self.cross_view_idx[:n] = new_inds
 
     def frame_distance_dense_disp(self, ii, jj, beta=0.3, bidirectional=True, view_offset=0, n_frames=None):
         """buffer.py:550-593 -> [M, n_views].  `n_frames`: frames the indices may address (default: the buffer's count)."""

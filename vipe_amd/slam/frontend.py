@@ -108,6 +108,7 @@ class SLAMFrontend:
             self._init_pose()
         for v in range(self.video.n_views):
             self.video.disps[self.t1, v] = self.video.disps[self.t1 - 1, v].mean()
+        self.video.dirty[int(self.graph.host_edges()["ii"].min()):self.t1] = True  # frontend.py:124 (host mirror: no read-back)
         self.video.touch()
         self._prefetch_proximity()
 
@@ -124,6 +125,7 @@ class SLAMFrontend:
             self._init_pose()
         for v in range(self.video.n_views):
             self.video.disps[self.t1, v] = self.video.disps[self.t1 - 4:self.t1, v].mean()
+        self.video.dirty[:self.t1] = True
         self.is_initialized = True
         self.graph.rm_factors(self.graph.host_edges()["ii"] < a.warmup - 4, store=True)
         self.video.touch()
