@@ -324,6 +324,17 @@ int vipe_corr_sampler_backward_host(const float* h_in1, const float* h_in2, cons
                                     int padH, int padW, int dilH, int dilW, int dil_patchH, int dil_patchW, int dH, int dW);
 
 /* ---------------------------------------------------------------------------------------------
+ * utils_ext.nearest_neighbours (csrc/utils_ext/knn.cu:27-67, utils_bind.cpp:23-24): exact k nearest neighbours of every
+ * query point among the tree points, squared L2 distance, points of 1..3 coordinates (missing ones count as 0, as the
+ * reference's zero padding).  query [M,qdim] f32, tree [N,tdim] f32 -> dist [M,knn] f32 ascending, idx [M,knn] int32.
+ * Brute force with the tree staged through LDS (the reference builds a kd-tree per call); 1 <= knn <= 8, knn <= N.
+ * Equal distances resolve to the lower index (the reference's kd-tree order is unspecified).  Used by
+ * SLAMMap.project_map(infill=True) (interface.py:126-139) - outside the update iteration.
+ * ------------------------------------------------------------------------------------------- */
+int vipe_nearest_neighbours(const float* d_query, int qdim, const float* d_tree, int tdim, int64_t M, int64_t N, int knn,
+                            float* d_dist, int* d_idx, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * [fused] flow-update operator convolutions (UpdateModule, droid_net.py:432-499): NHWC fp16
  * implicit-GEMM convolution on MFMA, fp32 accumulate, fused bias + activation.
  *   x [B,H,W,Cin_total] f16, reads channels [cin_off, cin_off+Cin); w packed [KH*KW, Cin, Cout] f16

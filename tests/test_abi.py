@@ -65,7 +65,9 @@ def test_out_of_scope_submodules_exist_and_raise():
     for name in ["droid_net_ext", "slam_ext", "lietorch_ext", "scatter_ext", "corr_ext", "utils_ext", "grounding_dino_ext"]:
         assert hasattr(ext, name)
     with pytest.raises(NotImplementedError):
-        ext.utils_ext.nearest_neighbours(None, None, 1)
+        ext.grounding_dino_ext.ms_deform_attn_forward()
+    with pytest.raises(RuntimeError):  # implemented (HIP kernel), device tensors only - like the reference's CHECK_CUDA
+        ext.utils_ext.nearest_neighbours(torch.zeros(4, 2), torch.zeros(4, 2), 1)
 
 
 def test_scatter_host_path_and_autograd():

@@ -1424,6 +1424,52 @@ def test_adaptive_cross_view_indices_on_a_two_view_rig():
                 assert got[s, v].tolist() == old[s, v].cpu().tolist()
 
 
+@pytest.mark.parametrize("dims,knn", [(2, 1), (3, 1), (3, 4), (2, 8)])
+def test_nearest_neighbours_matches_brute_force(dims, knn):
+    """`utils_ext.nearest_neighbours` (knn.cu:27-67: squared L2, [dist, idx] of shape [M, knn]) against torch.cdist +
+    topk: identical distances; indices identical wherever the k-th and (k+1)-th distances differ."""
+    from vipe_amd.ext import utils_ext
+    g = torch.Generator().manual_seed(dims * 10 + knn)
+    q = torch.rand(3001, dims, generator=g).to(dev())
+    t = torch.rand(2500, dims, generator=g).to(dev())
+    dist, idx = utils_ext.nearest_neighbours(q, t, knn)
+    assert dist.shape == (3001, knn) and idx.shape == (3001, knn) and idx.dtype == torch.int32
+    d2 = torch.cdist(q.double(), t.double()) ** 2
+    want_d, want_i = torch.topk(d2, knn, dim=1, largest=False)
+    assert (dist.double() - want_d).abs().max().item() < 1e-6
+    got_d = torch.gather(d2, 1, idx.long())
+    assert (got_d - want_d).abs().max().item() < 1e-12  # the returned indices realise the k smallest distances
+    assert bool((dist[:, 1:] >= dist[:, :-1]).all())
+    with pytest.raises(RuntimeError):
+        utils_ext.nearest_neighbours(q, t[:2], 4)  # knn > N (knn.cu:32)
+
+
+def test_project_map_infill_takes_the_nearest_projected_point():
+    """`SLAMMap.project_map(infill=True)` (interface.py:126-139): every pixel of the target view gets the depth of the
+    projected map point nearest to its centre; pixels that contain a point agree with the non-infill rendering
+    wherever that pixel holds exactly one point."""
+    from vipe_amd.ext.lietorch import SE3
+    from vipe_amd.slam.buffer import GraphBuffer
+    torch.manual_seed(3)
+    n = 4
+    buf = GraphBuffer(96, 128, buffer_size=8, device=dev())
+    buf.n_frames = n
+    buf.intrinsics[:] = torch.tensor([100.0, 100.0, 64.0, 48.0], device=dev())
+    buf.poses[:n, 0] = 0.02 * torch.arange(n, device=dev())
+    buf.disps[:n] = 0.4 + 0.05 * torch.rand(n, 1, 12, 16, device=dev())
+    buf.tstamp[:n] = torch.arange(n, device=dev(), dtype=torch.int)
+    m = buf.extract_slam_map(filter_thresh=1e9)
+    pose = SE3(buf.poses[1:2].clone()).inv()  # camera -> world of keyframe 1
+    intr = buf.intrinsics[0] / 8.0
+    sparse = m.project_map(1, 0, (12, 16), intr, pose[0])
+    dense = m.project_map(1, 0, (12, 16), intr, pose[0], infill=True)
+    assert dense.shape == (12, 16) and bool((dense > 0).all()) and bool(torch.isfinite(dense).all())
+    hit = sparse > 0
+    assert int(hit.sum()) > 20
+    # a pixel's own point(s) are among the candidates: the nearest point's depth lies within the range of map depths
+    assert float(dense.min()) >= float(sparse[hit].min()) - 1e-4 and float(dense.max()) <= float(sparse[hit].max()) + 0.5
+
+
 def test_frontend_prefetched_frame_distances_change_nothing():
     """The frontend launches the frame-distance kernel for the NEXT keyframe's edge proposal at the end of each step and
     reads the result from pinned memory one step later (no stream drain).  Same kernel, same inputs: the edge lists must

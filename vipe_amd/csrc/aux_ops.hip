@@ -479,3 +479,70 @@ VIPE_EXPORT int vipe_corr_sampler_backward_host(const float* h_in1, const float*
   return VIPE_OK;
 }
 
+// ---- utils_ext.nearest_neighbours (knn.cu:27-67): exact kNN by brute force.  One lane = one query with its k best in
+// registers (kept ascending by insertion); the tree travels through LDS in tiles of 1024 points that all 256 queries
+// of the workgroup scan (broadcast reads).  4e9 distance evaluations (a 512 x 384 query grid against 21 000 projected
+// points) take a few milliseconds; the reference builds and walks a kd-tree per call.
+namespace {
+constexpr int NN_TILE = 1024, NN_KMAX = 8;
+
+__global__ __launch_bounds__(256) void nearest_kernel(const float* __restrict__ query, int qdim, const float* __restrict__ tree,
+                                                      int tdim, int64_t M, int64_t N, int knn, float* __restrict__ dist,
+                                                      int* __restrict__ idx) {
+  __shared__ float4 pts[NN_TILE];
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  if (q < M) {
+    qx = query[q * qdim];
+    if (qdim > 1) qy = query[q * qdim + 1];
+    if (qdim > 2) qz = query[q * qdim + 2];
+  }
+  float bd[NN_KMAX];
+  int bi[NN_KMAX];
+#pragma unroll
+  for (int k = 0; k < NN_KMAX; ++k) { bd[k] = __builtin_inff(); bi[k] = -1; }
+  for (int64_t t0 = 0; t0 < N; t0 += NN_TILE) {
+    const int cnt = (int)(N - t0 < NN_TILE ? N - t0 : NN_TILE);
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+      const float* p = tree + (t0 + i) * tdim;
+      pts[i] = make_float4(p[0], tdim > 1 ? p[1] : 0.f, tdim > 2 ? p[2] : 0.f, 0.f);
+    }
+    __syncthreads();
+    for (int i = 0; i < cnt; ++i) {
+      const float4 p = pts[i];
+      const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+      const float d = dx * dx + dy * dy + dz * dz;
+      if (d < bd[NN_KMAX - 1] && (knn == NN_KMAX || d < bd[knn - 1])) {
+        // insertion into the ascending list (strict <: an equal distance keeps the earlier, i.e. lower, index first)
+        float cd = d;
+        int ci = (int)(t0 + i);
+#pragma unroll
+        for (int k = 0; k < NN_KMAX; ++k) {
+          if (k < knn && cd < bd[k]) {
+            const float td = bd[k]; const int ti = bi[k];
+            bd[k] = cd; bi[k] = ci;
+            cd = td; ci = ti;
+          }
+        }
+      }
+    }
+  }
+  if (q < M) {
+#pragma unroll
+    for (int k = 0; k < NN_KMAX; ++k)
+      if (k < knn) { dist[q * knn + k] = bd[k]; idx[q * knn + k] = bi[k]; }
+  }
+}
+}  // namespace
+
+extern "C" VIPE_EXPORT int vipe_nearest_neighbours(const float* d_query, int qdim, const float* d_tree, int tdim, int64_t M,
+                                                   int64_t N, int knn, float* d_dist, int* d_idx, void* stream) {
+  VIPE_CHECK_ARG(M >= 0 && N >= 0 && qdim >= 1 && qdim <= 3 && tdim >= 1 && tdim <= 3 && knn >= 1 && knn <= NN_KMAX);
+  VIPE_CHECK_ARG(N >= knn && N <= 0x7fffffff);
+  if (M == 0) return VIPE_OK;
+  VIPE_CHECK_ARG(d_query && d_tree && d_dist && d_idx);
+  nearest_kernel<<<(unsigned)((M + 255) / 256), 256, 0, as_stream(stream)>>>(d_query, qdim, d_tree, tdim, M, N, knn, d_dist, d_idx);
+  return vipe_launch_status();
+}
+

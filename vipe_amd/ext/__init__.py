@@ -7,4 +7,5 @@ function names, argument order, return structure and error behaviour.
 """
 
 from . import corr_ext, droid_net_ext, lietorch_ext, scatter_ext, slam_ext  # noqa: F401
-from ._out_of_scope import grounding_dino_ext, utils_ext  # noqa: F401
+from ._out_of_scope import grounding_dino_ext  # noqa: F401
+from . import utils_ext  # noqa: F401

@@ -14,5 +14,4 @@ class _Absent:
         return fn
 
 
-utils_ext = _Absent("utils_ext", ["nearest_neighbours"])
 grounding_dino_ext = _Absent("grounding_dino_ext", ["ms_deform_attn_forward", "ms_deform_attn_backward"])

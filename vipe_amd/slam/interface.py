@@ -44,9 +44,9 @@ class SLAMMap:
     def project_map(self, frame_tstamp, view_idx, target_size, target_intrinsics, target_pose, infill=False, tstamp_nn=3):
         """Depth image [H,W] of the points of the keyframes around `frame_tstamp` seen from the camera whose
         camera->world pose is `target_pose` (an SE3), through a pinhole camera (interface.py:92-141).  Where several points fall into one pixel the
-        reference keeps whichever its scatter writes last (unspecified); here the nearest one is kept.  `infill`
-        needs `utils_ext.nearest_neighbours`, which is outside the path."""
-        require(not infill, "infill uses utils_ext.nearest_neighbours (out of scope)")
+        reference keeps whichever its scatter writes last (unspecified); here the nearest one is kept.  `infill`: every
+        pixel takes the depth of the projected point nearest to its centre (`utils_ext.nearest_neighbours`,
+        interface.py:126-139)."""
         right = int(np.searchsorted(self.dense_disp_frame_inds, frame_tstamp))
         right = min(right + tstamp_nn, len(self.dense_disp_frame_inds) - 1)
         left = max(right - 2 * tstamp_nn, 0)
@@ -60,6 +60,14 @@ class SLAMMap:
         H, W = target_size
         ok = (uu > 0) & (uu < W) & (vv > 0) & (vv < H) & (1.0 / z > 0)
         uu, vv, depth = uu[ok], vv[ok], z[ok]
+        if infill:
+            from ..ext import utils_ext
+            tree = torch.stack((uu, vv), dim=-1).contiguous()
+            qx, qy = torch.meshgrid(torch.arange(W, device=xyz.device).float() + 0.5,
+                                    torch.arange(H, device=xyz.device).float() + 0.5, indexing="xy")
+            query = torch.stack((qx, qy), dim=-1).reshape(-1, 2).contiguous()
+            _, inds = utils_ext.nearest_neighbours(query, tree, 1)
+            return depth[inds.view(-1).long()].reshape(H, W)
         out = torch.full((H * W,), float("inf"), device=xyz.device)
         out.scatter_reduce_(0, vv.floor().long() * W + uu.floor().long(), depth, reduce="amin")
         return torch.where(torch.isinf(out), torch.zeros_like(out), out).view(H, W)
