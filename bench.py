@@ -243,7 +243,7 @@ def make_clip_runner(device, features=False, pipelined=True):
     um = dn.update
     side_stream = torch.cuda.Stream(device=device)
 
-    def run_clip(seed, n_frames, with_backend=False):
+    def run_clip(seed, n_frames, with_backend=False, with_infill=False):
         buf = GraphBuffer(384, 512, buffer_size=n_frames + 16, device=device)
         buf.intrinsics[:] = torch.tensor([460.8, 460.8, 256.0, 192.0], device=device)
         # keyframe_thresh = 0: every synthetic frame stays a keyframe (random-weight flow would otherwise make the
@@ -296,6 +296,7 @@ def make_clip_runner(device, features=False, pipelined=True):
                 if side is not None:
                     main.wait_stream(side)  # the keyframe's features were produced on the side stream
                 buf.fmaps[t], buf.nets[t], buf.inps[t] = mf.f_fmap, mf.f_net, mf.f_inp
+                buf.tstamp[t] = f
                 if side is not None:
                     for x in (mf.f_fmap, mf.f_net, mf.f_inp):
                         x.record_stream(main)
@@ -320,12 +321,35 @@ def make_clip_runner(device, features=False, pipelined=True):
             gb = be.run(BackendArgs().backend_iters, update_depth=False)
             backend_edges = int(gb.ii.numel())
             torch.cuda.synchronize()
+        t_be = time.perf_counter() - t0
         n = buf.n_frames
+        infill_frames = None
+        if with_infill and not features:
+            # pass 2 of SLAMSystem.run (system.py:284-294): the features of EVERY frame once more, appended behind the
+            # keyframes in chunks of 16, each chunk's poses interpolated between its keyframes and refined by ten
+            # motion-only update iterations (InnerFiller)
+            from vipe_amd.slam.encoders import normalize_images
+            from vipe_amd.slam.inner_filler import InfillArgs, InnerFiller
+            filler = InnerFiller(um, buf, InfillArgs(), device)
+            filler.set_start_idx(n)
+            for f in range(n_frames):
+                img = pool_img[f % 32]
+                x4 = normalize_images(img)
+                fmap = dn.encode_features(img, x4)
+                net, inp = dn.encode_context(img, x4)
+                t = buf.n_frames
+                buf.fmaps[t], buf.nets[t], buf.inps[t], buf.tstamp[t] = fmap, net, inp, f
+                buf.n_frames += 1
+                if filler.check() or f == n_frames - 1:
+                    filler.compute()
+            infill_frames = int(filler.get_result().poses.data.shape[0])
+            torch.cuda.synchronize()
         finite = bool(torch.isfinite(buf.poses[:n]).all() and torch.isfinite(buf.disps[:n]).all())
         return {"poses": buf.poses[:n].clone(), "intrinsics": buf.intrinsics[0, :4].clone(), "frames": n_frames,
-                "keyframes": int(n), "frontend_seconds": t_fe, "seconds": time.perf_counter() - t0, "finite": finite,
+                "keyframes": int(n), "frontend_seconds": t_fe, "backend_seconds": t_be - t_fe, "seconds_without_infill": t_be,
+                "seconds": time.perf_counter() - t0, "finite": finite,
                 "update_iterations": fe.n_updates, "edges_final": int(fe.graph.ii.numel()),
-                "backend_edges": backend_edges}
+                "backend_edges": backend_edges, "infill_frames": infill_frames}
 
     return run_clip
 
@@ -348,7 +372,7 @@ def video_mode(args, D):
     stats = []
 
     def process(cid):
-        r = run_clip(seed=cid, n_frames=args.frames, with_backend=args.with_backend)
+        r = run_clip(seed=cid, n_frames=args.frames, with_backend=args.with_backend, with_infill=args.with_infill)
         stats.append(r)
         return ClipResult(cid, r["poses"], r["intrinsics"], ok=r["finite"])
 
@@ -379,8 +403,9 @@ def video_mode(args, D):
                                    f"iterations per keyframe, one all_gather of the results, artifacts by rank 0",
                        "clips_ok": sum(r.ok for r in results), "clips": len(results), "artifacts_written": len(written),
                        "gather_backend": (D.dist.get_backend() if D.dist.is_initialized() else "none (1 rank)"),
-                       "rank0_clip": {k: mine.get(k) for k in ("frontend_seconds", "seconds", "update_iterations",
-                                                               "keyframes", "edges_final", "backend_edges", "finite")},
+                       "rank0_clip": {k: mine.get(k) for k in ("frontend_seconds", "backend_seconds", "seconds_without_infill",
+                                                               "seconds", "update_iterations", "keyframes", "edges_final",
+                                                               "backend_edges", "infill_frames", "finite")},
                        "rank0_seconds_to_gather_end": t_gather_end - t0,
                        "input": "feature maps (encoders skipped)" if args.video_features else
                                 "RGB frames: motion filter + feature / context encoders in the timed region"
@@ -492,15 +517,17 @@ def secondary_figures(args, device, graph, step):
     try:
         run_clip = make_clip_runner(device)
         run_clip(seed=10_000, n_frames=24)
-        r = run_clip(seed=0, n_frames=args.frames, with_backend=True)
+        r = run_clip(seed=0, n_frames=args.frames, with_backend=True, with_infill=True)
         out["frames_per_s"] = {
-            "frontend_only": r["frames"] / r["frontend_seconds"], "with_global_ba": r["frames"] / r["seconds"],
+            "frontend_only": r["frames"] / r["frontend_seconds"], "with_global_ba": r["frames"] / r["seconds_without_infill"],
+            "with_global_ba_and_infill": r["frames"] / r["seconds"],
             "frames": r["frames"], "update_iterations": r["update_iterations"], "backend_edges": r["backend_edges"],
             "state_finite": r["finite"],
             "what": "one synthetic 512x384 clip from RGB frames resident in HBM, every frame a keyframe: motion filter + "
                     "encoders + proximity edges + 4+2 update iterations per keyframe (whole clip incl. the 8-keyframe "
                     "initialisation), the filter of frame f+1 on a side stream while the frontend optimises keyframe f; "
-                    "with_global_ba adds backend.run(7) + backend.run(24)"}
+                    "with_global_ba adds backend.run(7) + backend.run(24); ..._and_infill adds pass 2 of SLAMSystem.run "
+                    "(every frame encoded again, chunks of 16 refined by InnerFiller - here every frame already is a keyframe)"}
     except Exception as e:  # noqa: BLE001
         out["frames_per_s"] = f"failed: {type(e).__name__}: {e}"
     _log("secondary: video done")
@@ -708,6 +735,8 @@ def main():
     ap.add_argument("--out-dir", default=None, help="video mode: keep rank 0's pose / intrinsics artifacts here")
     ap.add_argument("--no-hipgraph", action="store_true",
                     help="update mode: time eager launches instead of replaying the captured two-step HIP graph")
+    ap.add_argument("--with-infill", action="store_true",
+                    help="video mode: also pass 2 of SLAMSystem.run (every frame encoded again, InnerFiller chunks of 16)")
     ap.add_argument("--with-backend", action="store_true",
                     help="video mode: after the frontend pass also run the two global-BA passes of SLAMSystem.run "
                          "(backend.run(7), backend.run(24): system.py:272-275) inside the timed region")

@@ -1344,9 +1344,10 @@ def test_clip_pipeline_at_bench_resolution_from_rgb():
     res = {}
     for pipelined in (True, False):
         run_clip = bench.make_clip_runner(dev(), pipelined=pipelined)
-        res[pipelined] = run_clip(seed=3, n_frames=14, with_backend=True)
+        res[pipelined] = run_clip(seed=3, n_frames=14, with_backend=True, with_infill=True)
     for r in res.values():
         assert r["finite"] and r["keyframes"] == 14 and r["update_iterations"] == 8 + 6 * 6
+        assert r["infill_frames"] == 14  # pass 2: every frame got a pose (here all of them are keyframes)
         assert 0 < r["edges_final"] <= 48 + 2 * 3 and r["backend_edges"] > r["edges_final"]
         q = r["poses"][:, 3:]
         assert (q.norm(dim=-1) - 1.0).abs().max().item() < 1e-4  # unit quaternions after every retraction
@@ -1468,6 +1469,55 @@ def test_project_map_infill_takes_the_nearest_projected_point():
     assert int(hit.sum()) > 20
     # a pixel's own point(s) are among the candidates: the nearest point's depth lies within the range of map depths
     assert float(dense.min()) >= float(sparse[hit].min()) - 1e-4 and float(dense.max()) <= float(sparse[hit].max()) + 0.5
+
+
+def test_inner_filler_interpolates_and_refines_non_keyframe_poses():
+    """`InnerFiller` (inner_filler.py:46-138, pass 2 of SLAMSystem.run): all 16 frames of a clip appended behind its 6
+    keyframes.  The constant-velocity initial poses against the fp64 oracle group operations; then ten motion-only
+    update iterations on the (keyframe -> frame) graph: keyframes untouched, frame count restored, finite refined poses
+    that stay near their start (the synthetic targets are the graph's own reprojections)."""
+    import bench
+    from vipe_amd.slam.inner_filler import InfillArgs, InnerFiller
+
+    n_kf, n_all = 6, 16
+    g, buf, graph = bench.build_problem(dev(), n_kf, 128, 512, 3, 0, seed=41)
+    kf_t = torch.tensor([0, 3, 6, 9, 12, 15], device=dev(), dtype=buf.tstamp.dtype)
+    buf.tstamp[:n_kf] = kf_t
+    kf_poses = buf.poses[:n_kf].clone()
+    gen = torch.Generator().manual_seed(4)
+    for f in range(n_all):  # pass 2 appends every frame of the video (system.py:286-292)
+        t = buf.n_frames
+        buf.tstamp[t] = f
+        buf.fmaps[t, 0] = torch.randn(128, 16, 64, generator=gen).half().to(dev())
+        buf.nets[t, 0] = torch.randn(128, 16, 64, generator=gen).tanh().half().to(dev())
+        buf.inps[t, 0] = torch.randn(128, 16, 64, generator=gen).relu().half().to(dev())
+        buf.n_frames += 1
+    filler = InnerFiller(graph.update_op, buf, InfillArgs(infill_chunk_size=16), dev())
+    filler.set_start_idx(n_kf)
+    assert filler.check()
+    t0, t1, m_pose = filler.interpolate()
+    # oracle: Exp(Log(G_t1 G_t0^-1) * dt / DT) G_t0 in fp64
+    P = kf_poses.double().cpu().numpy()
+    t0n, t1n = t0.cpu().numpy(), t1.cpu().numpy()
+    kt = kf_t.double().cpu().numpy()
+    want = []
+    for f in range(n_all):
+        a, b = int(t0n[f]), int(t1n[f])
+        assert a == min(f // 3, n_kf - 1) and b == min(a + 1, n_kf - 1)
+        rel = ose3.se3_mul(P[b][None], ose3.se3_inv(P[a][None]))
+        xi = ose3.se3_log(rel) * ((f - kt[a]) / (kt[b] - kt[a] + 1e-3))
+        want.append(ose3.se3_mul(ose3.se3_exp(xi), P[a][None])[0])
+    want = np.stack(want)
+    got = m_pose.data.double().cpu().numpy()
+    sign = np.sign((got[:, 3:] * want[:, 3:]).sum(-1, keepdims=True))  # q and -q are the same rotation
+    assert np.abs(got[:, :3] - want[:, :3]).max() < 1e-5 and np.abs(got[:, 3:] * sign - want[:, 3:]).max() < 1e-5
+    filler.compute()
+    torch.cuda.synchronize()
+    r = filler.get_result()
+    assert buf.n_frames == n_kf and r.poses.data.shape == (n_all, 7) and r.dense_disps is None
+    assert torch.equal(buf.poses[:n_kf], kf_poses) and bool(torch.isfinite(r.poses.data).all())
+    assert (r.poses.data[:, 3:].norm(dim=-1) - 1.0).abs().max().item() < 1e-4
+    assert int(filler.last_graph.ii.numel()) >= n_all  # every frame is tied to its neighbouring keyframe(s)
 
 
 def test_frontend_prefetched_frame_distances_change_nothing():
