@@ -1898,3 +1898,68 @@ def test_ba_plan_reuse_equals_rebuilding_the_plan(monkeypatch):
         assert np.abs(da - db).max() <= 1e-4 * np.abs(db).max()
     # the third call saw the new sensor depth: frame 5 moved differently than it would have without it
     assert np.abs(a[2][1][5] - a[1][1][5]).max() > 0
+
+
+def test_slam_system_two_passes_over_rgb_frames():
+    """`SLAMSystem.run` (system.py:186-316) on a short synthetic clip: pass 1 (motion filter -> keyframes -> frontend,
+    the backend at the configured keyframe counts, the two final global-BA passes), pass 2 (every frame through the
+    InnerFiller), the map.  Random-init weights: what is pinned is the bookkeeping - which frames became keyframes, one
+    pose per input frame, unit quaternions, the keyframe timestamps of the map - with the filter scripted to keep
+    every third frame in the second case (so the context encoder's no-reuse branch and real interpolation run)."""
+    from vipe_amd.ext.lietorch import SE3
+    from vipe_amd.slam.frontend import FrontendArgs
+    from vipe_amd.slam.inner_filler import InfillArgs
+    from vipe_amd.slam.system import Frame, SLAMConfig, SLAMSystem
+
+    gen = torch.Generator().manual_seed(5)
+    T, H, W = 26, 128, 512
+    rgb = torch.rand(T, H, W, 3, generator=gen).to(dev())
+    depth = (1.0 + 4.0 * torch.rand(T, H, W, generator=gen)).to(dev())
+    intr = torch.tensor([460.8, 460.8, 256.0, 64.0])
+
+    def frames():
+        out = []
+        for t in range(T):
+            pose = SE3(torch.tensor([[-0.05 * t, 0, 0, 0, 0, 0, 1.0]], device=dev())).inv()  # camera -> world
+            out.append(Frame(rgb=rgb[t], metric_depth=depth[t], intrinsics=intr, pose=SE3(pose.data[0]),
+                             mask=torch.ones(H, W, dtype=torch.bool, device=dev())))
+        return out
+
+    torch.manual_seed(0)
+    for every in (1, 3):
+        cfg = SLAMConfig(buffer=64, filter_thresh=0.0, frontend_backend_iters=(10,),
+                         frontend=FrontendArgs(keyframe_thresh=0.0), infill=InfillArgs(infill_chunk_size=8))
+        sysm = SLAMSystem(dev(), cfg)
+        calls = {"backend": 0}
+        if every > 1:
+            import vipe_amd.slam.system as S
+            real_build = sysm._build_components
+
+            def build(*a, **k):
+                real_build(*a, **k)
+                mf, state = sysm.motion_filter, {"i": -1}
+                real_check = mf.check
+
+                def check(images, masks=None):
+                    state["i"] += 1
+                    return real_check(images, masks) if state["i"] % every == 0 else False
+                mf.check = check
+                real_run = sysm.backend.run_if_necessary
+
+                def run_if(*a, **k):
+                    calls["backend"] += 1
+                    return real_run(*a, **k)
+                sysm.backend.run_if_necessary = run_if
+            sysm._build_components = build
+        out = sysm.run(frames())
+        torch.cuda.synchronize()
+        want = sorted(set(range(0, T, every)) | {T - 1})
+        assert out.keyframe_ids.tolist() == want
+        assert out.trajectory.data.shape == (T, 7) and bool(torch.isfinite(out.trajectory.data).all())
+        assert (out.trajectory.data[:, 3:].norm(dim=-1) - 1).abs().max().item() < 1e-4
+        assert out.intrinsics.shape == (1, 4) and torch.allclose(out.intrinsics[0].cpu(), intr)
+        assert out.get_view_trajectory(0).data.shape == (T, 7)
+        assert sysm.buffer.n_frames == len(want) and out.slam_map is not None
+        assert bool((sysm.buffer.masks[:len(want)] == 0).all())  # all-valid masks -> nothing marked invalid
+        if every > 1:
+            assert calls["backend"] == 1  # 10 keyframes reached once

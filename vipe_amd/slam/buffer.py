@@ -80,6 +80,32 @@ class GraphBuffer:
     def flattened_fmaps(self):
         return self.fmaps.view(-1, *self.fmaps.shape[2:])
 
+    @property
+    def flattened_nets(self):
+        return self.nets.view(-1, *self.nets.shape[2:])
+
+    @property
+    def flattened_inps(self):
+        return self.inps.view(-1, *self.inps.shape[2:])
+
+    @property
+    def K(self):
+        """buffer.py:202-210: [V,3,3] pinhole calibration matrices at full resolution (numpy; MEI through its pinhole
+        equivalent, cameras.py:338-343)."""
+        import numpy as np
+        intr = (self._pinhole_intrinsics_8() * 8.0).cpu().numpy()
+        k_mat = np.eye(3)[None].repeat(self.n_views, axis=0)
+        k_mat[:, 0, 0], k_mat[:, 1, 1], k_mat[:, 0, 2], k_mat[:, 1, 2] = intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3]
+        return k_mat
+
+    @property
+    def K_dense_disp(self):
+        """buffer.py:212-216: the same at the 1/8 resolution of the disparity maps."""
+        k_mat = self.K
+        k_mat[:, 0] /= 8
+        k_mat[:, 1] /= 8
+        return k_mat
+
     def expand_edge_multiview(self, ii, jj, cross=True, view_offset=0):
         """buffer.py:318-361 -> pi, qi, di, pj, qj, dj (each [M * n_views])."""
         V = self.n_views

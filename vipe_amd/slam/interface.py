@@ -71,3 +71,21 @@ class SLAMMap:
         out = torch.full((H * W,), float("inf"), device=xyz.device)
         out.scatter_reduce_(0, vv.floor().long() * W + uu.floor().long(), depth, reduce="amin")
         return torch.where(torch.isinf(out), torch.zeros_like(out), out).view(H, W)
+
+
+class SLAMOutput:
+    """interface.py:143-163: what `SLAMSystem.run` returns - trajectory (camera -> world per frame, SE3 [N]), intrinsics
+    [V,4], the rig, the map, the BA residual."""
+
+    def __init__(self, *, trajectory, intrinsics, rig=None, slam_map=None, ba_residual=0.0):
+        self.trajectory, self.intrinsics, self.rig, self.slam_map, self.ba_residual = trajectory, intrinsics, rig, slam_map, ba_residual
+
+    @property
+    def keyframe_ids(self):
+        assert self.slam_map is not None, "SLAM map not available."
+        return np.array(self.slam_map.dense_disp_frame_inds)
+
+    def get_view_trajectory(self, view_idx):
+        assert self.rig is not None, "Rig not available."
+        return self.trajectory * self.rig[view_idx][None]
+

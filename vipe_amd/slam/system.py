@@ -1,0 +1,152 @@
+"""`SLAMSystem` - host-side mirror of the reference's top-level driver (vipe/slam/system.py:51-316) over frames that are
+already decoded, resized and resident on the device (decoding / resizing / the monocular depth networks / sparse tracks /
+the rerun visualisation are outside the path):
+
+    pass 1  every frame through the motion filter; accepted frames (and the last one) become keyframes - features and
+            context into the buffer, sensor disparities from the frame's metric depth or a caller-supplied depth model,
+            poses from the frame when given - then `SLAMFrontend.run()`; `SLAMBackend.run_if_necessary(5)` at
+            `frontend_backend_iters` keyframes (system.py:236-273)
+            `SLAMBackend.run(7)`, `SLAMBackend.run(backend_iters)` (system.py:279-282)
+    pass 2  every frame appended again behind the keyframes, `InnerFiller` in chunks (system.py:284-294)
+            `extract_slam_map`, `SLAMOutput(trajectory = filled poses inverted, intrinsics, rig, map)` (system.py:303-316)
+"""
+from dataclasses import dataclass, field
+
+import torch
+
+from ..ext.lietorch import SE3
+from .backend import BackendArgs, SLAMBackend
+from .buffer import GraphBuffer
+from .frontend import FrontendArgs, SLAMFrontend
+from .inner_filler import InfillArgs, InnerFiller
+from .interface import SLAMOutput
+from .motion_filter import DroidNet, MotionFilter
+
+
+@dataclass
+class SLAMConfig:
+    """configs/slam/default.yaml (the fields the path reads)"""
+    buffer: int = 1024
+    filter_thresh: float = 2.4
+    init_disp: float = 1.0
+    map_filter_thresh: float = 0.05
+    frontend_backend_iters: tuple = (16, 64, 256)
+    cross_view_idx: object = None
+    frontend: FrontendArgs = field(default_factory=FrontendArgs)
+    backend: BackendArgs = field(default_factory=BackendArgs)
+    infill: InfillArgs = field(default_factory=InfillArgs)
+
+
+@dataclass
+class Frame:
+    """What the path reads of the reference's `VideoFrame` (one per view): rgb [H,W,3] float 0-1, optional mask [H,W]
+    bool (True = usable pixel, system.py:199-211), metric depth [H,W], intrinsics [4] (or [5] MEI) at frame resolution,
+    camera->world pose (SE3)."""
+    rgb: torch.Tensor
+    mask: torch.Tensor = None
+    metric_depth: torch.Tensor = None
+    intrinsics: torch.Tensor = None
+    pose: SE3 = None
+
+
+class SLAMSystem:
+    def __init__(self, device=torch.device("cuda"), config=None, droid_net=None, depth_model=None):
+        self.device, self.config = device, config or SLAMConfig()
+        self.droid_net = droid_net if droid_net is not None else DroidNet()
+        self.metric_depth = depth_model  # system.py:114-127 builds it from `keyframe_depth`; here the caller's
+
+    def _build_components(self, height, width, n_views, rig, camera_type):
+        c = self.config
+        self.buffer = GraphBuffer(height, width, n_views=n_views, buffer_size=c.buffer, init_disp=c.init_disp,
+                                  cross_view_idx=c.cross_view_idx, camera_type=camera_type, device=self.device)
+        self.buffer.rig[:] = rig.data.to(self.device)
+        self.motion_filter = MotionFilter(self.droid_net, thresh=c.filter_thresh, device=self.device)
+        self.frontend = SLAMFrontend(self.droid_net.update, self.buffer, c.frontend, self.device)
+        self.backend = SLAMBackend(self.droid_net.update, self.buffer, c.backend, self.device)
+        self.inner_filler = InnerFiller(self.droid_net.update, self.buffer, c.infill, self.device)
+        if self.metric_depth is not None:
+            assert n_views == 1, "the global scale lies in the null space of a multi-view problem (system.py:115-118)"
+        self.backend.depth_model = self.metric_depth
+
+    def _precompute_features(self, frames):
+        """system.py:194-218: images [V,3,H,W]; masks [V,h,w] True = INVALID (bilinear 1/8 downsample > 0.9, inverted)."""
+        images = torch.stack([f.rgb for f in frames]).permute(0, 3, 1, 2).contiguous().to(self.device).float()
+        masks = None
+        if all(f.mask is not None for f in frames):
+            ms = []
+            for f in frames:
+                mh, mw = f.mask.shape[0] // 8, f.mask.shape[1] // 8
+                m = torch.nn.functional.interpolate(f.mask[None, None].float().to(self.device), (mh, mw), mode="bilinear")[0, 0] > 0.9
+                ms.append(~m)
+            masks = torch.stack(ms)
+        return images, masks
+
+    def _add_keyframe(self, frame_idx, images, buffer_masks, frames, phase, reuse=None):
+        """system.py:131-165.  `reuse`: (fmap, net, inp) the motion filter has just computed for these very images."""
+        b = self.buffer
+        k = b.n_frames
+        b.tstamp[k] = frame_idx
+        b.images[k] = images
+        if reuse is not None:
+            b.fmaps[k], b.nets[k], b.inps[k] = reuse
+        else:
+            b.fmaps[k] = self.droid_net.encode_features(images)
+            b.nets[k], b.inps[k] = self.droid_net.encode_context(images)
+        if buffer_masks is not None:
+            b.masks[k] = buffer_masks
+        for v, f in enumerate(frames):
+            if k == 0:
+                assert f.intrinsics is not None, "the first frame must carry intrinsics"
+                b.intrinsics[v] = f.intrinsics.to(self.device)
+            if f.metric_depth is not None:
+                d = f.metric_depth[3::8, 3::8].to(self.device)
+                assert not self.config.backend.optimize_intrinsics
+                b.disps_sens[k, v] = torch.where(d > 0, d.reciprocal(), d)
+            if f.pose is not None and phase == 1:
+                b.poses[k] = (SE3(b.rig[v]) * f.pose.inv()).data
+        if phase == 1:
+            b.update_disps_sens(self.metric_depth, frame_idx=k)
+        b.n_frames += 1
+        b.touch()
+
+    @torch.no_grad()
+    def run(self, frames, rig=None, camera_type="pinhole"):
+        """frames: sequence (length T) of per-view lists of `Frame` (a single `Frame` per step for one view)."""
+        frames = [f if isinstance(f, (list, tuple)) else [f] for f in frames]
+        total, n_views = len(frames), len(frames[0])
+        assert total > 0 and all(len(f) == n_views for f in frames)
+        if rig is None:
+            assert n_views == 1, "Need rig for multiple views"
+            rig = SE3.Identity(1)
+        height, width = frames[0][0].rgb.shape[:2]
+        self.config.frontend.has_init_pose = frames[0][0].pose is not None
+        self._build_components(height, width, n_views, rig, camera_type)
+        b = self.buffer
+        n_keyframes = []
+        for frame_idx, fl in enumerate(frames):  # SLAM pass 1/2
+            images, masks = self._precompute_features(fl)
+            kept = self.motion_filter.check(images, masks)
+            is_keyframe = kept or frame_idx == total - 1
+            if is_keyframe:
+                mf = self.motion_filter  # a frame the filter kept has its features and context there already
+                self._add_keyframe(frame_idx, images, masks, fl, phase=1,
+                                   reuse=(mf.f_fmap, mf.f_net, mf.f_inp) if kept else None)
+            self.frontend.run()
+            # the backend in between corrects intrinsics / extrinsics early (system.py:269-272)
+            if is_keyframe and b.n_frames in self.config.frontend_backend_iters:
+                self.backend.run_if_necessary(5)
+            n_keyframes.append(b.n_frames)
+        self.backend.run(7)
+        self.backend.run(self.config.backend.backend_iters, update_depth=False)
+        self.inner_filler.set_start_idx(b.n_frames)
+        for frame_idx, fl in enumerate(frames):  # SLAM pass 2/2
+            images, masks = self._precompute_features(fl)
+            self._add_keyframe(frame_idx, images, masks, fl, phase=2)
+            if self.inner_filler.check() or frame_idx == total - 1:
+                self.inner_filler.compute()
+        filled = self.inner_filler.get_result()
+        if filled.poses.data.shape[0] != total:
+            raise ValueError("fewer poses than frames: the frame sequence changed between the passes")
+        slam_map = b.extract_slam_map(filter_thresh=self.config.map_filter_thresh)
+        return SLAMOutput(trajectory=filled.poses.inv(), intrinsics=b.intrinsics.clone(), rig=SE3(b.rig.clone()),
+                          slam_map=slam_map)
