@@ -1963,3 +1963,56 @@ def test_slam_system_two_passes_over_rgb_frames():
         assert bool((sysm.buffer.masks[:len(want)] == 0).all())  # all-valid masks -> nothing marked invalid
         if every > 1:
             assert calls["backend"] == 1  # 10 keyframes reached once
+
+
+def test_operator_api_on_empty_inputs():
+    """Zero-sized batches through every operator of the boundary: an empty edge list / point set / element batch returns
+    correctly shaped empty (or untouched) outputs and launches nothing - a zero-block grid is a launch error in HIP, and a
+    pipeline that proposes no edge for a keyframe or filters every point of a map must not die on it."""
+    from vipe_amd.ext import corr_ext, droid_net_ext, lietorch_ext, scatter_ext, slam_ext, utils_ext
+    d = dev()
+    f32 = dict(device=d, dtype=torch.float32)
+    i64 = dict(device=d, dtype=torch.int64)
+    e = torch.zeros(0, **i64)
+    poses = torch.zeros(4, 7, **f32)
+    poses[:, 6] = 1
+    disps = torch.ones(4, 12, 16, **f32)
+    intr = torch.tensor([50.0, 50.0, 8.0, 6.0], **f32)
+    # slam_ext
+    assert slam_ext.frame_distance(poses, disps, intr[None], e, e, e, e, e, 0.3).shape == (0,)
+    coords, valid = slam_ext.projmap(poses, disps, intr, e, e)
+    assert coords.shape == (0, 12, 16, 3) and valid.shape == (0, 12, 16, 1)
+    assert slam_ext.depth_filter(poses[:0], disps[:0], intr, e, torch.zeros(0, **f32)).shape == (0, 12, 16)
+    assert slam_ext.iproj(poses[:0], disps[:0], intr).shape == (0, 12, 16, 3)
+    rig = torch.zeros(1, 7, **f32)
+    rig[:, 6] = 1
+    c, v = slam_ext.reproject(poses, disps, intr[None], rig, e, e, e, e, e)
+    assert c.shape[0] == 0 and v.shape[0] == 0
+    # droid_net_ext
+    vol = torch.zeros(0, 12, 16, 12, 16, device=d, dtype=torch.float16)
+    (o,) = droid_net_ext.corr_index_forward(vol, torch.zeros(0, 2, 12, 16, **f32), 3)
+    assert o.shape == (0, 7, 7, 12, 16)
+    (g,) = droid_net_ext.corr_index_backward(vol.float(), torch.zeros(0, 2, 12, 16, **f32), torch.zeros(0, 7, 7, 12, 16, **f32), 3)
+    assert g.shape == vol.shape
+    f1 = torch.zeros(1, 12, 16, 32, **f32)
+    (o,) = droid_net_ext.altcorr_forward(f1, f1, torch.zeros(1, 0, 12, 16, 2, **f32), 3)
+    assert o.shape == (1, 0, 49, 12, 16)
+    # lietorch_ext (gid 3 = SE3)
+    X0, a0 = torch.zeros(0, 7, **f32), torch.zeros(0, 6, **f32)
+    assert lietorch_ext.expm(3, a0).shape == (0, 7) and lietorch_ext.logm(3, X0).shape == (0, 6)
+    assert lietorch_ext.inv(3, X0).shape == (0, 7) and lietorch_ext.mul(3, X0, X0).shape == (0, 7)
+    assert lietorch_ext.adjT(3, X0, a0).shape == (0, 6) and lietorch_ext.act4(3, X0, torch.zeros(0, 4, **f32)).shape == (0, 4)
+    assert lietorch_ext.as_matrix(3, X0).shape == (0, 4, 4)
+    # scatter_ext
+    out = scatter_ext.scatter_sum(torch.zeros(0, 5, **f32), e, 0, None, 3)
+    assert out.shape == (3, 5) and float(out.abs().sum()) == 0
+    out = scatter_ext.scatter_mean(torch.zeros(0, 5, **f32), e, 0, None, 3)
+    assert out.shape == (3, 5) and bool(torch.isfinite(out).all())
+    mx, arg = scatter_ext.scatter_max(torch.zeros(0, 5, **f32), e, 0, None, 3)
+    assert mx.shape == (3, 5) and arg.shape == (3, 5)
+    # corr_ext, utils_ext
+    x = torch.zeros(0, 8, 6, 6, **f32)
+    assert corr_ext.forward(x, x, 1, 1, 3, 3, 0, 0, 1, 1, 1, 1, 1, 1).shape == (0, 3, 3, 6, 6)
+    dist, idx = utils_ext.nearest_neighbours(torch.zeros(0, 3, **f32), torch.rand(10, 3, **f32), 2)
+    assert dist.shape == (0, 2) and idx.shape == (0, 2)
+    torch.cuda.synchronize()

@@ -84,9 +84,9 @@ VIPE_EXPORT int vipe_reproject(const float* d_poses, const float* d_disps, const
                                const float* d_rig, const int64_t* d_pi, const int64_t* d_qi, const int64_t* d_pj,
                                const int64_t* d_qj, const int64_t* d_di, float* d_coords, float* d_valid, int M,
                                int ht, int wd, int n_views, int camera, float intr_factor, void* stream) {
-  VIPE_CHECK_ARG(d_poses && d_disps && d_intrinsics && d_rig && d_pi && d_qi && d_pj && d_qj && d_di && d_coords);
   VIPE_CHECK_ARG(M >= 0 && M <= 65535 && ht > 0 && wd > 0 && n_views >= 1 && intr_factor > 0);
-  if (M == 0) return VIPE_OK;
+  if (M == 0) return VIPE_OK;  // before the pointer checks: an empty tensor has a null data pointer
+  VIPE_CHECK_ARG(d_poses && d_disps && d_intrinsics && d_rig && d_pi && d_qi && d_pj && d_qj && d_di && d_coords);
   ReprojArgs a{d_poses, d_disps, d_intrinsics, d_rig, d_pi, d_qi, d_pj, d_qj, d_di, nullptr, d_coords, d_valid,
                nullptr, M, ht, wd, n_views, camera == VIPE_CAM_MEI ? 1 : 0, 1.0f / intr_factor};
   return launch<0>(a, camera, as_stream(stream));
@@ -97,10 +97,10 @@ VIPE_EXPORT int vipe_reproject_motion(const float* d_poses, const float* d_disps
                                       const int64_t* d_pj, const int64_t* d_qj, const int64_t* d_di,
                                       const float* d_target, float* d_coords, void* d_motn, int M, int ht, int wd,
                                       int n_views, int camera, float intr_factor, int motn_dtype, void* stream) {
+  VIPE_CHECK_ARG(M >= 0 && M <= 65535 && ht > 0 && wd > 0 && n_views >= 1 && intr_factor > 0);
+  if (M == 0) return VIPE_OK;  // before the pointer checks: an empty tensor has a null data pointer
   VIPE_CHECK_ARG(d_poses && d_disps && d_intrinsics && d_rig && d_pi && d_qi && d_pj && d_qj && d_di && d_coords);
   VIPE_CHECK_ARG(d_target && d_motn);
-  VIPE_CHECK_ARG(M >= 0 && M <= 65535 && ht > 0 && wd > 0 && n_views >= 1 && intr_factor > 0);
-  if (M == 0) return VIPE_OK;
   ReprojArgs a{d_poses, d_disps, d_intrinsics, d_rig, d_pi, d_qi, d_pj, d_qj, d_di, d_target, d_coords, nullptr,
                d_motn, M, ht, wd, n_views, camera == VIPE_CAM_MEI ? 1 : 0, 1.0f / intr_factor};
   if (motn_dtype == VIPE_F16) return launch<1>(a, camera, as_stream(stream));
@@ -113,10 +113,10 @@ VIPE_EXPORT int vipe_reproject_motion_nhwc(const float* d_poses, const float* d_
                                            const int64_t* d_pj, const int64_t* d_qj, const int64_t* d_di,
                                            const float* d_target, float* d_coords, void* d_motn, int M, int ht,
                                            int wd, int n_views, int camera, float intr_factor, void* stream) {
+  VIPE_CHECK_ARG(M >= 0 && M <= 65535 && ht > 0 && wd > 0 && n_views >= 1 && intr_factor > 0);
+  if (M == 0) return VIPE_OK;  // before the pointer checks: an empty tensor has a null data pointer
   VIPE_CHECK_ARG(d_poses && d_disps && d_intrinsics && d_rig && d_pi && d_qi && d_pj && d_qj && d_di && d_coords);
   VIPE_CHECK_ARG(d_target && d_motn);
-  VIPE_CHECK_ARG(M >= 0 && M <= 65535 && ht > 0 && wd > 0 && n_views >= 1 && intr_factor > 0);
-  if (M == 0) return VIPE_OK;
   ReprojArgs a{d_poses, d_disps, d_intrinsics, d_rig, d_pi, d_qi, d_pj, d_qj, d_di, d_target, d_coords, nullptr,
                d_motn, M, ht, wd, n_views, camera == VIPE_CAM_MEI ? 1 : 0, 1.0f / intr_factor};
   return launch<3>(a, camera, as_stream(stream));
