@@ -2016,3 +2016,38 @@ def test_operator_api_on_empty_inputs():
     dist, idx = utils_ext.nearest_neighbours(torch.zeros(0, 3, **f32), torch.rand(10, 3, **f32), 2)
     assert dist.shape == (0, 2) and idx.shape == (0, 2)
     torch.cuda.synchronize()
+
+
+def test_slam_system_on_a_two_camera_rig():
+    """`SLAMSystem.run` with two views per frame and a fixed rig (system.py:221-231: per-view intrinsics from the first
+    frame, `buffer.rig`, cross-view edges in frontend and backend): bookkeeping and finiteness of the whole two-pass
+    run, and the per-view trajectories `trajectory * rig[v]` of the output."""
+    from vipe_amd.ext.lietorch import SE3
+    from vipe_amd.slam.frontend import FrontendArgs
+    from vipe_amd.slam.inner_filler import InfillArgs
+    from vipe_amd.slam.system import Frame, SLAMConfig, SLAMSystem
+
+    gen = torch.Generator().manual_seed(9)
+    T, V, H, W = 14, 2, 128, 512
+    rgb = torch.rand(T, V, H, W, 3, generator=gen).to(dev())
+    depth = (1.0 + 4.0 * torch.rand(T, V, H, W, generator=gen)).to(dev())
+    intr = torch.tensor([[460.8, 460.8, 256.0, 64.0], [455.0, 455.0, 250.0, 66.0]])
+    rig = SE3(torch.tensor([[0, 0, 0, 0, 0, 0, 1.0], [-0.1, 0, 0, 0, 0, 0, 1.0]], device=dev()))
+    frames = []
+    for t in range(T):
+        pose = SE3(torch.tensor([-0.05 * t, 0, 0, 0, 0, 0, 1.0], device=dev())).inv()
+        frames.append([Frame(rgb=rgb[t, v], metric_depth=depth[t, v], intrinsics=intr[v],
+                             pose=(pose * rig[v]) if v else pose) for v in range(V)])
+    torch.manual_seed(0)
+    cfg = SLAMConfig(buffer=48, filter_thresh=0.0, frontend_backend_iters=(10,),
+                     frontend=FrontendArgs(keyframe_thresh=0.0), infill=InfillArgs(infill_chunk_size=8))
+    sysm = SLAMSystem(dev(), cfg)
+    out = sysm.run(frames, rig=rig)
+    torch.cuda.synchronize()
+    assert out.keyframe_ids.tolist() == list(range(T)) and sysm.buffer.n_views == 2
+    assert out.trajectory.data.shape == (T, 7) and bool(torch.isfinite(out.trajectory.data).all())
+    assert (out.trajectory.data[:, 3:].norm(dim=-1) - 1).abs().max().item() < 1e-4
+    assert torch.allclose(out.intrinsics.cpu(), intr) and torch.allclose(out.rig.data, rig.data)
+    v1 = out.get_view_trajectory(1)
+    assert v1.data.shape == (T, 7) and bool(torch.isfinite(v1.data).all())
+    assert bool(torch.isfinite(sysm.buffer.disps[:T]).all()) and bool((sysm.buffer.disps[:T] >= 1e-3).all())
