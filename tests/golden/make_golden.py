@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
 from oracle import se3 as ose3  # noqa: E402
-from vipe_amd.synth import make_graph  # noqa: E402
+from vipe_amd.synth import make_graph, make_tracks  # noqa: E402
 
 REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
 
@@ -101,8 +101,10 @@ def load_reference():
 
 def reference_ba(R, poses, disps, disps_sens, intrinsics, target, weight, eta, ii, jj, t0, t1, n_iters,
                  pose_damping, pose_ep, motion_only, limited_disp, optimize_intrinsics, camera="pinhole",
-                 alpha=0.001):
-    """Drive the reference Solver exactly as GraphBuffer.bundle_adjustment does (buffer.py:396-525), mono rig."""
+                 alpha=0.001, tracks=None):
+    """Drive the reference Solver exactly as GraphBuffer.bundle_adjustment does (buffer.py:396-525), mono rig.
+    `tracks` = (target, weight) of the second flow term the reference adds when sparse tracks are enabled
+    (buffer.py:422-447, weight_tracks = 0.001)."""
     Solver, SparseBlockVector = R.solver.Solver, R.vector.SparseBlockVector
     T, RT = R.terms, R.retractor
     cam = R.cameras.CameraType.PINHOLE if camera == "pinhole" else R.cameras.CameraType.MEI
@@ -124,6 +126,12 @@ def reference_ba(R, poses, disps, disps_sens, intrinsics, target, weight, eta, i
         target=torch.tensor(target).float().reshape(E, ht * wd, 2),
         weight=0.001 * torch.tensor(weight).float().reshape(E, ht * wd, 2),
         intrinsics=None, intrinsics_factor=8.0, rig=None, image_size=(ht, wd), camera_type=cam))
+    if tracks is not None:
+        solver.add_term(T.DenseDepthFlowTerm(
+            pose_i_inds=pi, pose_j_inds=pj, rig_i_inds=qi, rig_j_inds=qj, dense_disp_i_inds=di,
+            target=torch.tensor(tracks[0]).float().reshape(E, ht * wd, 2),
+            weight=0.001 * torch.tensor(tracks[1]).float().reshape(E, ht * wd, 2),
+            intrinsics=None, intrinsics_factor=8.0, rig=None, image_size=(ht, wd), camera_type=cam))
     solver.set_fixed("pose", torch.cat([pi_unique[pi_unique < t0], pi_unique[pi_unique >= t1]]) if t0 < t1 else None)
     solver.set_retractor("pose", RT.PoseRetractor())
     solver.set_damping("pose", damping=pose_damping, ep=pose_ep)
@@ -202,6 +210,23 @@ def gen_ba(R):
         out[name + "/energy"] = en
         print(name, "energy", en)
     np.savez_compressed(os.path.join(HERE, "ba_reference.npz"), **out)
+
+
+BA_TRACKS_CASES = ["n5_frontend", "n6_window_prior", "n6_infill_motion_limited"]
+
+
+def gen_ba_tracks(R):
+    """Two flow terms on the same edges - the dense one and the sparse-track one - through the reference Solver."""
+    out = {}
+    for k, name in enumerate(BA_TRACKS_CASES):
+        gk, bk = BA_CASES[name]
+        g = make_graph(**gk)
+        tt, tw = make_tracks(g, 100 + k)
+        p, d, kk, en = reference_ba(R, g.poses, g.disps, g.disps_sens, g.intrinsics, g.target, g.weight, g.eta, g.ii,
+                                    g.jj, tracks=(tt, tw), **bk)
+        out[name + "/poses"], out[name + "/disps"], out[name + "/intrinsics"], out[name + "/energy"] = p, d, kk, en
+        print(name, "+ tracks: energy", en)
+    np.savez_compressed(os.path.join(HERE, "ba_tracks_reference.npz"), **out)
 
 
 def reference_ba_rig(R, g, t0, t1, n_iters, pose_damping, pose_ep, motion_only=False, limited_disp=False,
@@ -464,6 +489,9 @@ if __name__ == "__main__":
     if os.environ.get("GOLDEN_ONLY") == "ba_rig":
         gen_ba_rig(R)
         sys.exit(0)
+    if os.environ.get("GOLDEN_ONLY") == "ba_tracks":
+        gen_ba_tracks(R)
+        sys.exit(0)
     if os.environ.get("GOLDEN_ONLY") == "encoder":
         gen_encoder(R)
         sys.exit(0)
@@ -472,6 +500,7 @@ if __name__ == "__main__":
     gen_reproject(R)
     gen_ba(R)
     gen_ba_rig(R)
+    gen_ba_tracks(R)
     gen_update_module(R)
     gen_corr(R)
     gen_encoder(R)

@@ -140,3 +140,31 @@ def test_gate_state_piece_validates_its_job_without_a_gpu():
     bounds2 = (ctypes.c_int * 3)(0, 6, 6)                                             # empty second piece: nothing to do
     job.bounds = ctypes.addressof(bounds2)
     assert L.vipe_update_gate_state_piece(ctypes.addressof(job), 1, 2, None) == 0
+
+
+def _sampler_reference(a, b, patch, dil_patch):
+    import torch.nn.functional as F
+    H, W = a.shape[-2:]
+    rH, rW = dil_patch[0] * (patch[0] - 1) // 2, dil_patch[1] * (patch[1] - 1) // 2
+    bp = F.pad(b, (rW, rW, rH, rH))
+    return torch.stack([torch.stack([(a * bp[:, :, ph * dil_patch[0]:ph * dil_patch[0] + H,
+                                             pw * dil_patch[1]:pw * dil_patch[1] + W]).sum(1)
+                                     for pw in range(patch[1])], 1) for ph in range(patch[0])], 1)
+
+
+def test_spatial_correlation_sampler_module_and_autograd_on_cpu():
+    """`vipe.ext.corr.SpatialCorrelationSampler` / `spatial_correlation_sample` (spatial_correlation_sampler.py:13-126):
+    values and gradients through autograd vs an explicit torch formulation; ints and pairs as size arguments."""
+    from vipe_amd.ext.corr import SpatialCorrelationSampler, spatial_correlation_sample
+    torch.manual_seed(3)
+    a = torch.randn(2, 4, 8, 10, requires_grad=True)
+    b = torch.randn(2, 4, 8, 10, requires_grad=True)
+    out = SpatialCorrelationSampler(kernel_size=1, patch_size=(3, 5), stride=1, padding=0, dilation=1, dilation_patch=(2, 1))(a, b)
+    ref = _sampler_reference(a, b, (3, 5), (2, 1))
+    assert out.shape == (2, 3, 5, 8, 10) and torch.allclose(out, ref, atol=1e-5)
+    go = torch.randn_like(ref)
+    g = torch.autograd.grad(out, (a, b), go)
+    r = torch.autograd.grad(ref, (a, b), go)
+    assert torch.allclose(g[0], r[0], atol=1e-5) and torch.allclose(g[1], r[1], atol=1e-5)
+    out2 = spatial_correlation_sample(a.detach(), b.detach(), patch_size=3)
+    assert torch.allclose(out2, _sampler_reference(a.detach(), b.detach(), (3, 3), (1, 1)), atol=1e-5)

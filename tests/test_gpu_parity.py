@@ -2051,3 +2051,67 @@ def test_slam_system_on_a_two_camera_rig():
     v1 = out.get_view_trajectory(1)
     assert v1.data.shape == (T, 7) and bool(torch.isfinite(v1.data).all())
     assert bool(torch.isfinite(sysm.buffer.disps[:T]).all()) and bool((sysm.buffer.disps[:T] >= 1e-3).all())
+
+
+def test_spatial_correlation_sampler_module_and_autograd():
+    """`vipe.ext.corr.SpatialCorrelationSampler` on device tensors: values and gradients through autograd vs an explicit
+    torch formulation."""
+    from vipe_amd.ext.corr import SpatialCorrelationSampler
+    torch.manual_seed(4)
+    a = torch.randn(2, 6, 9, 12, device=dev(), requires_grad=True)
+    b = torch.randn(2, 6, 9, 12, device=dev(), requires_grad=True)
+    patch, dil = (5, 3), (1, 2)
+    out = SpatialCorrelationSampler(1, patch, 1, 0, 1, dil)(a, b)
+    H, W = 9, 12
+    rH, rW = dil[0] * (patch[0] - 1) // 2, dil[1] * (patch[1] - 1) // 2
+    bp = torch.nn.functional.pad(b, (rW, rW, rH, rH))
+    ref = torch.stack([torch.stack([(a * bp[:, :, ph * dil[0]:ph * dil[0] + H, pw * dil[1]:pw * dil[1] + W]).sum(1)
+                                    for pw in range(patch[1])], 1) for ph in range(patch[0])], 1)
+    assert out.shape == ref.shape and torch.allclose(out, ref, atol=1e-4)
+    go = torch.randn_like(ref)
+    g = torch.autograd.grad(out, (a, b), go)
+    r = torch.autograd.grad(ref, (a, b), go)
+    assert torch.allclose(g[0], r[0], atol=1e-4) and torch.allclose(g[1], r[1], atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["n5_frontend", "n6_window_prior", "n6_infill_motion_limited"])
+def test_dense_ba_with_a_sparse_track_term_matches_reference_solver(name):
+    """The second flow term of buffer.py:422-447 (sparse tracks enabled) through `GraphBuffer.bundle_adjustment` with a
+    caller-supplied tracker object: HIP BA on the folded term vs the reference Solver run with BOTH terms (fixture)."""
+    from vipe_amd.slam.buffer import GraphBuffer
+    from vipe_amd.synth import make_tracks
+    names = ["n5_frontend", "n6_window_prior", "n6_infill_motion_limited"]
+    G = np.load(os.path.join(GOLD, "ba_tracks_reference.npz"))
+    gk, bk = BA_CASES[name]
+    g = make_graph(**gk)
+    tt, tw = make_tracks(g, 100 + names.index(name))
+    E, n = len(g.ii), g.poses.shape[0]
+
+    class Tracker:
+        enabled, calls = True, 0
+
+        def compute_dense_disp_target_weight(self, source_view_inds, source_frame_inds, target_view_inds, target_frame_inds,
+                                             image_size, dense_disp_size):
+            assert image_size == (gk["height"], gk["width"]) and dense_disp_size == (g.ht, g.wd)
+            assert source_frame_inds.cpu().tolist() == (10 * g.ii).tolist()  # time stamps, not buffer rows
+            Tracker.calls += 1
+            return T(tt.reshape(E, g.ht, g.wd, 2)), T(tw.reshape(E, g.ht, g.wd, 2))
+
+    buf = GraphBuffer(gk["height"], gk["width"], buffer_size=n + 2, device=dev())
+    buf.n_frames = n
+    buf.poses[:n], buf.disps[:n, 0], buf.disps_sens[:n, 0] = T(g.poses), T(g.disps), T(g.disps_sens)
+    buf.intrinsics[:] = T(g.intrinsics)
+    buf.tstamp[:n] = 10 * torch.arange(n, device=dev(), dtype=torch.int)
+    buf.sparse_tracks = Tracker()
+    damping = torch.zeros(n + 2, g.ht, g.wd, device=dev())
+    damping[:n] = T(g.eta)
+    kw = dict(bk)
+    buf.bundle_adjustment(T(g.target.reshape(E, -1, 2)), T(g.weight.reshape(E, -1, 2)), damping, T(g.ii), T(g.jj),
+                          kw.pop("t0"), kw.pop("t1"), kw.pop("n_iters"), kw.pop("pose_damping"), kw.pop("pose_ep"),
+                          kw.pop("motion_only"), kw.pop("limited_disp"), kw.pop("optimize_intrinsics"), False)
+    torch.cuda.synchronize()
+    p, d = buf.poses[:n].cpu().numpy(), buf.disps[:n, 0].cpu().numpy()
+    rp, rd = G[name + "/poses"], G[name + "/disps"]
+    assert Tracker.calls == 1
+    assert np.abs(p - rp).max() <= 1e-4 * max(1.0, np.abs(rp).max())
+    assert np.abs(d - rd).max() <= 1e-4 * np.abs(rd).max()

@@ -322,3 +322,28 @@ def test_encoders_match_reference():
         assert np.allclose(fmap.numpy(), G[tag + "/fmap"], atol=2e-5)
         assert np.allclose(net.numpy(), G[tag + "/net"], atol=2e-5)
         assert np.allclose(inp.numpy(), G[tag + "/inp"], atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["n5_frontend", "n6_window_prior", "n6_infill_motion_limited"])
+def test_ba_with_a_sparse_track_term_matches_reference_solver(name):
+    """buffer.py:422-447: with sparse tracks enabled the reference adds a SECOND DenseDepthFlowTerm on the same edges.
+    The fixture ran both terms through the reference Solver; here the two are folded into one (`fold_flow_terms`: summed
+    weights, weighted-mean target - the same normal equations) and given to the single-term oracle."""
+    import torch
+    from vipe_amd.slam.buffer import fold_flow_terms
+    from vipe_amd.synth import make_tracks
+    G = np.load(os.path.join(GOLD, "ba_tracks_reference.npz"))
+    G1 = np.load(os.path.join(GOLD, "ba_reference.npz"))
+    gk, bk = BA_CASES[name]
+    g = make_graph(**gk)
+    tt, tw = make_tracks(g, 100 + ["n5_frontend", "n6_window_prior", "n6_infill_motion_limited"].index(name))
+    E = len(g.ii)
+    ft, fw = fold_flow_terms(torch.tensor(g.target.reshape(E, -1, 2)), torch.tensor(g.weight.reshape(E, -1, 2)),
+                             torch.tensor(tt.reshape(E, -1, 2)), torch.tensor(tw.reshape(E, -1, 2)))
+    p, d, k, _ = ba.bundle_adjustment(g.poses, g.disps[:, None], g.disps_sens[:, None], g.intrinsics, se3.se3_identity(1),
+                                      ft.numpy(), fw.numpy(), g.eta[:, None], g.ii, g.jj, model="pinhole", dtype=np.float64, **bk)
+    rp, rd = G[name + "/poses"], G[name + "/disps"]
+    assert np.abs(p - rp).max() <= 2e-5 * max(1.0, np.abs(rp).max())
+    assert np.abs(d[:, 0] - rd).max() <= 2e-5 * np.abs(rd).max()
+    # the track term matters: the two-term result is not the one-term result
+    assert np.abs(rp - G1[name + "/poses"]).max() + np.abs(rd - G1[name + "/disps"]).max() > 1e-4

@@ -19,6 +19,16 @@ class BAConfig:
     dense_disp_alpha: float = 0.001  # configs/slam/default.yaml:48-49
 
 
+def fold_flow_terms(target, weight, target2, weight2):
+    """Two `DenseDepthFlowTerm`s on the same edges (buffer.py:405-447: the dense flow and the sparse-track flow, both
+    scaled by 0.001) share their Jacobians, so their normal equations J^T (W1 + W2) J and J^T (W1 r1 + W2 r2) are those of
+    ONE term with weight W1 + W2 and the weighted mean of the two targets; the energies differ by a constant the solver
+    never reads.  -> (target, weight) of that term for the fused BA."""
+    w = weight + weight2
+    t = (weight * target + weight2 * target2) / w.clamp(min=torch.finfo(w.dtype).tiny)
+    return torch.where(w > 0, t, target).contiguous(), w.contiguous()
+
+
 class GraphBuffer:
     def __init__(self, height, width, n_views=1, buffer_size=1024, init_disp=1.0, cross_view_idx=None,
                  ba_config=None, camera_type="pinhole", device=torch.device("cuda")):
@@ -52,6 +62,7 @@ class GraphBuffer:
         # buffer.py:106: frames changed since the last visualisation dump.  Only host code ever reads it: kept on the host
         # (the reference's device tensor costs a launch - and in the frontend an `ii.min()` read-back - per keyframe)
         self.dirty = torch.zeros(buffer_size, dtype=torch.bool)
+        self.sparse_tracks = None  # buffer.py:73: a caller-supplied tracker (`enabled`, `compute_dense_disp_target_weight`); None = disabled
         self.last_depth_intrinsics = None  # intrinsics the sensor disparities were last estimated with (buffer.py:233-268)
 
     def touch(self):
@@ -149,6 +160,15 @@ class GraphBuffer:
             pi, qi, di, pj, qj = plan if plan is not None else self.expand_edge_multiview(ii, jj)[:5]
         V = self.n_views
         n_poses = max(self.n_frames, int(t1)) - base
+        st = self.sparse_tracks
+        if st is not None and getattr(st, "enabled", False):
+            # buffer.py:422-447: a second flow term on the same edges, targets / weights from the caller's tracker
+            assert V == 1, "This does not support cross-view tracking yet."
+            s_target, s_weight = st.compute_dense_disp_target_weight(
+                source_view_inds=qi, source_frame_inds=self.tstamp[pi + base], target_view_inds=qj,
+                target_frame_inds=self.tstamp[pj + base], image_size=(self.height, self.width),
+                dense_disp_size=(self.height // 8, self.width // 8))
+            target, weight = fold_flow_terms(target, weight, s_target.flatten(1, 2), s_weight.flatten(1, 2))
         self.touch()
         return slam_ext.dense_ba(
             self.poses[base:], self.flattened_disps[base * V:], self.flattened_disps_sens[base * V:], self.intrinsics,

@@ -209,3 +209,14 @@ def make_graph(n=48, height=384, width=512, radius=3, extra_edges=0, seed=1234, 
     return SyntheticGraph(ht, wd, n, poses_gt.astype(f32), disps_gt.astype(f32), poses.astype(f32),
                           disps.astype(f32), sens.astype(f32), intr.astype(f32), ii, jj,
                           target.astype(f32), weight.astype(f32), eta.astype(f32))
+
+
+def make_tracks(g, seed):
+    """A second (target, weight) pair on the graph's edges, shaped like what `SparseTracks.compute_dense_disp_target_weight`
+    returns: about 4 % of the pixels carry a track observation (the flow target displaced by up to a pixel, weights of
+    the order of the dense ones), everything else has weight 0."""
+    rng = np.random.default_rng(seed)
+    target = (g.target + rng.normal(0, 0.7, g.target.shape)).astype(np.float32)
+    hit = rng.random(g.weight.shape[:-1] + (1,)) < 0.04
+    weight = (hit * rng.uniform(0.5, 3.0, g.weight.shape)).astype(np.float32)
+    return target, weight
