@@ -244,6 +244,8 @@ def make_clip_runner(device, features=False, pipelined=True):
     side_stream = torch.cuda.Stream(device=device)
 
     def run_clip(seed, n_frames, with_backend=False, with_infill=False):
+        from vipe_amd.slam import factor_graph as _fg
+        work0 = dict(_fg.WORK)
         buf = GraphBuffer(384, 512, buffer_size=n_frames + 16, device=device)
         buf.intrinsics[:] = torch.tensor([460.8, 460.8, 256.0, 192.0], device=device)
         # keyframe_thresh = 0: every synthetic frame stays a keyframe (random-weight flow would otherwise make the
@@ -311,6 +313,7 @@ def make_clip_runner(device, features=False, pipelined=True):
                 main.wait_stream(side)
         torch.cuda.synchronize()
         t_fe = time.perf_counter() - t0
+        work_fe = {k: _fg.WORK[k] - work0[k] for k in work0}
         if gc_was:
             gc.enable()
         backend_edges = None
@@ -349,9 +352,27 @@ def make_clip_runner(device, features=False, pipelined=True):
                 "keyframes": int(n), "frontend_seconds": t_fe, "backend_seconds": t_be - t_fe, "seconds_without_infill": t_be,
                 "seconds": time.perf_counter() - t0, "finite": finite,
                 "update_iterations": fe.n_updates, "edges_final": int(fe.graph.ii.numel()),
-                "backend_edges": backend_edges, "infill_frames": infill_frames}
+                "backend_edges": backend_edges, "infill_frames": infill_frames,
+                "work_frontend": work_fe, "work": {k: _fg.WORK[k] - work0[k] for k in work0}}
 
     return run_clip
+
+
+# SURVEY 8(d), per edge at 512x384 (P = 3072): one application of the update iteration moves 4.27 MB (lookup fused into
+# the correlation encoder; 6.68 MB unfused) and costs 14.03 GFLOP; one correlation pyramid is 26.7 MB written + 1.57 MB
+# read and 2.42 GFLOP; the two encoders are 10.6 GFLOP per frame
+MB_PER_EDGE_UPDATE, GF_PER_EDGE_UPDATE = 4.27, 14.03
+MB_PER_PYRAMID, GF_PER_PYRAMID, GF_PER_FRAME_ENC = 26.7 + 1.57, 2.42, 10.6
+
+
+def whole_run_roofline(work, frames, seconds):
+    """Algorithmic bytes / FLOPs of a whole clip (host-side edge counts x the per-edge figures above) over its wall time,
+    as fractions of the nominal peaks (8 TB/s HBM, 2.5 PFLOP/s dense fp16)."""
+    gb = (work["edge_updates"] * MB_PER_EDGE_UPDATE + work["pyramids_built"] * MB_PER_PYRAMID) / 1e3
+    tf = (work["edge_updates"] * GF_PER_EDGE_UPDATE + work["pyramids_built"] * GF_PER_PYRAMID + frames * GF_PER_FRAME_ENC) / 1e3
+    return {"edge_updates": work["edge_updates"], "pyramids_built": work["pyramids_built"],
+            "algorithmic_GB": gb, "algorithmic_TFLOP": tf, "hbm_frac": gb / seconds / 8000.0,
+            "mfma_frac": tf / seconds / 2500.0, "peaks": "8 TB/s, 2.5 PFLOP/s"}
 
 
 def video_mode(args, D):
@@ -406,6 +427,8 @@ def video_mode(args, D):
                        "rank0_clip": {k: mine.get(k) for k in ("frontend_seconds", "backend_seconds", "seconds_without_infill",
                                                                "seconds", "update_iterations", "keyframes", "edges_final",
                                                                "backend_edges", "infill_frames", "finite")},
+                       "rank0_clip_roofline": (whole_run_roofline(mine["work"], args.frames, mine["seconds"])
+                                               if "work" in mine else None),
                        "rank0_seconds_to_gather_end": t_gather_end - t0,
                        "input": "feature maps (encoders skipped)" if args.video_features else
                                 "RGB frames: motion filter + feature / context encoders in the timed region"
@@ -523,6 +546,8 @@ def secondary_figures(args, device, graph, step):
             "with_global_ba_and_infill": r["frames"] / r["seconds"],
             "frames": r["frames"], "update_iterations": r["update_iterations"], "backend_edges": r["backend_edges"],
             "state_finite": r["finite"],
+            "roofline_frontend_only": whole_run_roofline(r["work_frontend"], r["frames"], r["frontend_seconds"]),
+            "roofline_whole_clip": whole_run_roofline(r["work"], 2 * r["frames"], r["seconds"]),
             "what": "one synthetic 512x384 clip from RGB frames resident in HBM, every frame a keyframe: motion filter + "
                     "encoders + proximity edges + 4+2 update iterations per keyframe (whole clip incl. the 8-keyframe "
                     "initialisation), the filter of frame f+1 on a side stream while the frontend optimises keyframe f; "
@@ -703,6 +728,15 @@ def update_mode(args, D):
                                    "z|r convolution that starts from staged fp32 partial sums = instantiation <..., 1>)",
                          "avg_launch_ms": gate_ms, "flops_per_launch": flops_per_launch,
                          "launches_per_step": len(rec) // max(1, args.prof_steps)},
+            # the whole update iteration against both nominal peaks (SURVEY 8d totals per edge; N source nodes add
+            # 1.37 GFLOP each): MFMA-bound by construction, the HBM figure is what north_star asks to see beside it
+            "iteration_roofline": {
+                "algorithmic_GB": E * MB_PER_EDGE_UPDATE / 1e3,
+                "algorithmic_TFLOP": (E * GF_PER_EDGE_UPDATE + args.keyframes * 1.37) / 1e3,
+                "hbm_frac": E * MB_PER_EDGE_UPDATE / 1e3 * args.steps / dt / 8000.0,
+                "mfma_frac": (E * GF_PER_EDGE_UPDATE + args.keyframes * 1.37) / 1e3 * args.steps / dt / 2500.0,
+                "what": "reference-equivalent work of one update iteration (incl. the gate terms this build computes once "
+                        "per edge) over the measured step time, per GPU"},
         }
         if world == 1 and not args.no_secondary:
             out.update(secondary_figures(args, device, graph, step))

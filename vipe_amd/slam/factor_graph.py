@@ -15,6 +15,10 @@ from .._lib import upload
 from ..ext import slam_ext
 from .networks import AltCorrBlock, CorrBlock, CorrPool
 
+# host-side work counters (edge counts known without touching the device): edges x operator applications, correlation
+# pyramids built - what bench.py prices a whole clip's algorithmic bytes / FLOPs with (SURVEY 8d per-edge figures)
+WORK = {"edge_updates": 0, "pyramids_built": 0}
+
 
 class _Growable:
     """Per-edge state with spare capacity: `append` writes the new rows behind the live ones (the reference concatenates,
@@ -161,6 +165,7 @@ class FactorGraph:
                 self.corr = CorrPool(capacity=max(64, self.max_factors + 16))
             V = self.buffer.n_views
             self.corr.add_edges(self.buffer.flattened_fmaps, pi * V + qi, pj * V + qj)
+            WORK["pyramids_built"] += int(pi.shape[0])
             xb = torch.zeros((ii.shape[0] * self.buffer.n_views, self.ht, self.wd, 320), dtype=torch.half,
                              device=self.device)
             xb[..., 0:128] = self.buffer.inps[pi, qi].permute(0, 2, 3, 1)
@@ -415,6 +420,7 @@ class FactorGraph:
         t1 = P["t1"] if t1 is None else t1
         buf = self.buffer
         E_act = int(P["pi"].shape[0])
+        WORK["edge_updates"] += E_act
         if "io" not in P:  # per edge set: persistent coords / motion-feature buffers (stable addresses), frame masks
             P["io"] = (torch.empty((E_act, self.ht, self.wd, 2), dtype=torch.float32, device=self.device),
                        torch.empty((E_act, self.ht, self.wd, 4), dtype=torch.float16, device=self.device))
@@ -611,6 +617,7 @@ class FactorGraph:
                     vol = vols.get(gi)
                     if vol is None:
                         vol = CorrBlock.from_buffer(buf.flattened_fmaps, c["pis"] * V + c["qis"], c["pjs"] * V + c["qjs"])
+                        WORK["pyramids_built"] += n
                         if keep_vols:
                             vols[gi] = vol
                     corr_n = vol.lookup_deferred(c1)
@@ -620,6 +627,7 @@ class FactorGraph:
                     corr_n[..., :196] = corr1[0].permute(0, 2, 3, 1)
                 net, dw, eta, _ = eng.forward_nhwc(take(self.net_n).contiguous(), c["xb"], corr_n, take(motn).contiguous(),
                                                    ix=c["dixs"], n_src=c["n_src"], csr=c["csr"], pgate=c["pgate"])
+                WORK["edge_updates"] += n
                 self._gate_state = None
                 if whole:
                     self.net_n = net if net.data_ptr() != self.net_n.data_ptr() else net.clone()
