@@ -693,6 +693,16 @@ def update_mode(args, D):
         except Exception:  # noqa: BLE001
             pass
 
+    # matrix-core utilisation of the same kernel from the builder's SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE pass
+    # (profiles/r02_mfma_util.json) - like `traffic`, evidence collected beside this run, not by it
+    mfma_pmc = None
+    try:
+        mu = json.load(open(os.path.join(ROOT, "profiles", "r02_mfma_util.json")))["void conv_halo32_kernel<128, 3, true, 0>"]
+        mfma_pmc = {"mfma_busy_frac": mu["mfma_util"], "effective_clock_GHz": mu["effective_clock_GHz"],
+                    "avg_launch_ms": mu["avg_us"] / 1e3, "source": "profiles/r02_mfma_util.json (builder-side --pmc pass)"}
+    except Exception:  # noqa: BLE001
+        pass
+
     if rank == 0:
         out = {
             "metric": "dense-BA+flow update iters/s, 512x384 48-KF graph",
@@ -727,7 +737,7 @@ def update_mode(args, D):
                                    "launches with Cout >= 128 of the flow-update operator on the main stream, except the "
                                    "z|r convolution that starts from staged fp32 partial sums = instantiation <..., 1>)",
                          "avg_launch_ms": gate_ms, "flops_per_launch": flops_per_launch,
-                         "launches_per_step": len(rec) // max(1, args.prof_steps)},
+                         "launches_per_step": len(rec) // max(1, args.prof_steps), "pmc": mfma_pmc},
             # the whole update iteration against both nominal peaks (SURVEY 8d totals per edge; N source nodes add
             # 1.37 GFLOP each): MFMA-bound by construction, the HBM figure is what north_star asks to see beside it
             "iteration_roofline": {
