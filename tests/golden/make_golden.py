@@ -480,6 +480,22 @@ def gen_encoder(R):
     print("encoder:", {k: v.shape for k, v in out.items() if not k.startswith("sdsum")})
 
 
+def gen_splat(R):
+    """`bilinear_splatting_inplace` (vipe/utils/depth.py:123-155), the reference function itself: points inside, on the
+    borders, outside, on cell centres and exactly half-way between cells."""
+    depth = _load("vipe.utils.depth", "vipe/utils/depth.py")
+    rng = np.random.default_rng(5)
+    H, W = 12, 16
+    uv = np.concatenate([rng.uniform(-1.5, [W + 0.5, H + 0.5], (300, 2)),
+                         np.array([[3.0, 4.0], [3.5, 4.5], [0.0, 0.0], [-0.5, -0.5], [W - 1.0, H - 1.0], [W - 1.5, H - 1.5],
+                                   [W - 2.0, H - 2.0], [7.49999, 2.50001]])]).astype(np.float32)
+    data = rng.normal(0, 2, (uv.shape[0], 2)).astype(np.float32)
+    out, wgt = torch.zeros(H, W, 2), torch.zeros(H, W)
+    depth.bilinear_splatting_inplace(torch.tensor(data), torch.tensor(uv), out, wgt)
+    np.savez_compressed(os.path.join(HERE, "splat_reference.npz"), uv=uv, data=data, out=_np(out), weight=_np(wgt))
+    print("splat: weight sum", float(wgt.sum()))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     R = load_reference()
@@ -488,6 +504,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if os.environ.get("GOLDEN_ONLY") == "ba_rig":
         gen_ba_rig(R)
+        sys.exit(0)
+    if os.environ.get("GOLDEN_ONLY") == "splat":
+        gen_splat(R)
         sys.exit(0)
     if os.environ.get("GOLDEN_ONLY") == "ba_tracks":
         gen_ba_tracks(R)
@@ -501,6 +520,7 @@ if __name__ == "__main__":
     gen_ba(R)
     gen_ba_rig(R)
     gen_ba_tracks(R)
+    gen_splat(R)
     gen_update_module(R)
     gen_corr(R)
     gen_encoder(R)

@@ -168,3 +168,38 @@ def test_spatial_correlation_sampler_module_and_autograd_on_cpu():
     assert torch.allclose(g[0], r[0], atol=1e-5) and torch.allclose(g[1], r[1], atol=1e-5)
     out2 = spatial_correlation_sample(a.detach(), b.detach(), patch_size=3)
     assert torch.allclose(out2, _sampler_reference(a.detach(), b.detach(), (3, 3), (1, 1)), atol=1e-5)
+
+
+def test_motion_filter_sparse_track_score():
+    """motion_filter.py:112-135 on a scripted tracker: mean keypoint displacement per view summed, + 100 when more than
+    20 % of the previous frame's tracks are gone, nan (never above a threshold) without common keypoints."""
+    from vipe_amd.slam.motion_filter import MotionFilter
+
+    class Tracker:
+        enabled = True
+
+        def __init__(self):
+            self.obs = {}  # frame -> {kp: uv}
+
+        def get_correspondences(self, view_idx, a, b):
+            return torch.tensor(sorted(set(self.obs[a]) & set(self.obs[b])), dtype=torch.long)
+
+        def get_observations(self, view_idx, frame, kp):
+            return torch.tensor([self.obs[frame][int(k)] for k in kp], dtype=torch.float32).reshape(-1, 2)
+
+    tr = Tracker()
+    tr.obs[0] = {k: (10.0 * k, 5.0) for k in range(10)}
+    tr.obs[1] = {k: (10.0 * k + 3.0, 9.0) for k in range(10)}       # all ten tracks moved by (3, 4): 5 px
+    tr.obs[2] = {k: (10.0 * k + 6.0, 13.0) for k in range(7)}       # three of ten lost: 30 % > 20 %
+    tr.obs[3] = {k + 100: (1.0, 1.0) for k in range(4)}             # nothing in common with the keyframe
+    mf = MotionFilter(None, sparse_tracks=tr, thresh=2.4, device=torch.device("cpu"))
+    mf.last_kf_frame_idx, mf.last_n_sparse_tracks = 0, 0
+    mf.current_frame_idx = 1
+    assert abs(mf._sparse_motion_score(1) - 5.0) < 1e-6 and mf.last_n_sparse_tracks == 10
+    mf.current_frame_idx = 2
+    assert abs(mf._sparse_motion_score(1) - 110.0) < 1e-5 and mf.last_n_sparse_tracks == 7
+    mf.current_frame_idx = 3
+    s3 = mf._sparse_motion_score(1)  # 7 -> 0 tracks: + 100 on top of a nan mean
+    assert s3 != s3 and not (s3 > 4.8) and mf.last_n_sparse_tracks == 0
+    tr.enabled = False
+    assert mf._sparse_motion_score(1) == 0.0

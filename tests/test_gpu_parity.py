@@ -2115,3 +2115,64 @@ def test_dense_ba_with_a_sparse_track_term_matches_reference_solver(name):
     assert Tracker.calls == 1
     assert np.abs(p - rp).max() <= 1e-4 * max(1.0, np.abs(rp).max())
     assert np.abs(d - rd).max() <= 1e-4 * np.abs(rd).max()
+
+
+def test_slam_system_with_a_caller_supplied_tracker():
+    """The tracker hooks of the two-pass driver: `track_image` once per frame of pass 1 (system.py:255), the track score in
+    the motion filter (a tracker that loses all its keypoints forces keyframes), the track term in every BA."""
+    from vipe_amd.slam.frontend import FrontendArgs
+    from vipe_amd.slam.inner_filler import InfillArgs
+    from vipe_amd.slam.system import Frame, SLAMConfig, SLAMSystem
+
+    class Tracker:
+        enabled = True
+
+        def __init__(self):
+            self.frames, self.ba_calls = 0, 0
+
+        def track_image(self, frames):
+            self.frames += 1
+
+        def get_correspondences(self, view_idx, a, b):  # ten tracks on even frames, none on odd ones
+            return torch.arange(10 if (a % 2 == 0 and b % 2 == 0) else 0)
+
+        def get_observations(self, view_idx, frame, kp):
+            return torch.zeros(len(kp), 2) + 0.01 * frame
+
+        def compute_dense_disp_target_weight(self, source_view_inds, source_frame_inds, target_view_inds, target_frame_inds,
+                                             image_size, dense_disp_size):
+            self.ba_calls += 1
+            E = source_view_inds.shape[0]
+            z = torch.zeros(E, *dense_disp_size, 2, device=source_view_inds.device)
+            return z, z.clone()  # weight 0 everywhere: the folded term equals the dense one
+
+    gen = torch.Generator().manual_seed(6)
+    T, H, W = 16, 128, 512
+    rgb = torch.rand(T, H, W, 3, generator=gen).to(dev())
+    intr = torch.tensor([460.8, 460.8, 256.0, 64.0])
+    frames = [Frame(rgb=rgb[t], intrinsics=intr) for t in range(T)]
+    torch.manual_seed(0)
+    tr = Tracker()
+    cfg = SLAMConfig(buffer=48, filter_thresh=0.0, frontend_backend_iters=(),
+                     frontend=FrontendArgs(keyframe_thresh=0.0), infill=InfillArgs(infill_chunk_size=8))
+    out = SLAMSystem(dev(), cfg, sparse_tracks=tr).run(frames)
+    torch.cuda.synchronize()
+    assert tr.frames == T and tr.ba_calls > 0
+    assert out.trajectory.data.shape == (T, 7) and bool(torch.isfinite(out.trajectory.data).all())
+
+
+def test_sparse_tracks_target_weight_matches_oracle():
+    """`SparseTracks.compute_dense_disp_target_weight` on the device (the library's atomic scatter kernel) vs the numpy
+    restatement, and through `GraphBuffer.bundle_adjustment` as the BA's second flow term."""
+    from oracle import tracks
+    from test_oracle_golden import _synthetic_tracks
+    from vipe_amd.slam.sparse_tracks import ReplayedSparseTracks
+    tr = ReplayedSparseTracks(_synthetic_tracks(9, n_frames=8, n_kp=200, size=(384, 512)))
+    for _ in range(8):
+        tr.track_image(None)
+    ii = np.array([0, 1, 2, 3, 7, 4, 0, 6]); jj = np.array([1, 0, 4, 3, 2, 5, 7, 6])
+    z = torch.zeros(len(ii), dtype=torch.long, device=dev())
+    val, wgt = tr.compute_dense_disp_target_weight(z, T(ii), z, T(jj), (384, 512), (48, 64))
+    rv, rw = tracks.dense_disp_target_weight(tr.observations, [0] * len(ii), ii.tolist(), jj.tolist(), (384, 512), (48, 64))
+    assert np.abs(wgt.cpu().numpy() - rw).max() < 1e-5 and np.abs(val.cpu().numpy() - rv).max() < 1e-4
+    assert (rw > 0).sum() > 500

@@ -347,3 +347,47 @@ def test_ba_with_a_sparse_track_term_matches_reference_solver(name):
     assert np.abs(d[:, 0] - rd).max() <= 2e-5 * np.abs(rd).max()
     # the track term matters: the two-term result is not the one-term result
     assert np.abs(rp - G1[name + "/poses"]).max() + np.abs(rd - G1[name + "/disps"]).max() > 1e-4
+
+
+def test_bilinear_splat_matches_reference_function():
+    """`oracle.tracks.bilinear_splat` vs outputs of the reference's `bilinear_splatting_inplace` (fixture)."""
+    from oracle import tracks
+    G = np.load(os.path.join(GOLD, "splat_reference.npz"))
+    out, wgt = np.zeros_like(G["out"]), np.zeros_like(G["weight"])
+    tracks.bilinear_splat(G["data"], G["uv"], out, wgt)
+    assert np.abs(wgt - G["weight"]).max() < 1e-5 and np.abs(out - G["out"]).max() < 1e-4
+    assert G["weight"].max() > 1.0  # the reference's corner weights reach 1.5^2: not the textbook bilinear weights
+
+
+def _synthetic_tracks(seed, n_frames=6, n_kp=60, size=(96, 128)):
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform([0, 0], [size[1], size[0]], (n_kp, 2)).astype(np.float32)
+    vel = rng.normal(0, 1.5, (n_kp, 2)).astype(np.float32)
+    obs = []
+    for f in range(n_frames):
+        seen = rng.random(n_kp) < 0.8
+        obs.append({int(k): tuple((pos[k] + f * vel[k]).tolist()) for k in np.flatnonzero(seen)})
+    return [obs]
+
+
+def test_sparse_tracks_target_weight_matches_oracle_on_cpu():
+    """`SparseTracks.compute_dense_disp_target_weight` (one upload + two scatter launches for all edges) vs the per-edge
+    numpy restatement of sparse_tracks/__init__.py:68-141; correspondences and observations as the reference returns them."""
+    import torch
+    from oracle import tracks
+    from vipe_amd.slam.sparse_tracks import DummySparseTracks, ReplayedSparseTracks
+    tr = ReplayedSparseTracks(_synthetic_tracks(8))
+    for _ in range(6):
+        tr.track_image(None)
+    ii = np.array([0, 1, 2, 3, 5, 4, 0]); jj = np.array([1, 0, 4, 3, 2, 5, 5])
+    z = torch.zeros(len(ii), dtype=torch.long)
+    val, wgt = tr.compute_dense_disp_target_weight(z, torch.tensor(ii), z, torch.tensor(jj), (96, 128), (12, 16))
+    rv, rw = tracks.dense_disp_target_weight(tr.observations, [0] * len(ii), ii.tolist(), jj.tolist(), (96, 128), (12, 16))
+    assert val.shape == (7, 12, 16, 2) and np.abs(wgt.numpy() - rw).max() < 1e-5 and np.abs(val.numpy() - rv).max() < 1e-4
+    assert (rw > 0).sum() > 50 and np.array_equal(rv[3, ..., 0], np.tile(np.arange(16.0), (12, 1)))  # i == j: zero flow
+    kp = tr.get_correspondences(0, 0, 1)
+    assert kp.tolist() == sorted(set(tr.observations[0][0]) & set(tr.observations[0][1]))
+    assert tr.get_observations(0, 1, kp).shape == (len(kp), 2) and tr.get_observations(0, 1, kp[:0]).shape == (0, 2)
+    d = DummySparseTracks(2)
+    d.track_image(None)
+    assert not d.enabled and d.observations == [[{}], [{}]]

@@ -6,8 +6,8 @@ Per frame: feature encoder (HIP, `encoders.py`) -> correlation pyramid between t
 new ones -> ONE application of the flow-update operator on the identity grid -> mean flow magnitude against the
 threshold; the context encoder runs only when the frame becomes a keyframe.  Everything that is constant while the
 last keyframe stays (its hidden state / context features in channels-last form, the hoisted gate-context term of the
-GRU) is prepared once per keyframe.  Sparse tracks (`sparse_tracks.enabled`) are outside the dense path and treated as
-disabled, as `SparseTracks` is when the reference runs without a tracker."""
+GRU) is prepared once per keyframe.  The sparse-track score (`motion_filter.py:112-135`) is host arithmetic on what a caller-supplied
+tracker reports (`get_correspondences`, `get_observations`); the trackers themselves are outside the path."""
 import torch
 
 from .._lib import require
@@ -82,8 +82,6 @@ class MotionFilter:
         waited for.  A pipeline that filters frame t+1 on a side stream while the frontend optimises keyframe t on the
         main stream calls begin(t+1) before `frontend.run()` and finish(...) after it: the filter only depends on the
         last keyframe's features, which `finish(t)` has already installed."""
-        require(not (self.sparse_tracks is not None and getattr(self.sparse_tracks, "enabled", False)),
-                "sparse tracks are outside the dense path")
         ctx = torch.cuda.stream(stream) if stream is not None else _null_ctx()
         with ctx:
             x4 = normalize_images(images)
@@ -116,16 +114,41 @@ class MotionFilter:
                 self._set_keyframe(h["images"], h["x4"], h["gmap"], h["masks"])
                 self.current_frame_idx = 0
                 self.last_kf_frame_idx = 0
+                self.last_n_sparse_tracks = 0
                 self.initialized = True
                 return True
             self.current_frame_idx += 1
             h["event"].synchronize()
             self.last_score = float(h["score"])
-            if self.last_score > self.thresh:
+            sparse = self._sparse_motion_score(h["images"].shape[0])
+            # the track score is a sum over keypoints' mean displacement, not a pixel average: twice the threshold
+            if self.last_score > self.thresh or sparse > self.thresh * 2:
                 self._set_keyframe(h["images"], h["x4"], h["gmap"], h["masks"])
                 self.last_kf_frame_idx = self.current_frame_idx
+                self.last_n_sparse_tracks = 0
                 return True
             return False
+
+    def _sparse_motion_score(self, n_views):
+        """motion_filter.py:112-135, host arithmetic on what the caller's tracker reports: mean displacement of the
+        keypoints seen in both the current frame and the last keyframe, summed over the views; + 100 when more than 20 %
+        of the tracks of the previous frame are gone (forces a keyframe)."""
+        st = self.sparse_tracks
+        if st is None or not getattr(st, "enabled", False):
+            return 0.0
+        score, n_tracks = 0.0, 0
+        for v in range(n_views):
+            kp = st.get_correspondences(v, self.current_frame_idx, self.last_kf_frame_idx)
+            n_tracks += len(kp)
+            cur = st.get_observations(v, self.current_frame_idx, kp)
+            last = st.get_observations(v, self.last_kf_frame_idx, kp)
+            score += (cur - last).norm(dim=-1).mean().item()  # no common keypoint: nan, which never exceeds a threshold
+        lost = self.last_n_sparse_tracks - n_tracks
+        if lost > 0 and self.last_n_sparse_tracks > 0 and lost / self.last_n_sparse_tracks > 0.2:
+            score += 100.0
+        self.last_n_sparse_tracks = n_tracks
+        self.last_sparse_score = score
+        return score
 
     def _engine(self, device):
         """The filter's own execution engine of the update operator: private scratch buffers and descriptors, so that

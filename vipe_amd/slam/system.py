@@ -50,17 +50,21 @@ class Frame:
 
 
 class SLAMSystem:
-    def __init__(self, device=torch.device("cuda"), config=None, droid_net=None, depth_model=None):
+    def __init__(self, device=torch.device("cuda"), config=None, droid_net=None, depth_model=None, sparse_tracks=None):
         self.device, self.config = device, config or SLAMConfig()
         self.droid_net = droid_net if droid_net is not None else DroidNet()
         self.metric_depth = depth_model  # system.py:114-127 builds it from `keyframe_depth`; here the caller's
+        self.sparse_tracks = sparse_tracks
+        # system.py:91 builds a tracker from the config; here the caller's (`track_image(frames)` per frame of pass 1,
+        # `enabled`, `compute_dense_disp_target_weight` for the BA's track term) or None = the reference's dummy
 
     def _build_components(self, height, width, n_views, rig, camera_type):
         c = self.config
         self.buffer = GraphBuffer(height, width, n_views=n_views, buffer_size=c.buffer, init_disp=c.init_disp,
                                   cross_view_idx=c.cross_view_idx, camera_type=camera_type, device=self.device)
         self.buffer.rig[:] = rig.data.to(self.device)
-        self.motion_filter = MotionFilter(self.droid_net, thresh=c.filter_thresh, device=self.device)
+        self.buffer.sparse_tracks = self.sparse_tracks
+        self.motion_filter = MotionFilter(self.droid_net, sparse_tracks=self.sparse_tracks, thresh=c.filter_thresh, device=self.device)
         self.frontend = SLAMFrontend(self.droid_net.update, self.buffer, c.frontend, self.device)
         self.backend = SLAMBackend(self.droid_net.update, self.buffer, c.backend, self.device)
         self.inner_filler = InnerFiller(self.droid_net.update, self.buffer, c.infill, self.device)
@@ -125,6 +129,8 @@ class SLAMSystem:
         n_keyframes = []
         for frame_idx, fl in enumerate(frames):  # SLAM pass 1/2
             images, masks = self._precompute_features(fl)
+            if self.sparse_tracks is not None:
+                self.sparse_tracks.track_image(fl)
             kept = self.motion_filter.check(images, masks)
             is_keyframe = kept or frame_idx == total - 1
             if is_keyframe:
