@@ -31,6 +31,10 @@ def run(cin, cout, k):
     d = np.diff(rt, axis=1)
     clk = (cy[:, 2] - cy[:, 1]) / np.maximum(d[:, 1], 1e-9) / 1e3  # GHz over K loop
     print(f"cin={cin} cout={cout} k={k}: blocks={nblk} span={rt[:,4].max()-t0:.1f} us; per-block median us: prologue {np.median(d[:,0]):.2f}  kloop {np.median(d[:,1]):.2f}  stage {np.median(d[:,2]):.2f}  epilogue {np.median(d[:,3]):.2f}  total {np.median(rt[:,4]-rt[:,0]):.2f}; clock {np.median(clk):.2f} GHz", flush=True)
+    kc = cy[:, 2] - cy[:, 1]
+    if k == 3:
+        print(f"   wave 0 inside the K loop (share of its cycles): waiting for LDS-DMA (s_waitcnt vmcnt) {np.median(s[:,10]/np.maximum(kc,1)):.3f}  "
+              f"at the per-tap barrier {np.median(s[:,11]/np.maximum(kc,1)):.3f}")
     # gaps between consecutive blocks on a CU are not visible here; report the first-wave start distribution
     starts = np.sort(rt[:, 0] - t0)
     print("   start time percentiles (us):", np.percentile(starts, [0, 5, 25, 50, 75, 100]).round(1))

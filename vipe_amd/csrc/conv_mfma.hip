@@ -602,6 +602,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // count when there is nothing to fetch).  At the end of tap t the DMAs younger than W(step + 1) are
     // {X_t (t < 4), W(step + 2), X_{t-1} (1 <= t <= 4)}: vmcnt(2,3,3,3,2,1,1,1,1).  A halo piece issued at tap t <= 3 has
     // landed by the end of tap 5, before the chunk ends.
+#ifdef VIPE_CONV_STAMPS
+    unsigned long long stamp_vm = 0, stamp_bar = 0;
+#endif
     for (int c = 0; c < cs32; ++c) {
       const unsigned char* bx = ldsX + (c & 1) * H32_XBYTES;
       const bool more = c + 1 < cs32;
@@ -623,13 +626,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
 #endif
         mma_step(ldsW + (TAP % 3) * WSTAGE, bx, Rl, TAP / 3 - 1, TAP % 3 - 1);
+#ifdef VIPE_CONV_STAMPS  // diagnostic build: wave 0's time at the DMA wait and at the barrier of every tap
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long ts_a = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 #ifndef VIPE_ABL_NODMA
         if constexpr (TAP == 0 || TAP == 4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else if constexpr (TAP < 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
 #endif
+#ifdef VIPE_CONV_STAMPS
+        const unsigned long long ts_b = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 #ifndef VIPE_ABL_NOBAR  // ablation: no per-tap barrier
         __syncthreads();
+#endif
+#ifdef VIPE_CONV_STAMPS
+        const unsigned long long ts_c = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp_vm += ts_b - ts_a;
+        stamp_bar += ts_c - ts_b;
+        __builtin_amdgcn_sched_barrier(0);
 #endif
       };
       tap_step(std::integral_constant<int, 0>{});
@@ -642,6 +661,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       tap_step(std::integral_constant<int, 7>{});
       tap_step(std::integral_constant<int, 8>{});
     }
+#ifdef VIPE_CONV_STAMPS
+    if (g_stamps && threadIdx.x == 0) {
+      g_stamps[(size_t)blockIdx.x * 12 + 10] = stamp_vm;
+      g_stamps[(size_t)blockIdx.x * 12 + 11] = stamp_bar;
+    }
+#endif
   } else {
     for (int c = 0; c < cs32; ++c) {
       const unsigned char* bx = ldsX + (c & 1) * H32_XBYTES;
