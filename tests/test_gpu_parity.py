@@ -2176,3 +2176,23 @@ def test_sparse_tracks_target_weight_matches_oracle():
     rv, rw = tracks.dense_disp_target_weight(tr.observations, [0] * len(ii), ii.tolist(), jj.tolist(), (384, 512), (48, 64))
     assert np.abs(wgt.cpu().numpy() - rw).max() < 1e-5 and np.abs(val.cpu().numpy() - rv).max() < 1e-4
     assert (rw > 0).sum() > 500
+
+
+@pytest.mark.parametrize("n,radius", [(48, 3), (33, 2), (34, 1), (40, 3)])
+def test_two_chain_band_solve_equals_one_chain(n, radius, monkeypatch):
+    """Long pose-only neighbourhood chains are eliminated from both ends at once (band2_solve_body: chain A in natural order,
+    chain B mirrored, the separator's Schur contributions merged, separator factored, both chains back-substituted in
+    parallel).  Same fp64 arithmetic on another elimination order: poses / disparities agree with the one-chain form
+    (`VIPE_BA_BAND2=0`) to 1e-5 (the north_star tolerance is 1e-4), for even and odd chain splits and several band widths."""
+    bk = dict(t0=1, t1=n, n_iters=2, pose_damping=1e-3, pose_ep=0.1, motion_only=False, limited_disp=False,
+              optimize_intrinsics=False)
+    g = make_graph(n=n, height=96, width=128, radius=radius, seed=100 + n)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("VIPE_BA_BAND2", flag)
+        res[flag] = run_hip_ba(g, g.intrinsics, "pinhole", dict(bk))
+    (p1, d1, _, i1), (p0, d0, _, i0) = res["1"], res["0"]
+    assert i1[2] == 0 and i0[2] == 0 and i1[5] == 1 and i0[5] == 1  # no failed pivot; the LDS band solver took both
+    # (fp32 states; the accumulate kernels' atomics alone make two runs of ONE form differ in the last bits)
+    assert np.abs(p1 - p0).max() <= 1e-5 * max(1.0, np.abs(p0).max()) and np.abs(d1 - d0).max() <= 1e-5 * np.abs(d0).max()
+    assert np.abs(p0 - g.poses).max() > 1e-4  # the step moved the poses

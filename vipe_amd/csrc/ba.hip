@@ -64,6 +64,7 @@ struct BAArgs {
   // optimize_rig_rotation; view 0 is the gauge, buffer.py:506); ntail = both.  Mono: the F <= 2 shared intrinsics.
   int mv, nintr, ntail;
   int force_simple;  // VIPE_BA_ACCUM_SIMPLE: shuffle-reduction accumulate kernel for every graph (A/B, debugging)
+  int band2;         // two-chain band solve for long pose-only chains (VIPE_BA_BAND2=0 switches it off for A/B)
   // DROID semantics of slam_ext.ba (geom_kernels.cu:178-432, 1273-1404; see oracle/droid_ba.py for the list):
   // target / weight [M,2,P], eta [K,P] by krow, per-pixel depth prior, reduced-diagonal damping, poses free iff in
   // [t0,t1), stereo terms, MIN_DEPTH 0.25, pose t0 left out of the disparity back-substitution, dz written to dz_out
@@ -2155,14 +2156,294 @@ __device__ __forceinline__ void band_solve_body(const BAArgs& a, int lds_doubles
   SOLVE_STAMP(5);
 }
 
-__global__ __launch_bounds__(BAND_T) void ba_solve_band_kernel(BAArgs a, int lds_doubles) {
+// Two-chain ("burn at both ends") form of the band solve for pose-only systems (no intrinsics columns): the sequential
+// pivot chain, not arithmetic, bounds the kernel (47 dependent block steps at N = 48), and a block-banded SPD matrix can be
+// eliminated from BOTH ends at once.  Blocks 0..a-1 (chain A, natural order) and blocks nb-1..a+bandblk (chain B,
+// REVERSED order - the mirrored matrix is banded too, its lower triangle being the transposed upper one) are factorised
+// concurrently by the two halves of the workgroup, each on its own LDS band image with the same code as above; the
+// bandblk separator blocks in the middle are ordinary band rows at the end of both images, so both eliminations leave
+// their Schur contributions in them.  Chain B's are then added to chain A's image, chain A factors the separator (bandblk
+// more steps), and the back substitution runs separator first, then both chains at once.  Dependent block steps:
+// max(a, b) + bandblk forward, bandblk + max(a, b) back, instead of nb + nb.
+constexpr int B2_T = BAND_T;  // threads per chain: the kernel is launched with 2 * BAND_T threads, the one-chain forms use the first BAND_T
+
+__device__ __forceinline__ bool band2_solve_body(const BAArgs& a, int lds_doubles, unsigned char* smem_raw) {
+  const vipe_ba_params& prm = a.p;
+  const BAWs& w = a.w;
+  const int t = threadIdx.x, g = t >= B2_T ? 1 : 0, tl = t - g * B2_T;
+  const int n = w.info[3], nb = w.info[0], bandblk = w.info[4];
+  const int ld = w.ld;
+  if (n != 6 * nb || bandblk < 1 || nb < 4 * bandblk + 4) return false;
+  const int PB = 6 * bandblk, WB = PB + 6, WBP = WB + 1, KS = 6 * WBP;
+  if (PB + 7 > 64) return false;
+  const int ca = (nb - bandblk) / 2, cb = nb - bandblk - ca;  // chain lengths in blocks (cb >= ca)
+  const int nf = (g ? cb : ca) + bandblk, chain = g ? cb : ca;  // blocks of this image, of its chain
+  const int nfmax = cb + bandblk;
+  const int npr = 6 * nf, nprmax = 6 * nfmax;
+  const int npp = PB * (PB + 1) / 2, npair = npp + PB;
+  if (npair > 21 + 2 * (B2_T - 64)) return false;
+  // LDS carve per image: band [nprmax][WBP], rhs row [nprmax + 1], rdall [nprmax], blk 42, rd 6; then one flag
+  const int IMG = nprmax * WBP + (nprmax + 1) + nprmax + 48;
+  if (2 * IMG + 8 > lds_doubles) return false;
+  double* const L = reinterpret_cast<double*>(smem_raw) + g * IMG;
+  double* const y = L + nprmax * WBP;  // the image's right-hand side (a tail row of the factorisation)
+  double* const rdall = y + nprmax + 1;
+  double* const blk = rdall + nprmax;
+  double* const rd = blk + 42;
+  int* const failp = reinterpret_cast<int*>(reinterpret_cast<double*>(smem_raw) + 2 * IMG);
+  double* const LA = reinterpret_cast<double*>(smem_raw);
+  double* const LB = LA + IMG;
+  const double* S = w.S;
+  auto gblk = [&](int l) { return g ? nb - 1 - l : l; };  // local block -> global block
+  if (t == 0) { *failp = 0; w.info[5] = 0; }
+
+  // ---- load both images (LM damping on the diagonal, matrix.py:179-186).  Image B: mirrored; its separator square and
+  // separator right-hand side start from zero (they only collect chain B's contributions)
+  {
+    const int wv = tl >> 6, ln = tl & 63;
+#pragma unroll 6
+    for (int r = wv; r < npr; r += B2_T / 64) {
+      const int lr = r / 6, c = 6 * lr - PB + ln;
+      double v = 0.0;
+      if (ln < WB && c >= 0 && c <= r) {
+        const int lc = c / 6;
+        const int R = 6 * gblk(lr) + r % 6, C = 6 * gblk(lc) + c % 6;
+        const bool sepsq = g && lr >= chain && lc >= chain;
+        if (!sepsq) {
+          v = R >= C ? S[(int64_t)R * ld + C] : S[(int64_t)C * ld + R];
+          if (c == r) v += (double)prm.pose_ep + (double)prm.pose_damping * (a.droid ? v : w.Hd[R]);
+        }
+      }
+      if (ln < WBP) L[r * WBP + ln] = v;
+    }
+    for (int c = tl; c <= npr; c += B2_T) {
+      double v = 0.0;
+      if (c < npr && !(g && c / 6 >= chain)) v = S[(int64_t)n * ld + 6 * gblk(c / 6) + c % 6];
+      y[c] = v;
+    }
+  }
+  // ---- per-thread operand descriptors (as in band_solve_body, one tail row = the right-hand side)
+  int prow_off = 0, prow_str = 0, prow_ia = -1;
+  const bool has_prow = tl < PB + 1;
+  if (has_prow) {
+    if (tl < PB) { prow_ia = tl; prow_off = (6 + tl) * WBP - 6 - 6 * (tl / 6) + PB; prow_str = KS; }
+    else { prow_off = nprmax * WBP; prow_str = 6; }
+  }
+  constexpr int UPT = 2;
+  int uA[UPT], uB[UPT], uD[UPT], sA[UPT], sB[UPT], sD[UPT], u_ia[UPT], u_ib[UPT];
+  bool has_pair[UPT];
+#pragma unroll
+  for (int sl = 0; sl < UPT; ++sl) {
+    const int pid = tl < 64 ? (sl == 0 && tl < 21 ? tl : npair) : 21 + (tl - 64) + (B2_T - 64) * sl;
+    has_pair[sl] = pid < npair;
+    uA[sl] = uB[sl] = uD[sl] = sA[sl] = sB[sl] = sD[sl] = 0;
+    u_ia[sl] = u_ib[sl] = -1;
+    if (!has_pair[sl]) continue;
+    if (pid < npp) {
+      int ia = (int)((sqrtf(8.0f * (float)pid + 1.0f) - 1.0f) * 0.5f);
+      while ((ia + 1) * (ia + 2) / 2 <= pid) ++ia;
+      while (ia * (ia + 1) / 2 > pid) --ia;
+      const int ib = pid - ia * (ia + 1) / 2;
+      u_ia[sl] = ia; u_ib[sl] = ib;
+      uA[sl] = (6 + ia) * WBP - 6 - 6 * (ia / 6) + PB; sA[sl] = KS;
+      uB[sl] = (6 + ib) * WBP - 6 - 6 * (ib / 6) + PB; sB[sl] = KS;
+      uD[sl] = (6 + ia) * WBP + ib - 6 * (ia / 6) + PB; sD[sl] = KS;
+    } else {
+      const int ib = pid - npp;
+      u_ib[sl] = ib;
+      uA[sl] = nprmax * WBP; sA[sl] = 6;
+      uB[sl] = (6 + ib) * WBP - 6 - 6 * (ib / 6) + PB; sB[sl] = KS;
+      uD[sl] = nprmax * WBP + 6 + ib; sD[sl] = 6;
+    }
+  }
+  auto bofs = [&](int r, int c) { return r * WBP + c - 6 * (r / 6) + PB; };
+  auto factor_diag = [&](int kb) {
+    const int j0 = 6 * kb;
+    double* Dk = L + bofs(j0, j0);
+    double A[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) A[i][j] = Dk[i * WBP + j];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      double d = A[j][j];
+#pragma unroll
+      for (int m = 0; m < j; ++m) d = __builtin_fma(-(A[j][m]), A[j][m], d);
+      if (!(d > 0.0)) { *failp = 1; d = 1.0; }
+      const double rl = rsqrt_nr(d);
+      A[j][j] = d * rl;
+      rd[j] = rl;
+      rdall[j0 + j] = rl;
+#pragma unroll
+      for (int i = j + 1; i < 6; ++i) {
+        double sacc = A[i][j];
+#pragma unroll
+        for (int m = 0; m < j; ++m) sacc = __builtin_fma(-(A[i][m]), A[j][m], sacc);
+        A[i][j] = sacc * rl;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) { Dk[i * WBP + j] = A[i][j]; blk[i * 7 + j] = A[i][j]; }
+  };
+  // one block step of this image (the barriers are the caller's): panel, then trailing update + look-ahead
+  auto panel = [&](int kb) {
+    const int j0 = 6 * kb;
+    if (has_prow && (prow_ia < 0 || j0 + 6 + prow_ia < npr)) {
+      double* row = L + prow_off + kb * prow_str;
+      double x[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        double sacc = row[j];
+#pragma unroll
+        for (int m = 0; m < j; ++m) sacc = __builtin_fma(-(x[m]), blk[j * 7 + m], sacc);
+        x[j] = sacc * rd[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) row[j] = x[j];
+    }
+  };
+  auto trailing = [&](int kb, int kend) {
+    const int j0 = 6 * kb;
+#pragma unroll
+    for (int sl = 0; sl < UPT; ++sl) {
+      if (has_pair[sl] && (u_ia[sl] < 0 || j0 + 6 + u_ia[sl] < npr) && (u_ib[sl] < 0 || j0 + 6 + u_ib[sl] < npr)) {
+        const double* pa = L + uA[sl] + kb * sA[sl];
+        const double* pb = L + uB[sl] + kb * sB[sl];
+        double sacc = 0.0;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) sacc = __builtin_fma(pa[m], pb[m], sacc);
+        L[uD[sl] + kb * sD[sl]] -= sacc;
+      }
+    }
+    if (tl < 64) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (tl == 0 && kb + 1 < kend) factor_diag(kb + 1);
+    }
+  };
+  __syncthreads();
+  if (tl == 0) factor_diag(0);
+  __syncthreads();
+  // ---- both chains, one block per step
+  for (int kb = 0; kb < cb; ++kb) {
+    const bool mine = kb < chain;
+    if (mine) panel(kb);
+    __syncthreads();
+    if (mine) trailing(kb, chain);  // the look-ahead stops at the chain's end: the separator is not final yet
+    __syncthreads();
+  }
+  // ---- chain B's contributions to the separator square and right-hand side go to image A (mirrored back)
+  for (int idx = t; idx < PB * PB + PB; idx += 2 * B2_T) {
+    if (idx < PB * PB) {
+      const int rB = idx / PB, cB = idx % PB;  // separator-local row / column in image B's order, rB >= cB
+      if (rB >= cB) {
+        const int sr = rB / 6, sc = cB / 6, i = rB % 6, j = cB % 6;
+        const double v = LB[bofs(6 * cb + rB, 6 * cb + cB)];
+        const int br = bandblk - 1 - sr, bc = bandblk - 1 - sc;  // separator blocks in image A's order (br <= bc)
+        if (sr == sc) LA[bofs(6 * (ca + br) + i, 6 * (ca + br) + j)] += v;
+        else LA[bofs(6 * (ca + bc) + j, 6 * (ca + br) + i)] += v;  // the transposed position
+      }
+    } else {
+      const int q = idx - PB * PB, sq = q / 6, i = q % 6;
+      LA[nprmax * WBP + 6 * (ca + bandblk - 1 - sq) + i] += LB[nprmax * WBP + 6 * cb + q];
+    }
+  }
+  __syncthreads();
+  // ---- chain A goes on through the separator
+  if (g == 0 && tl == 0) factor_diag(ca);
+  __syncthreads();
+  for (int kb = ca; kb < ca + bandblk; ++kb) {
+    if (g == 0) panel(kb);
+    __syncthreads();
+    if (g == 0) trailing(kb, ca + bandblk);
+    __syncthreads();
+  }
+  // ---- back substitution, column oriented as in band_solve_body (one wave per image): separator first (image A) ...
+  auto backsub_block = [&](int kb, bool known, int colmax) {
+    // x of block kb (solved here, or `known`: already in y), then y[band columns < colmax] -= L[block rows][column] x
+    const int j0 = 6 * kb;
+    const double* Dk = L + bofs(j0, j0);
+    double Lk[6][6], rp[6], lc[6];
+    const int rt = j0 - PB + tl;
+    const bool upd = tl < PB && rt >= 0 && rt < colmax;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      rp[i] = rdall[j0 + i];
+      lc[i] = upd ? L[(j0 + i) * WBP + tl] : 0.0;
+#pragma unroll
+      for (int j = 0; j < i; ++j) Lk[i][j] = Dk[i * WBP + j];
+    }
+    double x[6];
+    if (known) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) x[j] = y[j0 + j];
+    } else {
+#pragma unroll
+      for (int j = 5; j >= 0; --j) {
+        double sacc = y[j0 + j];
+#pragma unroll
+        for (int m = 5; m > j; --m) sacc = __builtin_fma(-(Lk[m][j]), x[m], sacc);
+        x[j] = sacc * rp[j];
+      }
+      if (tl < 6) {
+        double xo = x[0];
+#pragma unroll
+        for (int j = 1; j < 6; ++j) xo = tl == j ? x[j] : xo;
+        y[j0 + tl] = xo;
+      }
+    }
+    if (upd) {
+      double sacc = lc[0] * x[0];
+#pragma unroll
+      for (int j = 1; j < 6; ++j) sacc = __builtin_fma(lc[j], x[j], sacc);
+      y[rt] -= sacc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  if (g == 0 && tl < 64)
+    for (int kb = ca + bandblk - 1; kb >= ca; --kb) backsub_block(kb, false, npr);
+  __syncthreads();
+  if (t < PB) LB[nprmax * WBP + 6 * (cb + bandblk - 1 - t / 6) + t % 6] = LA[nprmax * WBP + 6 * ca + t];  // x of the separator, mirrored
+  __syncthreads();
+  // ... then both chains at once; in image B the separator rows only hand their (known) x down to the chain's columns
+  if (tl < 64) {
+    if (g)
+      for (int kb = cb + bandblk - 1; kb >= cb; --kb) backsub_block(kb, true, 6 * cb);
+    for (int kb = chain - 1; kb >= 0; --kb) backsub_block(kb, false, npr);
+  }
+  __syncthreads();
+  const bool bad = *failp != 0;
+  if (t == 0) {
+    if (bad) w.info[2] += 1;
+    w.info[5] = 1;
+  }
+  for (int r = tl; r < (g ? 6 * cb : npr); r += B2_T) {  // image A: chain + separator, image B: its chain
+    double x = y[r];
+    if (bad || !(x == x)) x = 0.0;
+    w.dx[6 * gblk(r / 6) + r % 6] = (float)x;
+  }
+  __syncthreads();
+  apply_retraction(a, t, 2 * B2_T, nb);
+  return true;
+}
+
+__global__ __launch_bounds__(2 * BAND_T) void ba_solve_band_kernel(BAArgs a, int lds_doubles) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const BAWs& w = a.w;
   const int n = w.info[3], n_free = w.info[0], bandblk = w.info[4];
   const int ntail = n - 6 * n_free + 1, F = ntail - 1;
   const int PB = 6 * bandblk;
   const int npair = PB * (PB + 1) / 2 + ntail * PB + (F == 0 ? 0 : (F == 1 ? 2 : 5));
-  if (PB + 7 > 64 || npair > 21 + 2 * (BAND_T - 64)) band_solve_body<BAND_UPT, true>(a, lds_doubles, smem_raw);
+  const bool wide = PB + 7 > 64 || npair > 21 + 2 * (BAND_T - 64);
+  // long pose-only chains: both ends at once, one chain per half of the workgroup (a uniform decision made before any
+  // barrier; VIPE_BA_BAND2=0 in the environment keeps the one-chain form for A/B - passed down as a flag)
+  if (!wide && F == 0 && a.band2 && band2_solve_body(a, lds_doubles, smem_raw)) return;
+  if (threadIdx.x >= BAND_T) return;  // the one-chain forms are written for BAND_T threads
+  if (wide) band_solve_body<BAND_UPT, true>(a, lds_doubles, smem_raw);
   else band_solve_body<2, false>(a, lds_doubles, smem_raw);
 }
 
@@ -3267,7 +3548,7 @@ int run_iters(const BAArgs& a, hipStream_t s, int* pieces_done) {
     }
     if (a.force_simple == 1) ba_accum_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
     if (ev && hipEventRecord(ev, s) != hipSuccess) return VIPE_EINVAL;
-    if (!(hint & 8)) ba_solve_band_kernel<<<1, BAND_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)));
+    if (!(hint & 8)) ba_solve_band_kernel<<<1, 2 * BAND_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)));
     if (!(hint & 16)) ba_solve_dense_kernel<<<1, DN_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)), getenv("VIPE_BA_DEBUG_TIMING") ? 1 : 0);
     if (!(hint & 4)) {
       ba_solve_kernel<<<1, SOLVE_T, solve_lds, s>>>(a, panel_cap, getenv("VIPE_BA_DEBUG_TIMING") ? (long long*)(a.w.Hd + nmax) : nullptr);
@@ -3322,6 +3603,10 @@ VIPE_EXPORT int vipe_dense_ba(const vipe_ba_params* p, float* d_poses, float* d_
   a.nintr = tail_intr(*p);
   a.ntail = a.nintr + tail_rig(*p);
   a.force_simple = getenv("VIPE_BA_ACCUM_SIMPLE") ? 1 : (getenv("VIPE_BA_ACCUM_GENERAL") ? 2 : 0);
+  {
+    const char* b2 = getenv("VIPE_BA_BAND2");
+    a.band2 = !(b2 && b2[0] == '0');
+  }
   a.droid = 0;
   a.dz_out = nullptr;
   hipStream_t s = as_stream(stream);
@@ -3403,6 +3688,10 @@ VIPE_EXPORT int vipe_ba(float* d_poses, float* d_disps, const float* d_intrinsic
   a.P = ht * wd; a.nF = n_poses; a.D = 0;
   a.mv = 0; a.nintr = 0; a.ntail = 0;
   a.force_simple = getenv("VIPE_BA_ACCUM_SIMPLE") ? 1 : (getenv("VIPE_BA_ACCUM_GENERAL") ? 2 : 0);
+  {
+    const char* b2 = getenv("VIPE_BA_BAND2");
+    a.band2 = !(b2 && b2[0] == '0');
+  }
   a.droid = 1;
   a.dz_out = d_dz;
   if (iterations == 0 || t1 == t0) return VIPE_OK;
