@@ -50,6 +50,10 @@ struct ConvArgs {
   float* fout;                                 // GLO: glo_sum [B,Cout]; HEADS: [M,4]; ETA: [M]
   const half_t* accinit; int ai_ctot, ai_coff;  // optional initial accumulator [M, ai_ctot] (a partial conv sum)
   int ai_f32;                                   // ... held as fp32 (the output of an EPI_PARTIAL launch) instead of fp16
+  // flat tiling (FLAT kernels, any H x W): a tile is 256 consecutive positions q = y * Wp + x of the image padded to
+  // pitch Wp = W + pad columns (zeros); filled by launch_conv
+  int f_wp, f_hwp, f_tiles, f_pieces, f_xbytes, f_p1lo, f_p1hi;
+  float f_rcp;
 };
 
 constexpr int BNP = 128;  // pixels per tile
@@ -211,19 +215,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 // Out-of-image taps / channels >= Cin read a 16-byte zero page instead.  Blocks are remapped so that
 // consecutive logical tiles (and the cout tiles of one pixel tile) run on the same XCD and share its L2.
 __device__ __attribute__((aligned(16))) unsigned char g_zero_page[64];
-#ifdef VIPE_CONV_STAMPS
-// diagnostic build only (scratch/conv_stamps.py): per-workgroup phase stamps {s_memrealtime, s_memtime} x 5
-__device__ unsigned long long* g_stamps = nullptr;
-#define CONV_STAMP(k)                                                                   \
-  do {                                                                                  \
-    if (g_stamps && threadIdx.x == 0) {                                                 \
-      g_stamps[(size_t)blockIdx.x * 12 + 2 * (k)] = __builtin_amdgcn_s_memrealtime();   \
-      g_stamps[(size_t)blockIdx.x * 12 + 2 * (k) + 1] = __builtin_amdgcn_s_memtime();   \
-    }                                                                                   \
-  } while (0)
-#else
-#define CONV_STAMP(k)
-#endif
 
 // 16 bytes per lane, global -> LDS (wave-uniform LDS byte address + lane * 16), as inline asm: hipcc orders every
 // later LDS read behind a visible LDS-DMA with s_waitcnt vmcnt(0), which would serialise load and compute; hidden
@@ -421,11 +412,26 @@ __device__ __forceinline__ int swzf(int row) { return M16 ? ((row >> 2) & 1) << 
 template <bool M16>
 __device__ __forceinline__ int swz32(int row, int c) { return row * 64 + ((c ^ swzf<M16>(row)) << 4); }
 
-constexpr size_t halo32_lds_bytes(int bmc) { return 3 * (size_t)bmc * 64 + 2 * H32_XBYTES + 1024; }
+
+// position q of a flat tile -> pixel index of image e ((e * H + y) * W + x), or -1 for the pad column / beyond the image
+__device__ __forceinline__ int flat_pixel(int q, int e, int H, int W, int wp, int hwp, float rcp) {
+  if (q < 0 || q >= hwp) return -1;
+  int y = (int)(((float)q + 0.5f) * rcp);
+  int x = q - y * wp;
+  if (x < 0) { --y; x += wp; }
+  if (x >= wp) { ++y; x -= wp; }
+  return x < W ? (e * H + y) * W + x : -1;
+}
 
 // VAR: 0 = the general kernel; 1 = initial accumulators held as fp32 (a.ai_f32); 2 = EPI_PARTIAL (raw fp32 accumulators
 // out).  Separate instantiations: folded into the general one as run-time branches they cost it 75 spilled VGPRs.
-template <int BMC, int KS, bool M16, int VAR = 0>
+// FLAT: any H x W.  The image is taken with one zero column appended to every row (pitch Wp = W + 1; a 1x1 needs none)
+// and flattened: position q = y * Wp + x.  A tile is 256 CONSECUTIVE positions of one image, so tap (dy, dx) of every
+// position is the position dy * Wp + dx further on - one shifted window of a single run of 256 + 2 Wp + 2 halo rows in
+// LDS, whatever the image shape (the pad column is the left AND the right zero border).  The reference's resize gives
+// 41 x 73 grids for 16:9 video (vipe/slam/system.py:46-59): 12 tiles of 256 cover the 2993 pixels at 97 %, where 4 x 64
+// tiles would run at 53 %.  Wave wn owns positions 64 wn .. 64 wn + 63; pad positions are computed and not stored.
+template <int BMC, int KS, bool M16, int VAR = 0, bool FLAT = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_halo32_kernel(ConvArgs a, int gy) {
   // M16: v_mfma_f32_16x16x32_f16 (one instruction per 32-channel step and 16 x 16 tile; the chip holds a higher
   // clock on this shape, MI355X_MICROARCH.md 'DVFS give-back' (7)); otherwise 32x32x16.
@@ -433,24 +439,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   constexpr int MI = TM * 2, NJ = TN * 2;  // 16 x 16 tiles per wave (M16)
   constexpr int WSTAGE = BMC * 64;  // bytes per weight ring slot
   extern __shared__ __align__(16) unsigned char lds[];
-  CONV_STAMP(0);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = BMC == 32 ? 0 : (wave >> 2), wn = wave & 3;  // cout half, image row of the tile
   const int pxh = BMC == 32 ? (wave >> 2) * 32 : 0;           // BMC = 32: which half of the row
   const int L = xcd_remap(blockIdx.x, gridDim.x);
   const int tile = L / gy, cout0 = (L % gy) * BMC;
-  const int xsegs = a.W / HALO_TW, tiles_per_img = (a.H / HALO_TH) * xsegs;
+  const int xsegs = a.W / HALO_TW, tiles_per_img = FLAT ? a.f_tiles : (a.H / HALO_TH) * xsegs;
   const int e = tile / tiles_per_img, trem = tile % tiles_per_img;
   const int y0 = (trem / xsegs) * HALO_TH, x0 = (trem % xsegs) * HALO_TW;
-  // pixel index of tile pixel pl (row pl / 64, column pl % 64)
-  auto pix_of = [&](int pl) { return ((int64_t)(e * a.H + y0 + (pl >> 6))) * a.W + x0 + (pl & 63); };
+  const int q0 = trem * BP;                                   // FLAT: first position of the tile
+  const int pitch = FLAT ? a.f_wp : HALO_PITCH;               // halo rows per image row
+  const int xbytes = FLAT ? a.f_xbytes : H32_XBYTES;          // bytes of one halo buffer
+  const int npieces = FLAT ? a.f_pieces : H32_PIECES;
+  // pixel index of tile pixel pl (row pl / 64, column pl % 64; FLAT: position q0 + pl, -1 when it is no pixel)
+  auto pix_of = [&](int pl) -> int64_t {
+    if constexpr (FLAT) return flat_pixel(q0 + pl, e, a.H, a.W, a.f_wp, a.f_hwp, a.f_rcp);
+    else return ((int64_t)(e * a.H + y0 + (pl >> 6))) * a.W + x0 + (pl & 63);
+  };
   const int cs32 = a.Cin_pad / H32_BK, cs64 = a.Cin_pad / 64;
   const int r16 = lane >> 2, sl = lane & 3;
   const int lrow = lane & 31, lhalf = lane >> 5;
 
   const unsigned ldsW_a = lds_address(lds), ldsX_a = ldsW_a + 3 * WSTAGE;
-  const unsigned sink_a = ldsX_a + 2 * H32_XBYTES;  // 1 KiB sink for the count-keeping dummy DMAs
+  const unsigned sink_a = ldsX_a + 2 * xbytes;  // 1 KiB sink for the count-keeping dummy DMAs
   const unsigned char* ldsW = lds;
   const unsigned char* ldsX = lds + 3 * WSTAGE;
   const half_t* zp = reinterpret_cast<const half_t*>(g_zero_page);
@@ -463,31 +475,39 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const unsigned wdst = ldsW_a + (wave % WPIECES) * 1024;
   // halo pieces: one VGPR each (pixel index of this lane's halo row, or -1 outside the image); the lane's channel
   // chunk is the same for every piece because (16 * piece) >> 2 is a multiple of 4
-  int xpix[H32_XP];
+  // FLAT: halo row r holds position q0 - (Wp + 1) + r; its pixel index is recomputed at every issue (4 per wave and
+  // chunk, ~15 VALU each) instead of being kept in registers the K loop has none to spare of
+  int xpix[FLAT ? 1 : H32_XP];
   const int xk = (sl ^ swzf<M16>(r16)) * 8;
+  if constexpr (!FLAT) {
 #pragma unroll
-  for (int i = 0; i < H32_XP; ++i) {
-    const int pce = wave + 8 * i;
-    const int r = pce * 16 + r16;
-    const int hy = r / HALO_PITCH, hx = r % HALO_PITCH;
-    const int y = y0 + hy - 1, x = x0 + hx - 1;
-    const bool ok = pce < H32_PIECES && r < HALO_ROWS && y >= 0 && y < a.H && x >= 0 && x < a.W;
-    xpix[i] = ok ? (e * a.H + y) * a.W + x : -1;
+    for (int i = 0; i < H32_XP; ++i) {
+      const int pce = wave + 8 * i;
+      const int r = pce * 16 + r16;
+      const int hy = r / HALO_PITCH, hx = r % HALO_PITCH;
+      const int y = y0 + hy - 1, x = x0 + hx - 1;
+      const bool ok = pce < H32_PIECES && r < HALO_ROWS && y >= 0 && y < a.H && x >= 0 && x < a.W;
+      xpix[i] = ok ? (e * a.H + y) * a.W + x : -1;
+    }
   }
-  // a 1x1 reads only the tile's own rows: pieces 4..20 hold halo rows 64..335
+  // a 1x1 reads only the tile's own rows: pieces 4..20 hold halo rows 64..335 (FLAT: rows Wp + 1 .. Wp + 256)
   auto piece_used = [&](int i) {
     const int pce = wave + 8 * i;
-    return pce < H32_PIECES && (KS == 3 || (pce >= 4 && pce <= 20));
+    if constexpr (FLAT) return pce < npieces && (KS == 3 || (pce >= a.f_p1lo && pce <= a.f_p1hi));
+    else return pce < H32_PIECES && (KS == 3 || (pce >= 4 && pce <= 20));
   };
   auto issueX = [&](int c, int i, int buf) {
     const int c0 = c * H32_BK;
     const bool s0 = c0 < a.split;  // wave-uniform
     const int ctot = s0 ? a.x0_ctot : a.x1_ctot;
     const int cb = (s0 ? a.x0_coff : a.x1_coff - a.split) + c0;
-    const bool ok = xpix[i] >= 0 && (c0 + xk < a.Cin);
-    const unsigned off = ((unsigned)xpix[i] * (unsigned)ctot + (unsigned)(cb + xk)) * 2u;
+    int xp;
+    if constexpr (FLAT) xp = flat_pixel(q0 - pitch - 1 + (wave + 8 * i) * 16 + r16, e, a.H, a.W, a.f_wp, a.f_hwp, a.f_rcp);
+    else xp = xpix[i];
+    const bool ok = xp >= 0 && (c0 + xk < a.Cin);
+    const unsigned off = ((unsigned)xp * (unsigned)ctot + (unsigned)(cb + xk)) * 2u;
     const char* src = reinterpret_cast<const char*>(s0 ? a.x0 : a.x1) + off;
-    glds16(ok ? (const void*)src : (const void*)zp, ldsX_a + buf * H32_XBYTES + (wave + 8 * i) * 1024);
+    glds16(ok ? (const void*)src : (const void*)zp, ldsX_a + buf * xbytes + (wave + 8 * i) * 1024);
   };
   // weights of K-step (tap, c): the 64-byte half (c & 1) of rows cout0.. of packed block tap * cs64 + c / 2
   auto wsrc = [&](int tap, int c) {
@@ -512,6 +532,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const int64_t m = pix_of(wn * 64 + j * 16 + (lane & 15));
+          if (FLAT && m < 0) continue;
 #pragma unroll
           for (int i = 0; i < MI; ++i) {
             const int cg = cout0 + wm * (MI * 16) + i * 16 + 4 * (lane >> 4);
@@ -542,27 +563,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int wa0 = M16 ? swz32<true>(wm * MI * 16 + l16, lk) : swz32<false>(wm * TM * 32 + lrow, lhalf);
   // Rl = this lane's halo row of the (-1, -1) window; the caller passes it through an empty asm once per chunk so
   // that the nine per-tap addresses are recomputed (5 VALU each) instead of being hoisted into 9+ VGPRs (spills)
-  const int Rl0 = wn * HALO_PITCH + pxh + (M16 ? l16 : lrow);
+  const int Rl0 = (FLAT ? wn * HALO_TW : wn * HALO_PITCH) + pxh + (M16 ? l16 : lrow);
   auto mma_step = [&](const unsigned char* bw, const unsigned char* bx, int Rl, int dy, int dx) {
-    const int rb = Rl + (dy + 1) * HALO_PITCH + (dx + 1);
+    const int rb = Rl + (dy + 1) * pitch + (dx + 1);
     if constexpr (M16) {
       const int xa0 = swz32<true>(rb, lk);
       half8 wf[MI];
-#ifdef VIPE_ABL_NOLDS  // ablation builds (scratch/build_abl.sh): constant fragments instead of LDS reads
-      (void)xa0;
-#pragma unroll
-      for (int i = 0; i < MI; ++i) wf[i] = half8{(half_t)1, (half_t)2, (half_t)3, (half_t)4, (half_t)1, (half_t)2, (half_t)3, (half_t)4};
-#else
 #pragma unroll
       for (int i = 0; i < MI; ++i) wf[i] = *reinterpret_cast<const half8*>(bw + (wa0 + i * 1024));
-#endif
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-#ifdef VIPE_ABL_NOLDS
-        const half8 xf = half8{(half_t)0.5f, (half_t)0.25f, (half_t)0.5f, (half_t)0.25f, (half_t)0.5f, (half_t)0.25f, (half_t)0.5f, (half_t)0.25f};
-#else
         const half8 xf = *reinterpret_cast<const half8*>(bx + (xa0 + j * 1024));
-#endif
 #pragma unroll
         for (int i = 0; i < MI; ++i)
           acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf, acc16[i][j], 0, 0, 0);
@@ -594,7 +605,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   if constexpr (KS == 3) issueW(wsrc(1, 0), 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  CONV_STAMP(1);
 
   if constexpr (KS == 3) {
     // 9 taps fully unrolled: ring slot = tap % 3, tap offsets and the per-tap s_waitcnt count are compile-time.
@@ -602,18 +612,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // count when there is nothing to fetch).  At the end of tap t the DMAs younger than W(step + 1) are
     // {X_t (t < 4), W(step + 2), X_{t-1} (1 <= t <= 4)}: vmcnt(2,3,3,3,2,1,1,1,1).  A halo piece issued at tap t <= 3 has
     // landed by the end of tap 5, before the chunk ends.
-#ifdef VIPE_CONV_STAMPS
-    unsigned long long stamp_vm = 0, stamp_bar = 0;
-#endif
     for (int c = 0; c < cs32; ++c) {
-      const unsigned char* bx = ldsX + (c & 1) * H32_XBYTES;
+      const unsigned char* bx = ldsX + (c & 1) * xbytes;
       const bool more = c + 1 < cs32;
       int Rl = Rl0;
       asm volatile("" : "+v"(Rl));
       auto tap_step = [&](auto TAPC) {
         constexpr int TAP = decltype(TAPC)::value;
         constexpr int T2 = TAP + 2;
-#ifndef VIPE_ABL_NODMA  // ablation: no LDS-DMA in the K loop (operands stay those of the prologue)
         if constexpr (T2 < 9) {
           issueW(wsrc(T2, c), T2 % 3);
         } else {
@@ -624,32 +630,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           if (more && piece_used(TAP)) issueX(c + 1, TAP, (c + 1) & 1);
           else glds16(zp, sink_a);
         }
-#endif
         mma_step(ldsW + (TAP % 3) * WSTAGE, bx, Rl, TAP / 3 - 1, TAP % 3 - 1);
-#ifdef VIPE_CONV_STAMPS  // diagnostic build: wave 0's time at the DMA wait and at the barrier of every tap
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned long long ts_a = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-#ifndef VIPE_ABL_NODMA
         if constexpr (TAP == 0 || TAP == 4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else if constexpr (TAP < 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-#endif
-#ifdef VIPE_CONV_STAMPS
-        const unsigned long long ts_b = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-#ifndef VIPE_ABL_NOBAR  // ablation: no per-tap barrier
         __syncthreads();
-#endif
-#ifdef VIPE_CONV_STAMPS
-        const unsigned long long ts_c = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        stamp_vm += ts_b - ts_a;
-        stamp_bar += ts_c - ts_b;
-        __builtin_amdgcn_sched_barrier(0);
-#endif
       };
       tap_step(std::integral_constant<int, 0>{});
       tap_step(std::integral_constant<int, 1>{});
@@ -661,15 +646,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       tap_step(std::integral_constant<int, 7>{});
       tap_step(std::integral_constant<int, 8>{});
     }
-#ifdef VIPE_CONV_STAMPS
-    if (g_stamps && threadIdx.x == 0) {
-      g_stamps[(size_t)blockIdx.x * 12 + 10] = stamp_vm;
-      g_stamps[(size_t)blockIdx.x * 12 + 11] = stamp_bar;
-    }
-#endif
   } else {
     for (int c = 0; c < cs32; ++c) {
-      const unsigned char* bx = ldsX + (c & 1) * H32_XBYTES;
+      const unsigned char* bx = ldsX + (c & 1) * xbytes;
       if (c + 1 < cs32) {
         issueW(wsrc(0, c + 1), (c + 1) & 1);
 #pragma unroll
@@ -683,7 +662,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  CONV_STAMP(2);
 
   // ---- epilogue
   constexpr int CPP = BMC / 8;  // 8-channel chunks per pixel
@@ -697,6 +675,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const int64_t m = pix_of(wn * 64 + j * 16 + l16);
+          if (FLAT && m < 0) continue;
 #pragma unroll
           for (int i = 0; i < MI; ++i) {
             const int cg = cout0 + wm * (MI * 16) + i * 16 + 4 * lk;
@@ -766,17 +745,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int64_t m = pix_of(pl0 + PSTEP * it);
+        if (FLAT && m < 0) continue;  // no pixel here: the store loop skips this position as well
         if (want_net) nvv[it] = *reinterpret_cast<const half8*>(a.net + m * a.net_ctot + a.net_coff + cn);
         if (want_z) zvv[it] = *reinterpret_cast<const half8*>(a.zbuf + m * 128 + co);
       }
     }
     __syncthreads();
-    CONV_STAMP(3);
     float gsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int pl = pl0 + PSTEP * it;
       const int64_t m = pix_of(pl);
+      if (FLAT && m < 0) continue;
       const half8 sv = *reinterpret_cast<const half8*>(stage + pl * PITCH + ch);
       half8 o = sv;
       half_t* dst = nullptr;
@@ -843,7 +823,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       }
     }
     __syncthreads();
-    CONV_STAMP(3);
     float bv[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -854,6 +833,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int it = 0; it < NIT; ++it) {
       const int pl = pl0 + PSTEP * it;
       const int64_t m = pix_of(pl);
+      if (FLAT && m < 0) continue;
       const float4 v0 = *reinterpret_cast<const float4*>(stage + pl * PITCH + ch);
       const float4 v1 = *reinterpret_cast<const float4*>(stage + pl * PITCH + ch + 4);
       const float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3],
@@ -882,7 +862,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       }
     }
   }
-  CONV_STAMP(4);
 }
 
 // ---- 3x3 with at most 16 output channels (flow / confidence heads: 4, eta: 1).  One 16x16x32 A fragment covers all
@@ -890,20 +869,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // (measured 221 us for 15.6 GFLOP).  Here a step is a whole 32-channel chunk: the 9 taps' weights (9 x 1 KiB) and
 // the halo chunk are double buffered, one barrier per chunk, 18 MFMAs per wave between barriers.
 constexpr int NRW_WBYTES = 9 * 1024;
-constexpr size_t NRW_LDS = 2 * NRW_WBYTES + 2 * H32_XBYTES + 1024;
 
+template <bool FLAT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_halo32_narrow_kernel(ConvArgs a) {
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 3, pxh = (wave >> 2) * 32;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int xsegs = a.W / HALO_TW, tiles_per_img = (a.H / HALO_TH) * xsegs;
+  const int xsegs = a.W / HALO_TW, tiles_per_img = FLAT ? a.f_tiles : (a.H / HALO_TH) * xsegs;
   const int e = tile / tiles_per_img, trem = tile % tiles_per_img;
   const int y0 = (trem / xsegs) * HALO_TH, x0 = (trem % xsegs) * HALO_TW;
-  auto pix_of = [&](int pl) { return ((int64_t)(e * a.H + y0 + (pl >> 6))) * a.W + x0 + (pl & 63); };
+  const int q0 = trem * (HALO_TH * HALO_TW);  // FLAT tiling (see conv_halo32_kernel): first position of the tile
+  const int pitch = FLAT ? a.f_wp : HALO_PITCH, xbytes = FLAT ? a.f_xbytes : H32_XBYTES;
+  const int npieces = FLAT ? a.f_pieces : H32_PIECES;
+  auto pix_of = [&](int pl) -> int64_t {
+    if constexpr (FLAT) return flat_pixel(q0 + pl, e, a.H, a.W, a.f_wp, a.f_hwp, a.f_rcp);
+    else return ((int64_t)(e * a.H + y0 + (pl >> 6))) * a.W + x0 + (pl & 63);
+  };
   const int cs32 = a.Cin_pad / H32_BK, cs64 = a.Cin_pad / 64;
   const int r16 = lane >> 2, sl = lane & 3, l16 = lane & 15, lk = lane >> 4;
-  const unsigned ldsW_a = lds_address(lds), ldsX_a = ldsW_a + 2 * NRW_WBYTES, sink_a = ldsX_a + 2 * H32_XBYTES;
+  const unsigned ldsW_a = lds_address(lds), ldsX_a = ldsW_a + 2 * NRW_WBYTES;
   const unsigned char* ldsW = lds;
   const unsigned char* ldsX = lds + 2 * NRW_WBYTES;
   const half_t* zp = reinterpret_cast<const half_t*>(g_zero_page);
@@ -914,10 +899,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   for (int i = 0; i < H32_XP; ++i) {
     const int pce = wave + 8 * i;
     const int r = pce * 16 + r16;
-    const int hy = r / HALO_PITCH, hx = r % HALO_PITCH;
-    const int y = y0 + hy - 1, x = x0 + hx - 1;
-    const bool ok = pce < H32_PIECES && r < HALO_ROWS && y >= 0 && y < a.H && x >= 0 && x < a.W;
-    xpix[i] = ok ? (e * a.H + y) * a.W + x : -1;
+    if constexpr (FLAT) {
+      xpix[i] = pce < npieces ? flat_pixel(q0 - pitch - 1 + r, e, a.H, a.W, a.f_wp, a.f_hwp, a.f_rcp) : -1;
+    } else {
+      const int hy = r / HALO_PITCH, hx = r % HALO_PITCH;
+      const int y = y0 + hy - 1, x = x0 + hx - 1;
+      const bool ok = pce < H32_PIECES && r < HALO_ROWS && y >= 0 && y < a.H && x >= 0 && x < a.W;
+      xpix[i] = ok ? (e * a.H + y) * a.W + x : -1;
+    }
   }
   auto issue = [&](int c, int buf) {
     const int c0 = c * H32_BK;
@@ -926,11 +915,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int cb = (s0 ? a.x0_coff : a.x1_coff - a.split) + c0;
 #pragma unroll
     for (int i = 0; i < H32_XP; ++i) {
-      if (wave + 8 * i < H32_PIECES) {
+      if (wave + 8 * i < npieces) {
         const bool ok = xpix[i] >= 0 && (c0 + xk < a.Cin);
         const unsigned off = ((unsigned)xpix[i] * (unsigned)ctot + (unsigned)(cb + xk)) * 2u;
         const char* src = reinterpret_cast<const char*>(s0 ? a.x0 : a.x1) + off;
-        glds16(ok ? (const void*)src : (const void*)zp, ldsX_a + buf * H32_XBYTES + (wave + 8 * i) * 1024);
+        glds16(ok ? (const void*)src : (const void*)zp, ldsX_a + buf * xbytes + (wave + 8 * i) * 1024);
       }
     }
     // weights: tap `wave` (and tap 8 on wave 0): rows 0..15 of packed block tap * cs64 + c / 2, 64-byte half c & 1
@@ -945,17 +934,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
   float4v acc[2] = {float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}};
   const int wa0 = swz32<true>(l16, lk);
-  const int Rl0 = wn * HALO_PITCH + pxh + l16;
+  const int Rl0 = (FLAT ? wn * HALO_TW : wn * HALO_PITCH) + pxh + l16;
   issue(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int c = 0; c < cs32; ++c) {
     if (c + 1 < cs32) issue(c + 1, (c + 1) & 1);
     const unsigned char* bw = ldsW + (c & 1) * NRW_WBYTES;
-    const unsigned char* bx = ldsX + (c & 1) * H32_XBYTES;
+    const unsigned char* bx = ldsX + (c & 1) * xbytes;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int rb = Rl0 + (tap / 3) * HALO_PITCH + (tap % 3);
+      const int rb = Rl0 + (tap / 3) * pitch + (tap % 3);
       const int xa0 = swz32<true>(rb, lk);
       const half8 wf = *reinterpret_cast<const half8*>(bw + (wa0 + tap * 1024));
 #pragma unroll
@@ -975,8 +964,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     *reinterpret_cast<float4*>(stage + (wn * 64 + pxh + j * 16 + l16) * PITCH + 4 * lk) =
         make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
   __syncthreads();
-  if (tid < HALO_TH * HALO_TW) {
-    const int64_t m = pix_of(tid);
+  const int64_t m = tid < HALO_TH * HALO_TW ? pix_of(tid) : -1;
+  if (tid < HALO_TH * HALO_TW && (!FLAT || m >= 0)) {
     float v[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1018,15 +1007,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int l16 = lane & 15, kg = lane >> 4;
   const int wq = wave & 3, wp = wave >> 2;  // cout quarter (32 couts), pixel half (128 px)
   const int HW = a.H * a.W;
-  const int64_t pix0 = (int64_t)blockIdx.x * 256;  // tiles never straddle images: HW % 256 == 0
-  const int e = (int)(pix0 / HW);
+  const int tpi = (HW + 255) / 256;  // tiles per image: a tile never straddles images, the last one may be short
+  const int e = blockIdx.x / tpi, p0 = (blockIdx.x % tpi) * 256;
+  const int64_t pix0 = (int64_t)e * HW + p0;
   if (tid < 128) gacc[tid] = 0.0f;
-  // tile -> LDS (16 B per lane, 256 contiguous bytes per pixel)
+  // tile -> LDS (16 B per lane, 256 contiguous bytes per pixel); rows past the image are zero: sigmoid(.) * 0 adds nothing
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int i = tid + 512 * it, px = i >> 4, ck = i & 15;
-    *reinterpret_cast<half8*>(xt + px * GLO_PITCH + ck * 8) =
-        *reinterpret_cast<const half8*>(a.x0 + (pix0 + px) * a.x0_ctot + a.x0_coff + ck * 8);
+    half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (p0 + px < HW) v = *reinterpret_cast<const half8*>(a.x0 + (pix0 + px) * a.x0_ctot + a.x0_coff + ck * 8);
+    *reinterpret_cast<half8*>(xt + px * GLO_PITCH + ck * 8) = v;
   }
   // weights of this wave: couts 32 wq + 16 i + l16, k = 32 s + 8 kg (packed [k / 64][Cout_pad][64])
   half8 af[2][4];
@@ -1087,16 +1078,23 @@ constexpr int C7_WBYTES = 4 * 128 * 128;                    // 65536
 constexpr int C7_XBYTES = ((C7_PW * C7_ROWS * 8 + 15) / 16) * 16;
 constexpr int C7_LDS = (C7_WBYTES + C7_XBYTES) > (256 * 136 * 2) ? (C7_WBYTES + C7_XBYTES) : (256 * 136 * 2);
 
+// FLAT: the flat tiling of conv_halo32_kernel with THREE pad columns (pitch Wp = W + 3): tap (ty, tx) of position q is
+// position q + (ty - 3) Wp + (tx - 3) of one run of 256 + 6 Wp + 6 halo pixels.
+template <bool FLAT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv7x7_c4_kernel(ConvArgs a, int gy) {
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int L = xcd_remap(blockIdx.x, gridDim.x);
   const int tile = L / gy, cout0 = (L % gy) * 128;
-  const int xsegs = a.W / HALO_TW, tiles_per_img = (a.H / HALO_TH) * xsegs;
+  const int xsegs = a.W / HALO_TW, tiles_per_img = FLAT ? a.f_tiles : (a.H / HALO_TH) * xsegs;
   const int e = tile / tiles_per_img, trem = tile % tiles_per_img;
   const int y0 = (trem / xsegs) * HALO_TH, x0 = (trem % xsegs) * HALO_TW;
-  auto pix_of = [&](int pl) { return ((int64_t)(e * a.H + y0 + (pl >> 6))) * a.W + x0 + (pl & 63); };
+  const int q0 = trem * (HALO_TH * HALO_TW), pitch = FLAT ? a.f_wp : C7_PW;
+  auto pix_of = [&](int pl) -> int64_t {
+    if constexpr (FLAT) return flat_pixel(q0 + pl, e, a.H, a.W, a.f_wp, a.f_hwp, a.f_rcp);
+    else return ((int64_t)(e * a.H + y0 + (pl >> 6))) * a.W + x0 + (pl & 63);
+  };
   const int l16 = lane & 15, lk = lane >> 4;
   const unsigned ldsW_a = lds_address(lds);
   unsigned char* ldsX = lds + C7_WBYTES;
@@ -1113,13 +1111,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
   }
   // halo pixels (zero outside the image)
-  for (int i = tid; i < C7_PW * C7_ROWS; i += 512) {
-    const int hy = i / C7_PW, hx = i % C7_PW;
-    const int y = y0 + hy - 3, x = x0 + hx - 3;
-    uint2 v = make_uint2(0u, 0u);
-    if (y >= 0 && y < a.H && x >= 0 && x < a.W)
-      v = *reinterpret_cast<const uint2*>(a.x0 + ((int64_t)(e * a.H + y) * a.W + x) * a.x0_ctot + a.x0_coff);
-    *reinterpret_cast<uint2*>(ldsX + i * 8) = v;
+  if constexpr (FLAT) {
+    const int nh = HALO_TH * HALO_TW + 6 * pitch + 6;
+    for (int i = tid; i < nh; i += 512) {
+      const int m = flat_pixel(q0 - 3 * pitch - 3 + i, e, a.H, a.W, a.f_wp, a.f_hwp, a.f_rcp);
+      uint2 v = make_uint2(0u, 0u);
+      if (m >= 0) v = *reinterpret_cast<const uint2*>(a.x0 + (int64_t)m * a.x0_ctot + a.x0_coff);
+      *reinterpret_cast<uint2*>(ldsX + i * 8) = v;
+    }
+  } else {
+    for (int i = tid; i < C7_PW * C7_ROWS; i += 512) {
+      const int hy = i / C7_PW, hx = i % C7_PW;
+      const int y = y0 + hy - 3, x = x0 + hx - 3;
+      uint2 v = make_uint2(0u, 0u);
+      if (y >= 0 && y < a.H && x >= 0 && x < a.W)
+        v = *reinterpret_cast<const uint2*>(a.x0 + ((int64_t)(e * a.H + y) * a.W + x) * a.x0_ctot + a.x0_coff);
+      *reinterpret_cast<uint2*>(ldsX + i * 8) = v;
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -1138,7 +1146,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       wf[i] = *reinterpret_cast<const half8*>(lds + (st >> 1) * 16384 + swz(wm * 64 + i * 16 + l16, (st & 1) * 4 + lk));
     // this lane's two taps (k = 8 lk .. 8 lk + 7 of the step); taps >= 49 carry zero weights: read tap 48 (finite)
     const int t0 = min(st * 8 + lk * 2, 48), t1 = min(st * 8 + lk * 2 + 1, 48);
-    const int o0 = ((wn + t0 / 7) * C7_PW + l16 + t0 % 7) * 8, o1 = ((wn + t1 / 7) * C7_PW + l16 + t1 % 7) * 8;
+    const int wrow = FLAT ? wn * HALO_TW : wn * C7_PW;  // halo index of this wave's first pixel under tap (0, 0)
+    const int o0 = (wrow + (t0 / 7) * pitch + l16 + t0 % 7) * 8, o1 = (wrow + (t1 / 7) * pitch + l16 + t1 % 7) * 8;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const half4v lo = *reinterpret_cast<const half4v*>(ldsX + o0 + j * 128);
@@ -1171,8 +1180,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int pl = (tid >> 4) + 32 * it;
+    const int64_t m = pix_of(pl);
+    if (FLAT && m < 0) continue;
     const half8 o = *reinterpret_cast<const half8*>(stage + pl * PITCH + ch);
-    half_t* dst = a.y + pix_of(pl) * a.y_ctot + a.y_coff + co;
+    half_t* dst = a.y + m * a.y_ctot + a.y_coff + co;
     if (co + 8 <= a.Cout) {
       *reinterpret_cast<half8*>(dst) = o;
     } else {
@@ -1210,13 +1221,6 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 extern "C" {
 
-#ifdef VIPE_CONV_STAMPS
-VIPE_EXPORT int vipe_diag_set_conv_stamps(void* d_buf) {
-  unsigned long long* p = (unsigned long long*)d_buf;
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p));
-}
-#endif
-
 // Geometry helpers shared with the Python side: padded sizes of the packed weight tensor.
 VIPE_EXPORT int vipe_conv_packed_dims(int Cout, int Cin, int KH, int KW, int* cout_pad, int* cin_pad, int* k_pad) {
   if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return VIPE_EINVAL;
@@ -1247,6 +1251,78 @@ VIPE_EXPORT int vipe_conv_pack_weights(const void* d_w_oihw, void* d_w_packed, i
 
 namespace {
 
+// one hipFuncSetAttribute per (kernel, device): the dynamic-LDS ceiling of every kernel that may ask for > 64 KiB
+template <typename K>
+void allow_lds(K kernel, std::atomic<uint64_t>& seen, size_t bytes) {
+  if (vipe_first_on_device(seen)) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+constexpr size_t MAX_LDS = 160 * 1024;
+
+// flat tiling of an H x W image with `pad` zero columns per row (see conv_halo32_kernel): fills a.f_*; false when a
+// halo buffer would not fit the kernel's four 1-KiB pieces per wave
+bool flat_geometry(ConvArgs& a, int pad, bool is1x1) {
+  a.f_wp = a.W + pad;
+  a.f_hwp = a.H * a.f_wp;
+  a.f_tiles = (a.f_hwp + 255) / 256;
+  a.f_rcp = 1.0f / (float)a.f_wp;
+  const int rows = 256 + 2 * a.f_wp + 2;
+  a.f_pieces = (rows + 15) / 16;
+  a.f_xbytes = a.f_pieces * 1024;
+  a.f_p1lo = (a.f_wp + 1) / 16;
+  a.f_p1hi = (a.f_wp + 256) / 16;
+  (void)is1x1;
+  return a.f_pieces <= 8 * H32_XP && a.f_hwp < (1 << 23);
+}
+
+template <int BMC, int KS, int VAR, bool FLAT>
+int launch_halo32(const ConvArgs& a, int tiles, int gy, size_t lds, hipStream_t s) {
+  static std::atomic<uint64_t> seen{0};
+  allow_lds(conv_halo32_kernel<BMC, KS, true, VAR, FLAT>, seen, FLAT ? MAX_LDS : lds);
+  conv_halo32_kernel<BMC, KS, true, VAR, FLAT><<<dim3(tiles * gy), 512, lds, s>>>(a, gy);
+  return vipe_launch_status();
+}
+
+template <bool FLAT>
+int launch_halo_family(ConvArgs& a, int cp, int64_t M, hipStream_t s) {
+  const bool split_ok = a.split >= a.Cin || a.split % H32_BK == 0;
+  const int tiles = FLAT ? a.B * a.f_tiles : (int)(M / (HALO_TH * HALO_TW));
+  const size_t xb = FLAT ? (size_t)a.f_xbytes : (size_t)H32_XBYTES;
+  if (a.accinit || a.epi == EPI_PARTIAL || a.ai_f32) {
+    // initial accumulators / raw partial sums: the 16x16x32 halo kernel with >= 64 output channels (fp32 initial
+    // accumulators and partial sums: 3x3, >= 128 output channels)
+    const bool ok = cp >= 64 && split_ok && !(a.KH == 3 && a.Cout <= 16) && !(a.epi == EPI_PARTIAL && a.Cout % 4 != 0) &&
+                    !(a.ai_f32 && !a.accinit);
+    if (!ok) return VIPE_EUNSUPPORTED;
+  }
+  if (a.KH == 3 && a.Cout <= 16 && cp == 32 && split_ok && (a.epi == EPI_HEADS || a.epi == EPI_ETA || a.epi == EPI_PLAIN)) {
+    static std::atomic<uint64_t> seen{0};
+    const size_t lds = 2 * NRW_WBYTES + 2 * xb + 1024;
+    allow_lds(conv_halo32_narrow_kernel<FLAT>, seen, FLAT ? MAX_LDS : lds);
+    conv_halo32_narrow_kernel<FLAT><<<dim3(tiles), 512, lds, s>>>(a);
+    return vipe_launch_status();
+  }
+  if (!split_ok) return VIPE_EUNSUPPORTED;
+  const int bmc = cp >= 128 ? 128 : cp;
+  const int gy = cp >= 128 ? cp / 128 : 1;
+  // K-loop buffers (weight ring + two halo buffers + DMA sink) or the epilogue's staged tile, whichever is larger
+  size_t lds = 3 * (size_t)bmc * 64 + 2 * xb + 1024;
+  const size_t stage = bmc >= 64 ? (size_t)256 * (bmc + 8) * 2 : (size_t)256 * 36 * 4;
+  if (lds < stage) lds = stage;
+  if (a.ai_f32 || a.epi == EPI_PARTIAL) {
+    // the two variants of the staged z|r gates (vipe_update_gate_state): 3x3, >= 128 output channels
+    if (!(a.KH == 3 && bmc == 128 && !(a.ai_f32 && a.epi == EPI_PARTIAL))) return VIPE_EUNSUPPORTED;
+    return a.ai_f32 ? launch_halo32<128, 3, 1, FLAT>(a, tiles, gy, lds, s) : launch_halo32<128, 3, 2, FLAT>(a, tiles, gy, lds, s);
+  }
+  if (a.KH == 3) {
+    if (bmc == 128) return launch_halo32<128, 3, 0, FLAT>(a, tiles, gy, lds, s);
+    if (bmc == 64) return launch_halo32<64, 3, 0, FLAT>(a, tiles, 1, lds, s);
+    return launch_halo32<32, 3, 0, FLAT>(a, tiles, 1, lds, s);
+  }
+  if (bmc == 128) return launch_halo32<128, 1, 0, FLAT>(a, tiles, gy, lds, s);
+  if (bmc == 64) return launch_halo32<64, 1, 0, FLAT>(a, tiles, 1, lds, s);
+  return launch_halo32<32, 1, 0, FLAT>(a, tiles, 1, lds, s);
+}
+
 int launch_conv(ConvArgs& a, hipStream_t s) {
   int cp, cinp, kp;
   if (vipe_conv_packed_dims(a.Cout, a.Cin, a.KH, a.KW, &cp, &cinp, &kp) != VIPE_OK) return VIPE_EINVAL;
@@ -1257,100 +1333,55 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
   if (M == 0) return VIPE_OK;
   const bool small = a.Cin == 4;
   const int gx = (int)((M + BNP - 1) / BNP);
-  static std::atomic<uint64_t> attr{0};  // bit d: set on device d
-  if (vipe_first_on_device(attr)) {
-    (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<128, 2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<128, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)conv_mfma_glds_kernel<128, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-  }
-  const bool glds = !small && a.KH * a.KW <= 32 && getenv("VIPE_AMD_CONV_REGSTAGE") == nullptr;
-  const bool halo = glds && a.W % HALO_TW == 0 && a.H % HALO_TH == 0 && a.KH == a.KW && (a.KH == 1 || a.KH == 3) &&
-                    (int64_t)a.B * a.H * a.W * (a.x0_ctot > a.x1_ctot ? a.x0_ctot : a.x1_ctot) * 2 < (1ll << 32) &&
-                    getenv("VIPE_AMD_CONV_NOHALO") == nullptr;
-  if (a.accinit || a.epi == EPI_PARTIAL || a.ai_f32) {
-    // initial accumulators / raw partial sums are implemented by the 32-channel halo kernel (16x16x32 fragments) with
-    // >= 64 output channels only (fp32 initial accumulators and partial sums: 3x3, >= 128 output channels)
-    const bool ok = halo && cp >= 64 && (a.split >= a.Cin || a.split % H32_BK == 0) && !(a.KH == 3 && a.Cout <= 16) &&
-                    !(a.epi == EPI_PARTIAL && a.Cout % 4 != 0) && !(a.ai_f32 && !a.accinit);
-    if (!ok) return VIPE_EUNSUPPORTED;
-  }
+  // kernel families.  Tile kernels (halo in LDS once per 32-channel chunk): the 4 x 64 tiling when the image is made of
+  // such tiles, the FLAT tiling (256 consecutive positions of the row-padded image) for every other shape up to
+  // W = 126; wider ragged images take the per-tap gather kernel.
+  const bool sq13 = !small && a.KH == a.KW && (a.KH == 1 || a.KH == 3);
+  const bool off32 = (int64_t)a.B * a.H * a.W * (a.x0_ctot > a.x1_ctot ? a.x0_ctot : a.x1_ctot) * 2 < (1ll << 32);
+  const bool aligned = a.W % HALO_TW == 0 && a.H % HALO_TH == 0;
+  const bool halo = sq13 && aligned && off32;
+  const bool flat = sq13 && !aligned && off32 && flat_geometry(a, a.KH == 3 ? 1 : 0, a.KH == 1);
+  if ((a.accinit || a.epi == EPI_PARTIAL || a.ai_f32) && !halo && !flat) return VIPE_EUNSUPPORTED;
   if (a.epi == EPI_GLO && a.KH == 1 && a.KW == 1 && a.Cin == 128 && a.Cout == 128 && cp == 128 && a.split >= a.Cin &&
-      (a.H * a.W) % 256 == 0 && a.x0_ctot % 8 == 0 && a.x0_coff % 8 == 0 && a.net == a.x0 && a.net_ctot == a.x0_ctot &&
-      a.net_coff == a.x0_coff && a.extra == nullptr && getenv("VIPE_AMD_CONV_NOGLO") == nullptr) {
-    static std::atomic<uint64_t> gattr{0};  // bit d: set on device d
-    if (vipe_first_on_device(gattr)) {
-      (void)hipFuncSetAttribute((const void*)conv1x1_glo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GLO_LDS);
-    }
-    conv1x1_glo_kernel<<<dim3((unsigned)(M / 256)), 512, GLO_LDS, s>>>(a);
+      a.x0_ctot % 8 == 0 && a.x0_coff % 8 == 0 && a.net == a.x0 && a.net_ctot == a.x0_ctot && a.net_coff == a.x0_coff &&
+      a.extra == nullptr) {
+    static std::atomic<uint64_t> seen{0};
+    allow_lds(conv1x1_glo_kernel, seen, GLO_LDS);
+    conv1x1_glo_kernel<<<dim3((unsigned)(a.B * ((a.H * a.W + 255) / 256))), 512, GLO_LDS, s>>>(a);
     return vipe_launch_status();
   }
-  if (halo && a.KH == 3 && a.Cout <= 16 && cp == 32 && (a.split >= a.Cin || a.split % H32_BK == 0) &&
-      (a.epi == EPI_HEADS || a.epi == EPI_ETA || a.epi == EPI_PLAIN) && getenv("VIPE_AMD_CONV_NONARROW") == nullptr) {
-    static std::atomic<uint64_t> nattr{0};  // bit d: set on device d
-    if (vipe_first_on_device(nattr)) {
-      (void)hipFuncSetAttribute((const void*)conv_halo32_narrow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NRW_LDS);
-    }
-    conv_halo32_narrow_kernel<<<dim3((int)(M / (HALO_TH * HALO_TW))), 512, NRW_LDS, s>>>(a);
-    return vipe_launch_status();
+  if (halo) {
+    const int rc = launch_halo_family<false>(a, cp, M, s);
+    if (rc != VIPE_EUNSUPPORTED || a.accinit || a.epi == EPI_PARTIAL || a.ai_f32) return rc;
+  } else if (flat) {
+    const int rc = launch_halo_family<true>(a, cp, M, s);
+    if (rc != VIPE_EUNSUPPORTED || a.accinit || a.epi == EPI_PARTIAL || a.ai_f32) return rc;
   }
-  if (halo && (a.split >= a.Cin || a.split % H32_BK == 0)) {
-    static std::atomic<uint64_t> h32attr{0};  // bit d: set on device d
-    const int bmc = cp >= 128 ? 128 : cp;
-    if (vipe_first_on_device(h32attr)) {
-      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<128, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(128));
-      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<64, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(64));
-      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<32, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(32));
-      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<128, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(128));
-      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<64, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(64));
-      (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<32, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(32));
-    }
-    const int gy = cp >= 128 ? cp / 128 : 1;
-    const int tiles = (int)(M / (HALO_TH * HALO_TW));
-    const dim3 grid(tiles * gy);
-    const size_t lds = halo32_lds_bytes(bmc);
-    static const bool m32 = getenv("VIPE_AMD_CONV_MFMA32") != nullptr;  // A/B: 32x32x16 fragments
-    if (m32) {
-      static std::atomic<uint64_t> a32{0};  // bit d: set on device d
-      if (vipe_first_on_device(a32)) {
-        (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<128, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(128));
-        (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<128, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(128));
-      }
-    }
-    if (a.ai_f32 || a.epi == EPI_PARTIAL) {
-      // the two variants of the staged z|r gates (vipe_update_gate_state): 3x3, >= 128 output channels
-      if (!(a.KH == 3 && bmc == 128 && !m32 && !(a.ai_f32 && a.epi == EPI_PARTIAL))) return VIPE_EUNSUPPORTED;
-      static std::atomic<uint64_t> av{0};  // bit d: set on device d
-      if (vipe_first_on_device(av)) {
-        (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<128, 3, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(128));
-        (void)hipFuncSetAttribute((const void*)conv_halo32_kernel<128, 3, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)halo32_lds_bytes(128));
-      }
-      if (a.ai_f32) conv_halo32_kernel<128, 3, true, 1><<<grid, 512, lds, s>>>(a, gy);
-      else conv_halo32_kernel<128, 3, true, 2><<<grid, 512, lds, s>>>(a, gy);
+  if (small && a.KH == 7 && a.KW == 7 && cp % 128 == 0 && kp == 256 && a.epi == EPI_PLAIN && a.extra == nullptr &&
+      (int64_t)a.B * a.H * a.W * a.x0_ctot * 2 < (1ll << 32)) {
+    const int gy = cp / 128;
+    if (aligned) {
+      static std::atomic<uint64_t> seen{0};
+      allow_lds(conv7x7_c4_kernel<false>, seen, C7_LDS);
+      conv7x7_c4_kernel<false><<<dim3((int)(M / (HALO_TH * HALO_TW)) * gy), 512, C7_LDS, s>>>(a, gy);
       return vipe_launch_status();
     }
-    if (a.KH == 3) {
-      if (bmc == 128 && m32) conv_halo32_kernel<128, 3, false><<<grid, 512, lds, s>>>(a, gy);
-      else if (bmc == 128) conv_halo32_kernel<128, 3, true><<<grid, 512, lds, s>>>(a, gy);
-      else if (bmc == 64) conv_halo32_kernel<64, 3, true><<<grid, 512, lds, s>>>(a, 1);
-      else conv_halo32_kernel<32, 3, true><<<grid, 512, lds, s>>>(a, 1);
-    } else {
-      if (bmc == 128 && m32) conv_halo32_kernel<128, 1, false><<<grid, 512, lds, s>>>(a, gy);
-      else if (bmc == 128) conv_halo32_kernel<128, 1, true><<<grid, 512, lds, s>>>(a, gy);
-      else if (bmc == 64) conv_halo32_kernel<64, 1, true><<<grid, 512, lds, s>>>(a, 1);
-      else conv_halo32_kernel<32, 1, true><<<grid, 512, lds, s>>>(a, 1);
+    flat_geometry(a, 3, false);
+    const size_t need = C7_WBYTES + (size_t)(256 + 6 * a.f_wp + 6) * 8;
+    if (need <= MAX_LDS && a.f_hwp < (1 << 23)) {
+      static std::atomic<uint64_t> seen{0};
+      allow_lds(conv7x7_c4_kernel<true>, seen, MAX_LDS);
+      const size_t lds = need > (size_t)(256 * 136 * 2) ? need : (size_t)(256 * 136 * 2);
+      conv7x7_c4_kernel<true><<<dim3(a.B * a.f_tiles * gy), 512, lds, s>>>(a, gy);
+      return vipe_launch_status();
     }
-    return vipe_launch_status();
   }
-  if (small && a.KH == 7 && a.KW == 7 && a.W % HALO_TW == 0 && a.H % HALO_TH == 0 && cp % 128 == 0 && kp == 256 &&
-      a.epi == EPI_PLAIN && a.extra == nullptr && getenv("VIPE_AMD_CONV_NO7X7") == nullptr) {
-    static std::atomic<uint64_t> a7{0};  // bit d: set on device d
-    if (vipe_first_on_device(a7)) {
-      (void)hipFuncSetAttribute((const void*)conv7x7_c4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C7_LDS);
-    }
-    const int gy = cp / 128;
-    conv7x7_c4_kernel<<<dim3((int)(M / (HALO_TH * HALO_TW)) * gy), 512, C7_LDS, s>>>(a, gy);
-    return vipe_launch_status();
-  }
+  // per-tap gather kernels: any shape
+  const bool glds = !small && a.KH * a.KW <= 32;
+  static std::atomic<uint64_t> s1{0}, s2{0}, s3{0};
+  allow_lds(conv_mfma_kernel<128, 2, 2, false>, s1, 65536);
+  allow_lds(conv_mfma_kernel<128, 2, 2, true>, s2, 65536);
+  allow_lds(conv_mfma_glds_kernel<128, 2, 2>, s3, 65536);
   if (cp >= 128) {
     const size_t lds = 2 * (128 + BNP) * 128;
     const int gy = cp / 128;

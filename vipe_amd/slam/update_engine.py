@@ -151,8 +151,10 @@ class UpdateEngine:
 
     @staticmethod
     def supports_gate_split(ht, wd):
-        """Initial accumulators are implemented by the halo-tile convolution (width % 64 == 0, height % 4 == 0)."""
-        return wd % 64 == 0 and ht % 4 == 0 and os.environ.get("VIPE_AMD_GATE_SPLIT", "1") != "0"
+        """Initial accumulators are implemented by the tile convolutions (csrc/conv_mfma.hip): the 4 x 64 tiling for
+        grids made of such tiles, the flat tiling for every other grid up to 126 columns - i.e. every grid the
+        reference's resize to 384 x 512 pixels of area produces (vipe/slam/system.py:46-59: 41 x 73 for 16:9 video)."""
+        return ((wd % 64 == 0 and ht % 4 == 0) or wd <= 126) and os.environ.get("VIPE_AMD_GATE_SPLIT", "1") != "0"
 
     def gate_context(self, xbuf):
         """The part of the three GRU gate convolutions that only depends on the context features `inp`
