@@ -35,11 +35,17 @@ extern "C" {
 /* storage layout of a correlation pyramid (level i of an edge b, source pixel p1 = y1 * w + x1, target (y, x)):
  *   REFERENCE  level i = [B][h*w][h>>i][w>>i] for every level - CorrBlock.corr_pyramid, droid_net.py:56-69.
  *   BLOCKED    levels 0 and 1 regrouped into 64-byte tiles of 4 rows x 8 columns and 16 KiB / 8 KiB runs per 64
- *              source pixels (levels 2, 3 as REFERENCE); needs C == 128, w % 64 == 0, h % 8 == 0:
- *                level0[b][p1/64][(x/32)*(h/4) + y/4][p1%64][(x%32)/8][y%4][x%8]
- *                level1[b][p1/64][(x/16)*(h/8) + y/4][p1%64][(x%16)/8][y%4][x%8]     (x, y level-1 coordinates)
- *              Same bytes per level as REFERENCE.  The internal layout of pooled pyramids: built by
- *              vipe_corr_pyramid_build_indexed, read by vipe_corr_lookup_conv1x1. */
+ *              source pixels, on the grid PADDED to G = ceil(h w / 64) groups of source pixels, S = ceil(w / 32) strips
+ *              of 32 target columns and R = 2 ceil(h / 8) groups of 4 target rows (vipe_corr_blocked_dims):
+ *                level0[b][p1/64][(x/32)*R     + y/4][p1%64][(x%32)/8][y%4][x%8]
+ *                level1[b][p1/64][(x/16)*(R/2) + y/4][p1%64][(x%16)/8][y%4][x%8]     (x, y level-1 coordinates)
+ *                level2[b][G*64][R][8 S]      level3[b][G*64][R/2][round_up(4 S, 8)]  (one slab per source pixel)
+ *              For w % 64 == 0, h % 8 == 0 (the DROID maps at 1/8 of 512 x 384 and multiples) nothing is padded: the
+ *              same bytes per level as REFERENCE, levels 2 / 3 ARE the reference's.  For every other grid (41 x 73 for
+ *              16:9 video, vipe/slam/system.py:46-59) tiles wholly outside the h x w targets are never written or read,
+ *              and entries outside the floored (h >> i) x (w >> i) level (droid_net.py:66-68) hold zero.  The internal
+ *              layout of pooled pyramids: built by vipe_corr_pyramid_build_indexed / _prepared, read by
+ *              vipe_corr_lookup_conv1x1. */
 #define VIPE_PYRAMID_REFERENCE 0
 #define VIPE_PYRAMID_BLOCKED 1
 
@@ -82,7 +88,8 @@ int vipe_corr_pyramid_lookup_nhwc(const void* const* h_levels, const float* d_co
  * fp16 volume levels, Cout == 128; other configurations return VIPE_EUNSUPPORTED (use lookup_nhwc + conv2d).
  * d_slots (optional, [B] int32): edge b reads slot d_slots[b] of the level buffers (a pool of pyramids with capacity
  * >= B whose edges come and go without compaction, factor_graph.py:147-152,194-196); null: slot b.
- * layout: VIPE_PYRAMID_REFERENCE or VIPE_PYRAMID_BLOCKED (h1 == h2, w1 == w2 then). */
+ * layout: VIPE_PYRAMID_REFERENCE (level widths multiples of 8 down to level 3) or VIPE_PYRAMID_BLOCKED (h1 == h2,
+ * w1 == w2; any grid with h, w >= 8). */
 int vipe_corr_lookup_conv1x1(const void* const* h_levels, const float* d_coords, const void* d_w_packed,
                              const float* d_bias, void* d_out, int out_ctot, int out_coff, int B, int h1, int w1,
                              int h2, int w2, int Cout, int act, const int* d_slots, int layout, void* stream);
@@ -100,6 +107,27 @@ int vipe_corr_pyramid_build(const void* d_fmap1, const void* d_fmap2, void* cons
 int vipe_corr_pyramid_build_indexed(const void* d_fmaps, const int64_t* d_idx1, const int64_t* d_idx2,
                                     const int* d_slots, void* const* h_levels, int B, int C, int h, int w,
                                     int num_levels, int layout, void* stream);
+
+/* [fused] the same for ANY grid (C == 128): the keyframes' maps are first rewritten, once per frame, into the zero-padded
+ * operand images the MFMA kernel loads with aligned 16-byte accesses (an h x w map with an odd pixel count has no
+ * aligned rows):  vipe_corr_prep(d_fmaps [n,C,h,w] f16 -> d_prep [n][vipe_corr_prep_halves(C,h,w)] f16), then
+ * vipe_corr_pyramid_build_prepared with frame indices d_idx1 / d_idx2 counted from `frame_base` (d_prep holds frames
+ * frame_base .. frame_base + n - 1 of the keyframe buffer).  Output: VIPE_PYRAMID_BLOCKED on the padded grid.
+ * vipe_corr_blocked_dims: dims6 = {G, S, R, level-2 row pitch, level-3 row pitch, 1 if vipe_corr_pyramid_build_indexed
+ * tiles this grid directly (no preparation needed) else 0}. */
+int vipe_corr_blocked_dims(int h, int w, int* dims6);
+int64_t vipe_corr_prep_halves(int C, int h, int w);
+int vipe_corr_prep(const void* d_fmaps, void* d_prep, int n, int C, int h, int w, void* stream);
+int vipe_corr_pyramid_build_prepared(const void* d_prep, int64_t frame_base, const int64_t* d_idx1, const int64_t* d_idx2,
+                                     const int* d_slots, void* const* h_levels, int B, int C, int h, int w, int num_levels,
+                                     void* stream);
+
+/* CorrBlock.corr for any dtype / channel count (droid_net.py:94-102): volume[b][p1][p2] = sum_c (f1[b][c][p1] / 4)
+ * (f2[b][c][p2] / 4); fmaps [B,C,P] dtype, volume [B,P,P] dtype (plain tiled kernel: what the MFMA kernel of
+ * vipe_corr_pyramid_build does not take).  vipe_avg_pool2x2: F.avg_pool2d(x, 2, stride=2) over the last two dims of
+ * [n,h,w] -> [n,h>>1,w>>1] (droid_net.py:66-68), at::native rounding. */
+int vipe_corr_volume(const void* d_fmap1, const void* d_fmap2, void* d_volume, int B, int C, int P, int dtype, void* stream);
+int vipe_avg_pool2x2(const void* d_x, void* d_y, int64_t n, int h, int w, int dtype, void* stream);
 
 /* altcorr_forward: replaces altcorr_cuda_forward, altcorr_kernel.cu:266-290.
  * fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C] dtype (f16/f32); coords [B,N,H1,W1,2] f32; corr [B,N,(2r+1)^2,H1,W1]. */

@@ -154,3 +154,220 @@ def test_update_operator_on_ragged_grids_matches_torch_restatement(grid):
     n_a, dw_a = n_a.clone(), dw_a.clone()
     n_b, dw_b, _, _ = eng.forward_nhwc(net_n, xbuf.clone(), corr_n, motn, ix=ixd, n_src=2, csr=csr, pgate=pg)
     assert (n_a.float() - n_b.float()).abs().max().item() < 4e-3 and (dw_a - dw_b).abs().max().item() < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ correlation pyramid + lookup
+
+
+def _identity_lookup(levels, coords, slots, grid, E, h, w):
+    """all 196 channels of the FUSED lookup + 1x1 convolution kernel, bit for bit: the convolution is given 0/1 weights
+    that copy channels 0..127, then 68..195 (one fp16 value x 1.0 accumulated in fp32 and rounded back is itself)"""
+    from vipe_amd.ext import droid_net_ext
+    from vipe_amd.slam.update_engine import _Packed
+    out = torch.zeros(E, h, w, 196, dtype=torch.float16, device=dev())
+    for c0 in (0, 68):
+        wt = torch.zeros(128, 200, 1, 1)
+        wt[torch.arange(128), c0 + torch.arange(128)] = 1.0
+        pk = _Packed(wt.half(), torch.zeros(128), dev())
+        o = torch.empty(E, h, w, 128, dtype=torch.float16, device=dev())
+        droid_net_ext.corr_lookup_conv1x1(levels, coords, pk.packed, pk.bias, o, act="none", slots=slots, grid=grid)
+        out[..., c0:c0 + 128] = o
+    return out
+
+
+@pytest.mark.parametrize("grid", [(41, 73), (35, 85), (55, 55), (9, 18), (8, 8), (12, 100), (73, 41)])
+def test_pyramid_build_and_fused_lookup_on_ragged_grids(grid):
+    """Row a1 + a2 on grids that are not multiples of 8 x 64 (droid_net.py:56-82, correlation_kernels.cu:22-66):
+    `vipe_corr_prep` + `vipe_corr_pyramid_build_prepared` into the padded blocked store, through the pool's slots.
+    Level 0 against the fp32 contraction of the same fp16 maps (one rounding to half); levels 1..3 BIT-EXACT against
+    avg_pool2d's arithmetic on the kernel's own previous level with the reference's floored sizes (h >> i, w >> i); the
+    FUSED blocked lookup (every one of the 196 channels, windows hanging over every border) and the channels-last lookup
+    BIT-EXACT against oracle/corr.py on the device pyramid."""
+    from oracle import corr as ocorr
+    from vipe_amd.ext import droid_net_ext
+    from vipe_amd.slam.networks import CorrBlock, CorrPool
+    h, w = grid
+    g = torch.Generator().manual_seed(h * 1000 + w)
+    nf = 4
+    fmaps = torch.randn(nf, 128, h, w, generator=g).half().to(dev())
+    ii = torch.tensor([0, 1, 3, 2, 3])
+    jj = torch.tensor([1, 0, 3, 0, 1])
+    E = ii.shape[0]
+    pool = CorrPool(capacity=2)
+    pool.add_edges(fmaps, ii[:2].to(dev()), jj[:2].to(dev()), frame_range=(0, 2))
+    pool.add_edges(fmaps, ii[2:].to(dev()), jj[2:].to(dev()))  # frame range read back
+    assert pool.blocked and pool.pool[0].dim() == 7
+    lv = pool.corr_pyramid
+    assert [tuple(x.shape) for x in lv] == [(E, h, w, h >> i, w >> i) for i in range(4)]
+    f1, f2 = fmaps[ii.to(dev())], fmaps[jj.to(dev())]
+    ref0 = torch.matmul((f1.float() / 4).reshape(E, 128, h * w).transpose(1, 2), (f2.float() / 4).reshape(E, 128, h * w))
+    d0 = (lv[0].float().reshape(E, h * w, h * w) - ref0).abs()
+    assert float((d0 - ref0.abs() * 2.0 ** -10).max()) <= 2.0 ** -14, "level 0 is not the rounded fp32 contraction"
+    for i in range(3):
+        hn, wn = h >> (i + 1), w >> (i + 1)
+        x = lv[i].float().reshape(-1, h >> i, w >> i)[:, :2 * hn, :2 * wn]
+        pooled = (((x[:, 0::2, 0::2] + x[:, 0::2, 1::2]) + x[:, 1::2, 0::2]) + x[:, 1::2, 1::2]) / 4.0
+        assert torch.equal(pooled.half().reshape(lv[i + 1].shape), lv[i + 1]), f"level {i + 1} pooling not bit-exact"
+    # the same pyramid from gathered maps (CorrBlock's constructor: prepared operands of both map sets, no slots)
+    blk = CorrBlock(f1[None], f2[None])
+    for a, b_ in zip(blk.corr_pyramid, lv):
+        assert torch.equal(a, b_)
+    # blocked -> reference -> blocked round trip of the converters reproduces what the kernel stored where it matters
+    rt = droid_net_ext.pyramid_to_reference(droid_net_ext.pyramid_to_blocked(lv, h, w), h, w)
+    for a, b_ in zip(rt, lv):
+        assert torch.equal(a, b_)
+    # lookups
+    u, v = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+    base = torch.from_numpy(np.stack([u, v], -1))[None].repeat(E, 1, 1, 1)
+    coords = base + 5.0 * torch.randn(E, h, w, 2, generator=g)
+    coords[0] = torch.rand(h, w, 2, generator=g) * torch.tensor([w + 10.0, h + 10.0]) - 5.0  # anywhere, incl. outside
+    coords[1, 0, :min(w, 8)] = torch.tensor([[w - 1.0, h - 1.0], [w - 0.5, h - 0.5], [float(w), float(h)], [-1.0, -1.0],
+                                             [w - 4.0, 0.0], [0.0, h - 4.0], [w + 2.5, 3.0], [-50.0, -50.0]])[:min(w, 8)]
+    coords = coords.to(dev()).contiguous()
+    ref = ocorr.corr_lookup([x.cpu().numpy() for x in lv], coords.cpu().numpy()[None], 3)[0]  # [E,196,h,w]
+    hd = pool.lookup_deferred(coords)
+    assert hd[0] == "lookup" and hd[4] == (h, w)
+    got = _identity_lookup(hd[1], hd[2], hd[3], hd[4], E, h, w).permute(0, 3, 1, 2).cpu().numpy()
+    assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)), "fused blocked lookup not bit-exact"
+    hb = blk.lookup_deferred(coords)
+    got = _identity_lookup(hb[1], hb[2], hb[3], hb[4], E, h, w).permute(0, 3, 1, 2).cpu().numpy()
+    assert np.array_equal(got.view(np.uint16), ref.view(np.uint16))
+    nhwc = pool.lookup_nhwc(coords)
+    assert np.array_equal(nhwc[..., :196].permute(0, 3, 1, 2).cpu().numpy().view(np.uint16), ref.view(np.uint16))
+    assert torch.count_nonzero(nhwc[..., 196:]) == 0
+    # slot reuse after removals: the new edges land in freed slots of a store that held other data
+    pool = pool[np.array([0, 3])]
+    pool.add_edges(fmaps, torch.tensor([2, 1]).to(dev()), torch.tensor([2, 3]).to(dev()), frame_range=(1, 4))
+    ii2, jj2 = torch.tensor([0, 2, 2, 1]), torch.tensor([1, 0, 2, 3])
+    ref_blk = CorrBlock(fmaps[ii2.to(dev())][None], fmaps[jj2.to(dev())][None])
+    for a, b_ in zip(pool.corr_pyramid, ref_blk.corr_pyramid):
+        assert torch.equal(a, b_)
+
+
+def test_corr_block_other_dtypes_and_channel_counts_use_the_plain_kernels():
+    """CorrBlock is dtype-generic in the reference (droid_net.py:94-102): fp32 maps / channel counts other than 128 take
+    `vipe_corr_volume` + `vipe_avg_pool2x2` - against torch on the host."""
+    import torch.nn.functional as F
+    from vipe_amd.slam.networks import CorrBlock
+    g = torch.Generator().manual_seed(2)
+    for (C, h, w, dt, tol) in ((128, 12, 16, torch.float32, 2e-5), (64, 9, 11, torch.float32, 2e-5), (96, 8, 8, torch.float16, 2e-3)):
+        f1 = torch.randn(1, 2, C, h, w, generator=g).to(dt)
+        f2 = torch.randn(1, 2, C, h, w, generator=g).to(dt)
+        blk = CorrBlock(f1.to(dev()), f2.to(dev()))
+        vol = torch.matmul((f1.float() / 4).reshape(2, C, h * w).transpose(1, 2), (f2.float() / 4).reshape(2, C, h * w))
+        vol = vol.reshape(2 * h * w, 1, h, w)
+        for i, lv in enumerate(blk.corr_pyramid):
+            assert tuple(lv.shape) == (2, h, w, h >> i, w >> i) and lv.dtype == dt
+            assert float((lv.float().cpu().reshape(vol.shape) - vol).abs().max()) < tol * max(1.0, float(vol.abs().max()))
+            if i < 3:
+                vol = F.avg_pool2d(vol, 2, stride=2)
+
+
+# ------------------------------------------------------------------------------------------------ the update iteration
+
+
+def test_factor_graph_update_on_the_16_9_grid():
+    """BASELINE configs[1]'s real input size (1280 x 720 -> 328 x 584 -> 41 x 73 grid, system.py:46-59): ONE
+    FactorGraph.update at N = 12 (E = 60), sensor-depth prior on.  (i) the fused lookup on the pool's device-built pyramid
+    is bit-exact vs the oracle for every edge of a sample; (ii) the operator's outputs agree with the fp32 restatement of
+    UpdateModule fed the oracle's reprojection and lookup (fp16 activations: 5e-2 px on the targets); (iii) the BA step
+    equals the fp64 oracle BA fed the device's own targets / weights / damping at 1e-4 relative (north_star tolerance);
+    (iv) the energy of those factors decreases; (v) every tile kernel was taken: gate hoisting and the staged gates are on."""
+    import bench
+    from oracle import ba as oba
+    from oracle import corr as ocorr
+    from oracle import geom as ogeom
+    from oracle import se3 as ose3
+    from oracle import update_module as oum
+    from vipe_amd.ext import slam_ext
+    n, H, W = 12, 328, 584
+    g, buf, graph = bench.build_problem(dev(), n, H, W, 3, 0, seed=77, depth_prior=True)
+    ht, wd = 41, 73
+    assert (g.ht, g.wd) == (ht, wd) and graph.pgate is not None and graph.corr.blocked
+    E = len(g.ii)
+    graph.gate_overlap_min_edges = 16  # take the staged-gates path at this edge count too
+    poses0, disps0 = buf.poses[:n].cpu().numpy().copy(), buf.disps[:n, 0].cpu().numpy().copy()
+    target0 = graph.target[0].cpu().numpy().copy()
+    net0, inp0 = graph.f_net.float().cpu(), graph.inp.float().cpu()
+    z = torch.zeros(E, dtype=torch.long, device=dev())
+    coords1, _ = slam_ext.reproject(buf.poses, buf.flattened_disps, buf.intrinsics, buf.rig, graph.ii, z, graph.jj, z, graph.ii)
+    # (i)
+    sel = list(range(0, E, 7))
+    lv_all = graph.corr.corr_pyramid
+    ref = ocorr.corr_lookup([lv[sel].cpu().numpy() for lv in lv_all], coords1[sel].cpu().numpy()[None], 3)[0]
+    hd = graph.corr.lookup_deferred(coords1)
+    got = _identity_lookup(hd[1], hd[2], hd[3], hd[4], E, ht, wd)[sel].permute(0, 3, 1, 2).cpu().numpy()
+    assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)), "lookup on the device pyramid not bit-exact"
+    # two updates: the second one consumes the gate state the first staged under its BA
+    graph.update(t0=1, t1=n, itrs=3)
+    torch.cuda.synchronize()
+    assert graph._gate_state is not None
+    tg, wg = graph.target[0].cpu().numpy(), graph.weight[0].cpu().numpy()
+    damping = graph.damping[:n].cpu().numpy()
+    p1, d1 = buf.poses[:n].cpu().numpy(), buf.disps[:n, 0].cpu().numpy()
+    assert np.isfinite(p1).all() and np.isfinite(d1).all() and np.isfinite(tg).all()
+    # (ii) oracle composition of the operator's inputs and outputs
+    zz = np.zeros_like(g.ii)
+    rig = ose3.se3_identity(1)
+    o = ogeom.reproject(poses0, disps0, (g.intrinsics / 8.0).astype(np.float32), rig, g.ii, g.jj, zz, zz, g.ii)
+    c1 = o["coords"]
+    assert np.abs(c1 - coords1.cpu().numpy()).max() < 2e-3
+    u, v = ogeom.pixel_grid(ht, wd, np.float32)
+    motn = np.clip(np.concatenate([c1 - np.stack([u, v], -1), target0 - c1], -1).transpose(0, 3, 1, 2), -64, 64)
+    corr = ocorr.corr_lookup([lv.cpu().numpy() for lv in lv_all], coords1.cpu().numpy()[None], 3)
+    ix = torch.from_numpy(np.unique(g.ii, return_inverse=True)[1])
+    sd = {k: w_.float() for k, w_ in graph.update_op.state_dict().items()}
+    with torch.no_grad():
+        net2, delta, weight, eta, _ = oum.update_forward(sd, net0, inp0, torch.from_numpy(corr).float(),
+                                                         torch.from_numpy(motn).float()[None].half().float(), ix)
+    assert np.abs(tg - (c1 + delta[0].numpy())).max() < 0.05
+    assert np.abs(wg - weight[0].numpy()).max() < 0.02
+    assert np.abs(graph.f_net.float().cpu().numpy() - net2.numpy()).max() < 0.03
+    # (iii) fp64 oracle BA on the device's targets / weights / eta, from the pre-update state
+    kw = dict(t0=1, t1=n, n_iters=3, pose_damping=1e-3, pose_ep=0.1)
+    op, od, _, _ = oba.bundle_adjustment(poses0, disps0[:, None], g.disps_sens[:, None], g.intrinsics, rig,
+                                         tg.reshape(E, -1, 2), wg.reshape(E, -1, 2), damping[:, None], g.ii, g.jj, **kw)
+    assert np.abs(p1 - op).max() <= 1e-4 * max(1.0, np.abs(op).max()), np.abs(p1 - op).max()
+    assert np.abs(d1 - od[:, 0]).max() <= 1e-4 * np.abs(od).max(), np.abs(d1 - od[:, 0]).max()
+    # (iv)
+    e0 = oba.energy(poses0, disps0[:, None], g.intrinsics, rig, tg, wg, g.ii, g.jj)
+    e1 = oba.energy(p1, d1[:, None], g.intrinsics, rig, tg, wg, g.ii, g.jj)
+    assert e1 < e0
+    # (v) second iteration through the staged gate state == the same iteration without it (fp32 summation order)
+    import copy
+    state = (buf.poses.clone(), buf.disps.clone(), graph.net_n.clone(), graph.target.clone(), graph.weight.clone(),
+             graph.damping.clone())
+    gs = graph._gate_state
+    graph.update(t0=1, t1=n, itrs=3)
+    a = (buf.poses[:n].clone(), buf.disps[:n].clone(), graph.net_n.clone(), graph.target.clone())
+    buf.poses.copy_(state[0]); buf.disps.copy_(state[1])
+    graph.net_n = state[2]; graph.target = state[3]; graph.weight = state[4]; graph.damping.copy_(state[5])
+    graph._gate_state = None
+    del gs, copy
+    graph.update(t0=1, t1=n, itrs=3)
+    b = (buf.poses[:n], buf.disps[:n], graph.net_n, graph.target)
+    assert (a[2].float() - b[2].float()).abs().max().item() < 4e-3
+    assert (a[3] - b[3]).abs().max().item() < 2e-2
+    assert (a[0] - b[0]).abs().max().item() < 1e-4 and (a[1] - b[1]).abs().max().item() < 1e-3
+
+
+def test_update_batch_on_the_16_9_grid_uses_the_volume_path():
+    """hot loop B (factor_graph.py:316-394) on a 41 x 73 grid: the backend builds its pyramids with the general-grid
+    kernel and matches the reference-shaped AltCorrBlock path (volume-free, fp32) up to fp16 lookup rounding."""
+    import bench
+    n, H, W = 8, 328, 584
+    res = []
+    for alt in (False, True):
+        import os
+        if alt:
+            os.environ["VIPE_AMD_BACKEND_ALTCORR"] = "1"
+        try:
+            g, buf, graph = bench.build_problem(dev(), n, H, W, 2, 0, seed=5, depth_prior=False)
+            graph.update_batch(itrs=2, steps=2, optimize_intrinsics=False, optimize_rig_rotation=False)
+            torch.cuda.synchronize()
+            res.append((buf.poses[:n].clone(), buf.disps[:n].clone(), graph.target.clone()))
+        finally:
+            os.environ.pop("VIPE_AMD_BACKEND_ALTCORR", None)
+    assert torch.isfinite(res[0][0]).all() and torch.isfinite(res[0][1]).all()
+    assert (res[0][2] - res[1][2]).abs().max().item() < 0.25   # targets: px, fp16 volume vs fp32 volume-free correlation
+    assert (res[0][0] - res[1][0]).abs().max().item() < 5e-3

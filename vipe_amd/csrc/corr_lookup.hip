@@ -329,6 +329,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int l16 = lane & 15, kg = lane >> 4;
   const int gpp = (P + 31) / 32;
   const int ngroups = B * gpp;
+  // padded blocked layout (include/vipe_amd.h): G groups of 64 source pixels, S strips of 32 columns, R row groups of 4
+  const int bG = (P + 63) >> 6, bS = (w2 + 31) >> 5, bR = ((h2 + 7) >> 3) << 1;
   // this wave's weights: couts 32 wave + 16 i + l16, k = 32 s + 8 kg .. + 7  (packed [k / 64][cout_pad][64])
   half8v af[2][7];
 #pragma unroll
@@ -357,23 +359,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const float sc = 1.0f / (float)(1 << l);
       const int h2l = h2 >> l, w2l = w2 >> l;
       const int bx = (int)floorf(c.x * sc) - R, by = (int)floorf(c.y * sc) - R;
-      const int y1 = by + j, c0 = bx >> 3, nchunks = w2l >> 3;
+      const int y1 = by + j, c0 = bx >> 3;
+      // 8-column pieces of a row: whole ones in the reference layout; in the blocked layout the last one may be partial
+      // (columns >= w2l stored as zero by the build kernel)
+      const int nchunks = blocked ? (w2l + 7) >> 3 : w2l >> 3;
       const bool rowok = (y1 >= 0) & (y1 < h2l);
       lo[l] = uint4v{0, 0, 0, 0};
       hi[l] = uint4v{0, 0, 0, 0};
       if (blocked && l < 2) {
         // VIPE_PYRAMID_BLOCKED (include/vipe_amd.h): 16-byte piece (row y1, columns 8 c ..) of source pixel pc lives in
-        // run ((x-strip) * (h2l / 4) + y1 / 4) of the pixel's group of 64, tile c % T, tile row y1 % 4
-        const int T = 4 >> l, rgs = h2l >> 2;
-        const int64_t eg = (int64_t)ns * (P >> 6) + (pc >> 6);
+        // run ((x-strip) * (R >> l) + y1 / 4) of the pixel's group of 64, tile c % T, tile row y1 % 4
+        const int T = 4 >> l, rgs = bR >> l;
+        const int64_t eg = (int64_t)ns * bG + (pc >> 6);
         const half_t* base = reinterpret_cast<const half_t*>(lv.p[l]);
         const int yr = rowok ? y1 : 0;
         auto piece = [&](int cc) {
-          const int64_t run = eg * ((int64_t)rgs * (w2 >> 5)) + (cc / T) * rgs + (yr >> 2);
+          const int64_t run = eg * ((int64_t)rgs * bS) + (cc / T) * rgs + (yr >> 2);
           return *reinterpret_cast<const uint4v*>(base + (run * 64 + (pc & 63)) * (T * 32) + (cc % T) * 32 + (yr & 3) * 8);
         };
         if (rowok & (c0 >= 0) & (c0 < nchunks)) lo[l] = piece(c0);
         if (rowok & (c0 + 1 >= 0) & (c0 + 1 < nchunks)) hi[l] = piece(c0 + 1);
+      } else if (blocked) {
+        // levels 2 / 3 of the blocked layout: one slab per source pixel of every group, R >> (l - 2) rows of
+        // 8 S / round_up(4 S, 8) entries
+        const int hlp = bR >> (l - 2), wlp = l == 2 ? 8 * bS : ((4 * bS + 7) & ~7);
+        const half_t* slab = reinterpret_cast<const half_t*>(lv.p[l]) + ((int64_t)ns * bG * 64 + pc) * ((int64_t)hlp * wlp);
+        const uint4v* rowp = reinterpret_cast<const uint4v*>(slab + (int64_t)(rowok ? y1 : 0) * wlp);
+        if (rowok & (c0 >= 0) & (c0 < nchunks)) lo[l] = rowp[c0];
+        if (rowok & (c0 + 1 >= 0) & (c0 + 1 < nchunks)) hi[l] = rowp[c0 + 1];
       } else {
         const half_t* slab = reinterpret_cast<const half_t*>(lv.p[l]) + ((int64_t)ns * P + pc) * ((int64_t)h2l * w2l);
         const uint4v* rowp = reinterpret_cast<const uint4v*>(slab + (int64_t)(rowok ? y1 : 0) * w2l);
@@ -568,8 +581,8 @@ static int pyramid_lookup_impl(const void* const* h_levels, const float* d_coord
     lv.p[i] = h_levels[i];
   }
   hipStream_t s = as_stream(stream);
-  if (dtype == VIPE_F16 && radius == 3 && ((w2 >> (num_levels - 1)) & 7) == 0 && getenv("VIPE_AMD_LOOKUP_SIMPLE") == nullptr) {
-    if (num_levels == 4 && nhwc_stride == 200 && getenv("VIPE_AMD_LOOKUP_PERLEVEL") == nullptr) {
+  if (dtype == VIPE_F16 && radius == 3 && ((w2 >> (num_levels - 1)) & 7) == 0) {
+    if (num_levels == 4 && nhwc_stride == 200) {
       corr_pyramid_lookup_rows4_kernel<<<dim3((h1 * w1 + 31) / 32, B), 256, 0, s>>>(lv, d_coords, (half_t*)d_out, h1, w1,
                                                                                    h2, w2, nhwc_stride);
       return vipe_launch_status();
@@ -610,10 +623,12 @@ VIPE_EXPORT int vipe_corr_lookup_conv1x1(const void* const* h_levels, const floa
   VIPE_CHECK_ARG(h_levels && d_coords && d_w_packed && d_bias && d_out);
   VIPE_CHECK_ARG(act == VIPE_ACT_NONE || act == VIPE_ACT_RELU);
   VIPE_CHECK_ARG(out_ctot % 8 == 0 && out_coff % 8 == 0 && out_coff + Cout <= out_ctot);
-  // 4 levels, radius 3, fp16 volume whose coarsest level still has 8-element row chunks; 128 output channels
-  if (Cout != 128 || ((w2 >> 3) & 7) != 0 || (h2 >> 3) < 1) return VIPE_EUNSUPPORTED;
   VIPE_CHECK_ARG(layout == VIPE_PYRAMID_REFERENCE || layout == VIPE_PYRAMID_BLOCKED);
-  if (layout == VIPE_PYRAMID_BLOCKED) VIPE_CHECK_ARG(h1 == h2 && w1 == w2 && w2 % 64 == 0 && h2 % 8 == 0);
+  // 4 levels, radius 3, fp16 volume, 128 output channels.  Reference layout: the coarsest level must still have
+  // 8-element row chunks (16-byte loads); the blocked layout pads its rows itself: any grid with a non-empty level 3
+  if (Cout != 128 || (h2 >> 3) < 1 || (w2 >> 3) < 1) return VIPE_EUNSUPPORTED;
+  if (layout == VIPE_PYRAMID_REFERENCE && ((w2 >> 3) & 7) != 0) return VIPE_EUNSUPPORTED;
+  if (layout == VIPE_PYRAMID_BLOCKED) VIPE_CHECK_ARG(h1 == h2 && w1 == w2);
   LevelPtrs lv;
   for (int i = 0; i < 4; ++i) {
     VIPE_CHECK_ARG(h_levels[i]);

@@ -164,7 +164,8 @@ class FactorGraph:
             if self.corr is None:
                 self.corr = CorrPool(capacity=max(64, self.max_factors + 16))
             V = self.buffer.n_views
-            self.corr.add_edges(self.buffer.flattened_fmaps, pi * V + qi, pj * V + qj)
+            lo, hi = int(min(ii_h.min(), jj_h.min())), int(max(ii_h.max(), jj_h.max()))
+            self.corr.add_edges(self.buffer.flattened_fmaps, pi * V + qi, pj * V + qj, frame_range=(lo * V, (hi + 1) * V))
             WORK["pyramids_built"] += int(pi.shape[0])
             xb = torch.zeros((ii.shape[0] * self.buffer.n_views, self.ht, self.wd, 320), dtype=torch.half,
                              device=self.device)
@@ -537,14 +538,18 @@ class FactorGraph:
         # The reference's backend uses the volume-free AltCorrBlock to fit 24 GB devices (droid_net.py:121-176).  With
         # 288 GB of HBM the per-chunk volume (~33 MB per edge, ~1.5 GB per chunk of 8 source keyframes) is cheap, and
         # building it (one fused kernel, 10 us per edge) + the fused lookup is >10x faster than 49 x 128-channel dot
-        # products per pixel and level; AltCorrBlock stays the path for grids the volume kernels do not cover.
-        use_volume = self.wd % 64 == 0 and self.ht % 8 == 0 and os.environ.get("VIPE_AMD_BACKEND_ALTCORR") is None
+        # products per pixel and level; the volume kernels cover every grid (blocked store on the padded grid), AltCorrBlock
+        # stays the reference-shaped alternative (VIPE_AMD_BACKEND_ALTCORR=1) for devices where the volumes do not fit.
+        from ..ext import droid_net_ext
+        use_volume = (droid_net_ext.fused_build_covers(buf.flattened_fmaps.shape[1], self.ht, self.wd, 4, buf.flattened_fmaps.dtype)
+                      and os.environ.get("VIPE_AMD_BACKEND_ALTCORR") is None)
         corr_op = None if use_volume else AltCorrBlock(buf.flattened_fmaps[None])
         P = self._edge_plan()
         V = buf.n_views
         # The feature maps do not change during the `steps` passes: each chunk's correlation pyramid is built in the
         # first pass and kept for the others while all of them fit VIPE_AMD_BACKEND_VOLUME_GB (default 160 of 288 GB).
-        vol_bytes = self.ii.shape[0] * V * (self.ht * self.wd) ** 2 * 2 * (1 + 1 / 4 + 1 / 16 + 1 / 64)
+        G_, S_, R_ = droid_net_ext.blocked_dims(self.ht, self.wd)[:3]  # the store is padded to G x 64 sources, R x 4 rows, S x 32 columns
+        vol_bytes = self.ii.shape[0] * V * (G_ * 64) * (R_ * 4 * S_ * 32) * 2 * (1 + 1 / 4 + 1 / 16 + 1 / 64)
         keep_vols = use_volume and steps > 1 and vol_bytes <= float(os.environ.get("VIPE_AMD_BACKEND_VOLUME_GB", "160")) * 2**30
         # The reference walks the source keyframes in groups of 8 (factor_graph.py:337-343) to bound memory.  The
         # operator couples edges only through GraphAgg's per-source-frame mean, so ANY partition that keeps every
@@ -616,7 +621,9 @@ class FactorGraph:
                 if use_volume:
                     vol = vols.get(gi)
                     if vol is None:
-                        vol = CorrBlock.from_buffer(buf.flattened_fmaps, c["pis"] * V + c["qis"], c["pjs"] * V + c["qjs"])
+                        vol = CorrBlock.from_buffer(buf.flattened_fmaps, c["pis"] * V + c["qis"], c["pjs"] * V + c["qjs"],
+                                                    frame_range=(int(min(ii_np.min(), jj_np.min())) * V,
+                                                                 (int(max(ii_np.max(), jj_np.max())) + 1) * V))
                         WORK["pyramids_built"] += n
                         if keep_vols:
                             vols[gi] = vol

@@ -22,7 +22,8 @@ class CorrBlock:
     Layout: level i is [E, h1, w1, h2/2^i, w2/2^i], contiguous, dtype of the feature maps (fp16 under
     autocast in the reference, factor_graph.py:119) - 25.1 MB/edge at 48x64.  `from_buffer` builds the same pyramid
     from frame indices in the BLOCKED internal layout (include/vipe_amd.h) that the fused lookup kernel reads with half
-    the memory sectors; `corr_pyramid` then converts on access.
+    the memory sectors; `corr_pyramid` then converts on access.  Grids that are not multiples of 8 x 64 (41 x 73 for 16:9
+    video) are always held blocked - their reference layout has no 16-byte aligned rows.
     """
 
     def __init__(self, fmap1, fmap2, num_levels=4, radius=3):
@@ -30,21 +31,30 @@ class CorrBlock:
         self.radius = radius
         batch, num, dim, ht, wd = fmap1.shape
         self.ht, self.wd = ht, wd
-        self.levels = droid_net_ext.corr_pyramid_build(
-            fmap1.reshape(batch * num, dim, ht, wd), fmap2.reshape(batch * num, dim, ht, wd), num_levels)
+        f1, f2 = fmap1.reshape(batch * num, dim, ht, wd), fmap2.reshape(batch * num, dim, ht, wd)
+        blocked = (f1.is_cuda and f1.dtype == f2.dtype and droid_net_ext.fused_build_covers(dim, ht, wd, num_levels, f1.dtype)
+                   and not droid_net_ext.blocked_dims(ht, wd)[5])
+        self.levels = droid_net_ext.corr_pyramid_build(f1, f2, num_levels,
+                                                       droid_net_ext.BLOCKED if blocked else droid_net_ext.REFERENCE)
 
     @classmethod
-    def from_buffer(cls, fmaps, idx1, idx2, num_levels=4, radius=3):
+    def from_buffer(cls, fmaps, idx1, idx2, num_levels=4, radius=3, frame_range=None):
         """fmaps [n_frames,C,h,w]; edge e correlates frame idx1[e] with frame idx2[e] - the gathered copies
-        `fmaps[idx1]`, `fmaps[idx2]` (factor_graph.py:147-148) are never made when the fused kernel covers the shape."""
+        `fmaps[idx1]`, `fmaps[idx2]` (factor_graph.py:147-148) are never made when the fused kernel covers the shape.
+        `frame_range` (lo, hi): see droid_net_ext.corr_pyramid_build_indexed."""
         n, C, ht, wd = fmaps.shape
         if not (fmaps.is_cuda and droid_net_ext.fused_build_covers(C, ht, wd, num_levels, fmaps.dtype)):
             return cls(fmaps[idx1][None], fmaps[idx2][None], num_levels, radius)
         self = cls.__new__(cls)
         self.num_levels, self.radius, self.ht, self.wd = num_levels, radius, ht, wd
         self.levels = droid_net_ext.corr_pyramid_build_indexed(fmaps, idx1.contiguous(), idx2.contiguous(),
-                                                               num_levels=num_levels)
+                                                               num_levels=num_levels, frame_range=frame_range)
         return self
+
+    def _fused_lookup_covers(self, lv):
+        """4 levels, radius 3, fp16 on the device; the reference layout needs 8-element row chunks down to level 3"""
+        return (self.num_levels == 4 and self.radius == 3 and lv[0].dtype == torch.float16 and lv[0].is_cuda
+                and (self.wd >> 3) >= 1 and (self.ht >> 3) >= 1 and (lv[0].dim() == 7 or (self.wd >> 3) % 8 == 0))
 
     @property
     def corr_pyramid(self):
@@ -68,9 +78,8 @@ class CorrBlock:
         """Handle for the fused lookup + correlation-encoder kernel (`UpdateEngine.forward_nhwc` consumes it), or the
         materialised channels-last lookup when the fused kernel does not cover this pyramid."""
         lv = self.levels
-        if (self.num_levels == 4 and self.radius == 3 and lv[0].dtype == torch.float16 and lv[0].is_cuda
-                and (self.wd >> 3) % 8 == 0 and (self.ht >> 3) >= 1):
-            return ("lookup", lv, coords.contiguous())
+        if self._fused_lookup_covers(lv):
+            return ("lookup", lv, coords.contiguous(), None, (self.ht, self.wd))
         return self.lookup_nhwc(coords)
 
     def cat(self, other):
@@ -91,15 +100,8 @@ class CorrBlock:
 
 
 def _to_blocked(levels, ht, wd):
-    """reference-layout levels -> BLOCKED (inverse of droid_net_ext.pyramid_to_reference; copies levels 0 / 1)"""
-    out = list(levels)
-    for i in range(min(2, len(levels))):
-        lv = levels[i]
-        n, T = lv.shape[0], 4 >> i
-        hl, wl = ht >> i, wd >> i
-        x = lv.reshape(n, ht * wd // 64, 64, hl // 4, 4, wl // (8 * T), T, 8).permute(0, 1, 5, 3, 2, 6, 4, 7)
-        out[i] = x.reshape(n, ht * wd // 64, (hl // 4) * (wl // (8 * T)), 64, T, 4, 8).contiguous()
-    return out
+    """reference-layout levels -> BLOCKED (inverse of droid_net_ext.pyramid_to_reference)"""
+    return droid_net_ext.pyramid_to_blocked(levels, ht, wd)
 
 
 class CorrPool:
@@ -148,8 +150,9 @@ class CorrPool:
         self.slots = new if self.slots is None else torch.cat([self.slots, new], 0)
         return ids, new
 
-    def add_edges(self, fmaps, idx1, idx2):
-        """append the edges (frame idx1[e] -> frame idx2[e]) of fmaps [n_frames,C,h,w]"""
+    def add_edges(self, fmaps, idx1, idx2, frame_range=None):
+        """append the edges (frame idx1[e] -> frame idx2[e]) of fmaps [n_frames,C,h,w]; `frame_range` (lo, hi): the
+        frames the indices lie in (droid_net_ext.corr_pyramid_build_indexed)"""
         n, C, ht, wd = fmaps.shape
         k = int(idx1.shape[0])
         fused = fmaps.is_cuda and droid_net_ext.fused_build_covers(C, ht, wd, self.num_levels, fmaps.dtype)
@@ -160,7 +163,7 @@ class CorrPool:
                       fmaps.dtype, fmaps.device)
         _, new = self._take(k, fmaps.device)
         droid_net_ext.corr_pyramid_build_indexed(fmaps, idx1.contiguous(), idx2.contiguous(), levels=self.pool, slots=new,
-                                                 num_levels=self.num_levels)
+                                                 num_levels=self.num_levels, frame_range=frame_range)
         return self
 
     def cat(self, other):
@@ -168,7 +171,7 @@ class CorrPool:
         lv = other.levels if hasattr(other, "levels") else other.corr_pyramid
         k = lv[0].shape[0]
         if self.ht is None:
-            self.ht, self.wd = (int(x) for x in lv[min(2, len(lv) - 1)].shape[1:3])
+            self.ht, self.wd = (other.ht, other.wd) if hasattr(other, "ht") else (int(x) for x in lv[-1].shape[1:3])
         if self.pool is not None and self.blocked and lv[0].dim() != 7:
             lv = _to_blocked(lv, self.ht, self.wd)
         elif self.pool is None:
@@ -210,9 +213,8 @@ class CorrPool:
 
     def lookup_deferred(self, coords):
         lv = self.pool
-        if (self.num_levels == 4 and self.radius == 3 and lv[0].dtype == torch.float16 and lv[0].is_cuda
-                and (self.wd >> 3) % 8 == 0 and (self.ht >> 3) >= 1):
-            return ("lookup", lv, coords.contiguous(), self.slots)
+        if CorrBlock._fused_lookup_covers(self, lv):
+            return ("lookup", lv, coords.contiguous(), self.slots, (self.ht, self.wd))
         return self.lookup_nhwc(coords)
 
 

@@ -275,7 +275,8 @@ class UpdateEngine:
         if isinstance(corr, tuple):
             from ..ext import droid_net_ext
             droid_net_ext.corr_lookup_conv1x1(corr[1], corr[2], self.corr0.packed, self.corr0.bias, c1, act="relu",
-                                              slots=corr[3] if len(corr) > 3 else None)
+                                              slots=corr[3] if len(corr) > 3 else None,
+                                              grid=corr[4] if len(corr) > 4 else None)
         else:
             self._conv(self.corr0, corr, 0, E, H, W, y=c1, act="relu", cin=CORR_CH)
         self._conv(self.corr2, c1, 0, E, H, W, y=xbuf, y_coff=128, act="relu")
@@ -348,7 +349,7 @@ class UpdateEngine:
             eta = self._buf("eta", (n_src, H, W), torch.float32)  # persistent: callers consume it before the next call
         lookup = isinstance(corr, tuple)
         tensors = (net, net_out, xbuf, motn, pgate, c1, f1, zb, rnet, hbuf, dw, glo, extra, order, rowptr, agg, a2, eta) + \
-            ((tuple(corr[1]) + (corr[2],) + ((corr[3],) if len(corr) > 3 else ())) if lookup else (corr,))
+            ((tuple(corr[1]) + (corr[2],) + ((corr[3],) if len(corr) > 3 and corr[3] is not None else ())) if lookup else (corr,))
         pzr = gate_state["pzr"] if gate_state is not None else None
         two_streams = E >= self.op_side_min_edges
         if two_streams and self._op_side is None:
@@ -368,7 +369,10 @@ class UpdateEngine:
                     b.levels[i] = lv[i].data_ptr()
                 b.coords = corr[2].data_ptr()
                 b.slots = corr[3].data_ptr() if len(corr) > 3 and corr[3] is not None else None
-                b.h2, b.w2 = int(lv[2].shape[3]) << 2, int(lv[2].shape[4]) << 2
+                if len(corr) > 4 and corr[4] is not None:  # (h, w) of the targets: a padded blocked store does not show them
+                    b.h2, b.w2 = int(corr[4][0]), int(corr[4][1])
+                else:
+                    b.h2, b.w2 = int(lv[2].shape[3]) << 2, int(lv[2].shape[4]) << 2
                 b.pyramid_layout = 1 if lv[0].dim() == 7 else 0
             else:
                 b.corr = corr.data_ptr()
