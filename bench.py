@@ -504,8 +504,119 @@ def plumbing_mode(args, D):
     D.close()
 
 
+# ---------------------------------------------------------------------------------------------- roofline helper
+def conv_roofline(graph, step, device, prof_steps):
+    """Roofline of the dominant kernel: conv_halo32_kernel<128, 3, true, 0, FLAT> (every 3x3 convolution of the flow-update
+    operator with >= 128 output channels: corr2, z|r, q, delta0|weight0|agg1, agg2 - 5 launches per step, ~50 % of the
+    step).  Every launch of that instantiation in `prof_steps` extra steps is bracketed by events on the launch stream;
+    achieved = (algorithmic flops of those launches) / (their summed duration).
+    -> (avg launch ms, flops per launch, achieved TFLOP/s, launches per step)"""
+    eng = graph.update_op.engine(device)
+    rec = []
+    recording = False
+    orig = eng._conv
+
+    def timed_conv(pk, x0, x0_coff, B, H, W, *a, **k):
+        cin = k.get("cin") or pk.cin
+        # the dominant instantiation only (<128, 3, true, 0>): the z|r convolution that starts from the staged fp32 partial
+        # sums is its own instantiation (<..., 1>) and rocprof row
+        staged = k.get("accinit") is not None and k["accinit"].dtype == torch.float32
+        if recording and pk.cout > 64 and pk.kh == 3 and not staged:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(pk, x0, x0_coff, B, H, W, *a, **k)
+            e1.record()
+            rec.append((e0, e1, 2.0 * B * H * W * cin * pk.cout * pk.kh * pk.kw))
+        else:
+            orig(pk, x0, x0_coff, B, H, W, *a, **k)
+
+    # the operator is normally ONE natively sequenced library call; for these few steps the same kernels are issued one
+    # by one from Python (forward_nhwc(native=False)) so that single launches can be bracketed by events
+    fwd = eng.forward_nhwc
+    eng._conv, eng.forward_nhwc = timed_conv, (lambda *a, **k: fwd(*a, **dict(k, native=False)))
+    try:
+        # three unrecorded steps first: the gather / host work after the timed region lets the clocks fall, and the first
+        # kernels after an idle gap run 10-50 % slower than in the timed region (kernel trace of this very command)
+        for _ in range(3 if prof_steps else 0):
+            step()
+        recording = True
+        for _ in range(prof_steps):
+            step()
+        torch.cuda.synchronize()
+    finally:
+        eng._conv = orig
+        del eng.forward_nhwc
+    tot_ms = sum(a.elapsed_time(b) for a, b, _ in rec) or float("nan")
+    tot_fl = sum(f for _, _, f in rec)
+    return (tot_ms / max(1, len(rec)), tot_fl / max(1, len(rec)), tot_fl / (tot_ms * 1e-3) / 1e12,
+            len(rec) // max(1, prof_steps))
+
+
+def capture_two_steps(step):
+    """two consecutive update iterations as one HIP graph (see update_mode); None when capture is not possible"""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # allocate everything the two steps need outside the capture
+        step()
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    cg = torch.cuda.CUDAGraph()
+    # thread_local: the RCCL watchdog thread of a multi-GPU run may touch the runtime while this thread captures
+    with torch.cuda.graph(cg, capture_error_mode="thread_local"):
+        step()
+        step()
+    torch.cuda.synchronize()
+    cg.replay()  # one untimed replay
+    return cg
+
+
+def grid_figure(device, height, width, n_kf, steps, prof_steps, headline_px_rate=None):
+    """The headline measurement (graph replay of two captured update iterations, radius-3 graph, depth prior on, 3 GN
+    iterations) on another image size, with the event-timed roofline of its dominant convolution."""
+    g, buf, graph = build_problem(device, n_kf, height, width, 3, 0, seed=1234)
+    E = int(graph.ii.numel())
+
+    def step():
+        graph.update(t0=1, t1=n_kf, itrs=3)
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    try:
+        cg, launch = capture_two_steps(step), "hipgraph (2 steps per replay)"
+    except Exception as e:  # noqa: BLE001
+        cg, launch = None, f"eager (graph capture failed: {type(e).__name__})"
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps // 2):
+        cg.replay() if cg is not None else (step(), step())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = 2 * (steps // 2)
+    finite = bool(torch.isfinite(buf.poses[:n_kf]).all() and torch.isfinite(buf.disps[:n_kf]).all()
+                  and torch.isfinite(graph.target).all())
+    ms, fpl, ach, lps = conv_roofline(graph, step, device, prof_steps)
+    P = g.ht * g.wd
+    out = {"value": n / dt, "unit": "iters/s", "ms_per_step": 1e3 * dt / n, "steps": n, "grid": [g.ht, g.wd], "pixels": P,
+           "keyframes": n_kf, "edges": E, "launch": launch, "state_finite": finite,
+           "edge_pixels_per_s": n / dt * E * P,
+           "tile_kernels": {"gate_context_hoisted": graph.pgate is not None,
+                            "pyramid_store": "blocked" if getattr(graph.corr, "blocked", False) else "reference",
+                            "staged_gates": getattr(graph, "_gate_state", None) is not None},
+           "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / PEAK_FP16_TFLOPS, "traffic": None, "avg_launch_ms": ms, "flops_per_launch": fpl,
+                        "launches_per_step": lps,
+                        "kernel": "conv_halo32_kernel<128, 3, true, 0, FLAT> on this grid (event-timed launches)"}}
+    if headline_px_rate:
+        out["per_pixel_throughput_vs_48x64"] = out["edge_pixels_per_s"] / headline_px_rate
+    del graph, buf
+    torch.cuda.empty_cache()
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- secondary figures
-def secondary_figures(args, device, graph, step):
+def secondary_figures(args, device, graph, step, headline_px_rate=None):
     """Figures north_star asks to be reported next to the headline, measured in the same driver-run process AFTER (and
     outside) the timed headline region, N = 1 only.  Each is a plain eager-launch timing."""
     out = {}
@@ -526,6 +637,15 @@ def secondary_figures(args, device, graph, step):
         out["value_all_gate_work_per_iteration"] = timed(step, 6)
         graph.pgate = keep
     _log("secondary: all-gate-work done")
+    # (1b) the same measurement on the grid the reference's resize produces for 16:9 video (1280 x 720 -> 328 x 584 ->
+    # 41 x 73, vipe/slam/system.py:46-59; both clips of assets/examples), and on BASELINE configs[4]'s 1024 x 512 (64 x 128)
+    for key, (hh, ww, nk, st) in {"value_grid_41x73": (328, 584, args.keyframes, 20),
+                                  "value_config5_grid_64x128": (512, 1024, args.keyframes, 10)}.items():
+        try:
+            out[key] = grid_figure(device, hh, ww, nk, st, args.prof_steps, headline_px_rate)
+        except Exception as e:  # noqa: BLE001
+            out[key] = f"failed: {type(e).__name__}: {e}"
+        _log(f"secondary: {key} done")
     # (2) E = 768 stress (backend cap 16 t): radius-3 graph + 492 seeded long-range edges
     try:
         _, _, g768 = build_problem(device, args.keyframes, 384, 512, 3, 492, seed=4321)
@@ -565,7 +685,7 @@ def update_mode(args, D):
 
     device, world, rank = D.device, D.world, D.rank
     # clip sharding: rank r owns clip r (seed differs per rank), no exchange during compute
-    g, buf, graph = build_problem(device, args.keyframes, 384, 512, 3, args.extra_edges, seed=1234 + rank)
+    g, buf, graph = build_problem(device, args.keyframes, args.height, args.width, 3, args.extra_edges, seed=1234 + rank)
     E = int(graph.ii.numel())
     if args.serial_operator:  # profiling aid: every kernel of the operator on ONE stream (per-kernel durations then are
         graph.update_op.engine(device).op_side_min_edges = 10 ** 9  # those of the kernel running alone)
@@ -588,20 +708,7 @@ def update_mode(args, D):
     launch, cg = "eager", None
     if not args.no_hipgraph and args.steps >= 2:
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):  # allocate everything the two steps need outside the capture
-                step()
-                step()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            cg = torch.cuda.CUDAGraph()
-            # thread_local: the RCCL watchdog thread of a multi-GPU run may touch the runtime while this thread captures
-            with torch.cuda.graph(cg, capture_error_mode="thread_local"):
-                step()
-                step()
-            torch.cuda.synchronize()
-            cg.replay()  # one untimed replay
+            cg = capture_two_steps(step)
             launch = "hipgraph (2 steps per replay)"
         except Exception as e:  # noqa: BLE001 - fall back to eager launches and say so
             cg = None
@@ -635,49 +742,7 @@ def update_mode(args, D):
     n_seen = D.n_ranks_seen()
     _log(f"timed region done: {world * args.steps / dt:.1f} it/s")
 
-    # ---- roofline of the dominant kernel: conv_halo32_kernel<128, 3, true> (every 3x3 convolution of the
-    # flow-update operator with >= 128 output channels: corr2, z|r, q, delta0|weight0|agg1, agg2 - 5 launches per
-    # step, ~50 % of the step).  Every launch of that instantiation in a few extra steps is bracketed by events on
-    # the launch stream; achieved = (algorithmic flops of those launches) / (their summed duration).
-    eng = graph.update_op.engine(device)
-    rec = []
-    recording = False
-    orig = eng._conv
-
-    def timed_conv(pk, x0, x0_coff, B, H, W, *a, **k):
-        cin = k.get("cin") or pk.cin
-        # the dominant instantiation only (conv_halo32_kernel<128, 3, true, 0>): the z|r convolution that starts from the
-        # staged fp32 partial sums is its own instantiation (<..., 1>) and rocprof row
-        staged = k.get("accinit") is not None and k["accinit"].dtype == torch.float32
-        if recording and pk.cout > 64 and pk.kh == 3 and not staged:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            orig(pk, x0, x0_coff, B, H, W, *a, **k)
-            e1.record()
-            rec.append((e0, e1, 2.0 * B * H * W * cin * pk.cout * pk.kh * pk.kw))
-        else:
-            orig(pk, x0, x0_coff, B, H, W, *a, **k)
-
-    # the operator is normally ONE natively sequenced library call; for these few steps the same kernels are issued one
-    # by one from Python (forward_nhwc(native=False)) so that single launches can be bracketed by events
-    fwd = eng.forward_nhwc
-    eng._conv, eng.forward_nhwc = timed_conv, (lambda *a, **k: fwd(*a, **dict(k, native=False)))
-    # three unrecorded steps first: the gather / host work after the timed region lets the clocks fall, and the first
-    # kernels after an idle gap run 10-50 % slower than in the timed region (kernel trace of this very command)
-    recording = False
-    for _ in range(3 if args.prof_steps else 0):
-        step()
-    recording = True
-    for _ in range(args.prof_steps):
-        step()
-    torch.cuda.synchronize()
-    eng._conv = orig
-    del eng.forward_nhwc
-    tot_ms = sum(a.elapsed_time(b) for a, b, _ in rec) or float("nan")
-    tot_fl = sum(f for _, _, f in rec)
-    gate_ms = tot_ms / max(1, len(rec))
-    flops_per_launch = tot_fl / max(1, len(rec))
-    achieved = tot_fl / (tot_ms * 1e-3) / 1e12
+    gate_ms, flops_per_launch, achieved, launches_per_step = conv_roofline(graph, step, device, args.prof_steps)
 
     # HBM traffic of the dominant kernel per launch: FETCH_SIZE x2 + WRITE_SIZE from the builder's own rocprofv3 --pmc
     # passes of this command (profiles/rNN_summary.json, committed) - counters cannot be collected from inside the
@@ -717,7 +782,8 @@ def update_mode(args, D):
             "vs_baseline": None,
             "dtype": DTYPE,
             "data": "synthetic",
-            "config": {"workload": f"configs[2]: 512x384, {args.keyframes}-keyframe factor graph, E={E} edges "
+            "config": {"workload": f"{'configs[2]: ' if (args.height, args.width) == (384, 512) else 'NOT the headline size: '}"
+                                   f"{args.width}x{args.height}, {args.keyframes}-keyframe factor graph, E={E} edges "
                                    f"(radius-3 bidirectional), depth_align on (sensor-depth prior on every keyframe), "
                                    f"3 GN iterations per update, one clip per GPU",
                        "parallelism": f"clip-sharded x{world}", "launch": launch,
@@ -737,7 +803,7 @@ def update_mode(args, D):
                                    "launches with Cout >= 128 of the flow-update operator on the main stream, except the "
                                    "z|r convolution that starts from staged fp32 partial sums = instantiation <..., 1>)",
                          "avg_launch_ms": gate_ms, "flops_per_launch": flops_per_launch,
-                         "launches_per_step": len(rec) // max(1, args.prof_steps), "pmc": mfma_pmc},
+                         "launches_per_step": launches_per_step, "pmc": mfma_pmc},
             # the whole update iteration against both nominal peaks (SURVEY 8d totals per edge; N source nodes add
             # 1.37 GFLOP each): MFMA-bound by construction, the HBM figure is what north_star asks to see beside it
             "iteration_roofline": {
@@ -749,7 +815,7 @@ def update_mode(args, D):
                         "per edge) over the measured step time, per GPU"},
         }
         if world == 1 and not args.no_secondary:
-            out.update(secondary_figures(args, device, graph, step))
+            out.update(secondary_figures(args, device, graph, step, out["value"] * E * g.ht * g.wd))
         out["cpu_baseline"] = cpu_baseline() if (world == 1 and not args.no_cpu_baseline) else None
         print(json.dumps(out))
     D.close()
@@ -763,6 +829,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--keyframes", type=int, default=48)
+    ap.add_argument("--height", type=int, default=384, help="update mode: image height (default: the headline's 384)")
+    ap.add_argument("--width", type=int, default=512, help="update mode: image width (328 x 584 = the 41 x 73 grid of 16:9 video)")
     ap.add_argument("--extra-edges", type=int, default=0, help="seeded long-range edges on top of the radius-3 graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
