@@ -371,3 +371,185 @@ def test_update_batch_on_the_16_9_grid_uses_the_volume_path():
     assert torch.isfinite(res[0][0]).all() and torch.isfinite(res[0][1]).all()
     assert (res[0][2] - res[1][2]).abs().max().item() < 0.25   # targets: px, fp16 volume vs fp32 volume-free correlation
     assert (res[0][0] - res[1][0]).abs().max().item() < 5e-3
+
+
+# ------------------------------------------------------------------------------------------------ the driver-timed code path
+
+
+def test_replayed_two_step_graph_equals_eager_steps():
+    """What bench.py's timed region runs (bench.capture_two_steps): two consecutive `FactorGraph.update` calls captured
+    into ONE HIP graph - the operator natively sequenced on two streams, the next iteration's hidden-state gates forked
+    onto a side stream through the BA's overlap hook INSIDE the capture, plan reuse and path hints on - replayed, against
+    the same number of eager steps on a twin problem from the same seeds.  Equal up to the fp32 / fp64 order of the
+    atomically accumulated sums (global-context pooling, reduced system): the tolerances of
+    test_update_with_gate_state_on_side_stream_matches_serial_update."""
+    import bench
+    n = 14  # radius-3 graph: E = 72 >= 64 edges -> gate overlap ("gated") and the operator's second stream are on
+    out = {}
+    for mode in ("eager", "graph"):
+        g, buf, graph = bench.build_problem(dev(), n, 384, 512, 3, 0, seed=99, depth_prior=True)
+        E = int(graph.ii.numel())
+        assert E >= graph.gate_overlap_min_edges and E >= graph.update_op.engine(dev()).op_side_min_edges
+        assert graph.gate_overlap_mode == "gated"
+
+        def step():
+            graph.update(t0=1, t1=n, itrs=3)
+
+        for _ in range(3):
+            step()
+        if mode == "graph":
+            cg = bench.capture_two_steps(step)   # runs 2 steps, captures 2 (not executed), replays once (2 steps)
+            assert graph._gate_state is not None
+            cg.replay()
+            cg.replay()
+        else:
+            for _ in range(8):
+                step()
+            assert graph._gate_state is not None
+        torch.cuda.synchronize()
+        out[mode] = (buf.poses[:n].clone(), buf.disps[:n].clone(), graph.target.clone(), graph.weight.clone(),
+                     graph.net_n.clone(), graph.damping[:n].clone())
+        assert all(torch.isfinite(t.float()).all() for t in out[mode])
+    a, b = out["eager"], out["graph"]
+    assert (a[0] - b[0]).abs().max().item() < 1e-4, "poses"
+    assert (a[1] - b[1]).abs().max().item() < 1e-4 * float(a[1].abs().max()) + 1e-4, "inverse depth"
+    assert (a[4].float() - b[4].float()).abs().max().item() < 1e-2, "hidden state"
+    assert (a[2] - b[2]).abs().max().item() < 5e-2, "targets (px)"
+    assert (a[3] - b[3]).abs().max().item() < 2e-2, "weights"
+    assert (a[5] - b[5]).abs().max().item() < 1e-3, "damping (eta)"
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs[4]: 1024 x 512
+
+
+def test_config5_end_to_end_at_64x128():
+    """BASELINE configs[4]'s size (1024 x 512 -> 64 x 128 grid, P = 8192, 134 MB of level-0 volume per edge; pinhole model:
+    the reference's panorama camera has no projection, cameras.py:357-407): pyramid build (level 0 = rounded fp32
+    contraction, pooled levels bit-exact), the fused blocked lookup bit-exact vs the oracle, one FactorGraph.update whose
+    BA equals the fp64 oracle fed the device's own targets / weights / damping at 1e-4, and the encoders at 1024 x 512
+    against the fp32 restatement of BasicEncoder."""
+    import bench
+    from oracle import ba as oba
+    from oracle import corr as ocorr
+    from oracle import encoder as oenc
+    from oracle import se3 as ose3
+    from vipe_amd.ext import slam_ext
+    from vipe_amd.slam.motion_filter import DroidNet
+    n, H, W = 6, 512, 1024
+    g, buf, graph = bench.build_problem(dev(), n, H, W, 2, 0, seed=31, depth_prior=True)
+    ht, wd = 64, 128
+    E = len(g.ii)
+    assert (g.ht, g.wd) == (ht, wd) and graph.corr.blocked and graph.pgate is not None
+    poses0, disps0 = buf.poses[:n].cpu().numpy().copy(), buf.disps[:n, 0].cpu().numpy().copy()
+    # pyramid of two edges
+    sel = [0, E - 1]
+    lv = [x[sel] for x in graph.corr.corr_pyramid]
+    ii, jj = torch.from_numpy(g.ii[sel]).to(dev()), torch.from_numpy(g.jj[sel]).to(dev())
+    f1, f2 = buf.fmaps[ii, 0], buf.fmaps[jj, 0]
+    ref0 = torch.matmul((f1.float() / 4).reshape(2, 128, ht * wd).transpose(1, 2), (f2.float() / 4).reshape(2, 128, ht * wd))
+    d0 = (lv[0].float().reshape(2, ht * wd, ht * wd) - ref0).abs()
+    assert float((d0 - ref0.abs() * 2.0 ** -10).max()) <= 2.0 ** -14
+    del ref0, d0
+    for i in range(3):
+        x = lv[i].float().reshape(-1, ht >> i, wd >> i)
+        pooled = (((x[:, 0::2, 0::2] + x[:, 0::2, 1::2]) + x[:, 1::2, 0::2]) + x[:, 1::2, 1::2]) / 4.0
+        assert torch.equal(pooled.half().reshape(lv[i + 1].shape), lv[i + 1])
+    # fused lookup, bit-exact on those edges
+    z = torch.zeros(E, dtype=torch.long, device=dev())
+    coords1, _ = slam_ext.reproject(buf.poses, buf.flattened_disps, buf.intrinsics, buf.rig, graph.ii, z, graph.jj, z, graph.ii)
+    ref = ocorr.corr_lookup([x.cpu().numpy() for x in lv], coords1[sel].cpu().numpy()[None], 3)[0]
+    hd = graph.corr.lookup_deferred(coords1)
+    got = _identity_lookup(hd[1], hd[2], hd[3], hd[4], E, ht, wd)[sel].permute(0, 3, 1, 2).cpu().numpy()
+    assert np.array_equal(got.view(np.uint16), ref.view(np.uint16))
+    del lv, got, ref
+    # one update
+    graph.update(t0=1, t1=n, itrs=3)
+    torch.cuda.synchronize()
+    tg, wg = graph.target[0].cpu().numpy(), graph.weight[0].cpu().numpy()
+    damping = graph.damping[:n].cpu().numpy()
+    p1, d1 = buf.poses[:n].cpu().numpy(), buf.disps[:n, 0].cpu().numpy()
+    rig = ose3.se3_identity(1)
+    kw = dict(t0=1, t1=n, n_iters=3, pose_damping=1e-3, pose_ep=0.1)
+    op, od, _, _ = oba.bundle_adjustment(poses0, disps0[:, None], g.disps_sens[:, None], g.intrinsics, rig,
+                                         tg.reshape(E, -1, 2), wg.reshape(E, -1, 2), damping[:, None], g.ii, g.jj, **kw)
+    assert np.abs(p1 - op).max() <= 1e-4 * max(1.0, np.abs(op).max()), np.abs(p1 - op).max()
+    assert np.abs(d1 - od[:, 0]).max() <= 1e-4 * np.abs(od).max(), np.abs(d1 - od[:, 0]).max()
+    assert oba.energy(p1, d1[:, None], g.intrinsics, rig, tg, wg, g.ii, g.jj) < \
+        oba.energy(poses0, disps0[:, None], g.intrinsics, rig, tg, wg, g.ii, g.jj)
+    del graph, buf
+    torch.cuda.empty_cache()
+    # encoders at 1024 x 512
+    torch.manual_seed(0)
+    dn = DroidNet()
+    img = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        f_ref = oenc.encode_features({k: v.clone().float().cpu() for k, v in dn.fnet.state_dict().items()}, img)
+        n_ref, i_ref = oenc.encode_context({k: v.clone().float().cpu() for k, v in dn.cnet.state_dict().items()}, img)
+    enc = dn.to(dev())
+    fmap = enc.encode_features(img.to(dev()).contiguous())
+    net, inp = enc.encode_context(img.to(dev()).contiguous())
+    for name, got, want in (("fmap", fmap, f_ref), ("net", net, n_ref), ("inp", inp, i_ref)):
+        want = want.reshape(got.shape).numpy()
+        err = np.abs(got.float().cpu().numpy() - want).max()
+        assert tuple(got.shape[-2:]) == (ht, wd) and err < 3e-2 * max(1.0, np.abs(want).max()), (name, err)
+
+
+def test_motion_filter_and_encoders_on_the_16_9_size():
+    """328 x 584 frames (1280 x 720 through the reference's resize): encoders -> 41 x 73 maps vs the fp32 restatement, and
+    MotionFilter.check's score (one operator application on a CorrBlock of the general-grid kernels) vs the oracle chain."""
+    from oracle import corr as ocorr
+    from oracle import encoder as oenc
+    from oracle import update_module as oum
+    from vipe_amd.slam.motion_filter import DroidNet, MotionFilter
+    torch.manual_seed(0)
+    dn = DroidNet()
+    sd_f = {k: v.clone() for k, v in dn.fnet.state_dict().items()}
+    sd_c = {k: v.clone() for k, v in dn.cnet.state_dict().items()}
+    sd_u = {k: v.clone() for k, v in dn.update.state_dict().items()}
+    gen = torch.Generator().manual_seed(21)
+    V, H, W = 1, 328, 584
+    img0 = torch.rand(V, 3, H, W, generator=gen)
+    img1 = (img0 + 0.1 * torch.rand(V, 3, H, W, generator=gen)).clamp(0, 1)
+    mf = MotionFilter(dn, thresh=1e9, device=dev())
+    assert mf.check(img0.to(dev()).contiguous(), None) is True
+    assert mf.check(img1.to(dev()).contiguous(), None) is False
+    assert tuple(mf.f_fmap.shape[-2:]) == (41, 73)
+    with torch.no_grad():
+        f0, f1 = oenc.encode_features(sd_f, img0), oenc.encode_features(sd_f, img1)
+        net, inp = oenc.encode_context(sd_c, img0)
+        ht, wd = H // 8, W // 8
+        assert np.abs(mf.f_fmap.float().cpu().numpy() - f0.reshape(mf.f_fmap.shape).numpy()).max() < 3e-2 * max(1.0, float(f0.abs().max()))
+        pyr = [l.numpy() for l in ocorr.corr_pyramid(f0[None], f1[None])]
+        coords0 = MotionFilter.coords_grid(ht, wd)[None, None].repeat(1, V, 1, 1, 1).numpy()
+        corr = torch.from_numpy(ocorr.corr_lookup(pyr, coords0, 3))
+        _, delta, _ = oum.update_forward(sd_u, net[None], inp[None], corr, torch.zeros(1, V, 4, ht, wd))
+        ref = float(delta.norm(dim=-1)[0].mean([1, 2]).min())
+    assert abs(mf.last_score - ref) < 3e-2 * max(ref, 1e-3), (mf.last_score, ref)
+
+
+# ------------------------------------------------------------------------------------------------ N > 1 control flow
+
+
+def test_bench_two_ranks_on_one_card_as_a_child_process():
+    """`python bench.py --gpus 2` as the driver starts it, from a fresh child process that has not touched the GPU: the
+    parent spawns two ranks (torch.distributed.run), each sets its problem up, captures its step graph, joins the process
+    group (gloo here: both ranks share the ONE card of this box, RCCL needs a card per rank), times its clip and enters
+    the result gather.  No scaling number is read off this - it covers the N > 1 control flow (spawn -> capture ->
+    process group -> barrier -> all_gather -> max over ranks) on a GPU box."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VIPE_BENCH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--keyframes", "10", "--no-cpu-baseline", "--no-secondary", "--prof-steps", "1"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["scaling"] == "weak" and line["value"] > 0
+    cfg = line["config"]
+    assert cfg["result_gather"]["clips"] == 2 and cfg["result_gather"]["inside_timed_region"] and cfg["state_finite"]
+    assert cfg["result_gather"]["backend"] == "gloo" and cfg["launch"].startswith("hipgraph")
