@@ -54,7 +54,7 @@ extern "C" {
 
 /* library / build identification ("gfx950", ABI version) */
 const char* vipe_amd_version(void);
-int vipe_amd_abi_version(void); /* 2 since round 2 (struct layouts of vipe_ba_params / vipe_update_buffers grew) */
+int vipe_amd_abi_version(void); /* 3 since round 3 (vipe_ba_params.solver_options; rounds 1-2: 1, 2) */
 
 /* ---------------------------------------------------------------------------------------------
  * droid_net_ext  (csrc/droid_net_ext/droid.cpp:57-63)
@@ -267,7 +267,11 @@ typedef struct {
   void* overlap_stream;        /* co-scheduling hook (see vipe_overlap_fn); NULL / NULL: none */
   vipe_overlap_fn overlap_fn;
   void* overlap_user;
+  int solver_options;          /* 0 = the default kernel selection.  VIPE_BA_OPT_* bits pick the equivalent general forms, for
+                                  validating the specialised kernels against them (tests/test_gpu_parity.py) */
 } vipe_ba_params;
+#define VIPE_BA_OPT_ONE_CHAIN 1           /* band solve: eliminate the pose chain from one end (default: both ends at once) */
+#define VIPE_BA_OPT_GENERAL_ACCUMULATE 2  /* accumulate: the walk + Schur kernel pair for every source-frame degree */
 
 int64_t vipe_dense_ba_workspace_bytes(const vipe_ba_params* p);
 int vipe_dense_ba(const vipe_ba_params* p, float* d_poses, float* d_disps, const float* d_disps_sens,

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     L = _lib.lib()
     assert b"gfx950" in L.vipe_amd_version()
-    assert L.vipe_amd_abi_version() == 2
+    assert L.vipe_amd_abi_version() == 3
 
 
 def test_header_cites_reference_interfaces():

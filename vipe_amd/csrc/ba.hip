@@ -7,13 +7,13 @@
 // host round trips (maths/matrix.py:66-81) -> scipy spsolve on the CPU (solver.py:33-44).
 //
 // MI355X design (one GN iteration = 3 launches, no host sync):
-//   ba_accum_kernel   grid (pixel tiles, source frames).  One lane owns pixel p of source frame k and walks
+//   ba_accum_mfma_kernel (source frames of <= 6 terms) / ba_walk_kernel + ba_schur_kernel (any degree)
+//                     grid (pixel tiles, source frames).  One lane owns pixel p of source frame k and walks
 //                     ALL terms (edges) whose source is k (device-built CSR), so the per-pixel quantities
 //                     C_k, w_k, E_kk stay in registers and are final when the walk ends; Jacobians never
-//                     touch memory.  J^T W J blocks are reduced with wave shuffles (64 lanes), combined
-//                     across the block's 4 waves in LDS and added to the dense reduced system in fp64.
-//                     The Schur complement of frame k (all member pairs of k) is formed by the same lanes
-//                     right after the walk, from registers + the term's E_j rows it just wrote.
+//                     touch memory.  J^T W J blocks are Gram matrices on the matrix cores (v_mfma_f32_16x16x4_f32),
+//                     combined in LDS and added to the dense reduced system in fp64.  The Schur complement of
+//                     frame k (all member pairs of k) is formed right after the walk.
 //   ba_solve_kernel   one workgroup: LM damping, blocked (6-wide) right-looking Cholesky in fp64 with the
 //                     rhs carried as an extra matrix row (forward substitution for free), blocked backward
 //                     substitution, pose / intrinsics retraction.
@@ -63,8 +63,8 @@ struct BAArgs {
   // per view (nintr = V (1 + D) unknowns when optimize_intrinsics) and one rotation block per view >= 1 (6 (V - 1) when
   // optimize_rig_rotation; view 0 is the gauge, buffer.py:506); ntail = both.  Mono: the F <= 2 shared intrinsics.
   int mv, nintr, ntail;
-  int force_simple;  // VIPE_BA_ACCUM_SIMPLE: shuffle-reduction accumulate kernel for every graph (A/B, debugging)
-  int band2;         // two-chain band solve for long pose-only chains (VIPE_BA_BAND2=0 switches it off for A/B)
+  int force_general; // vipe_ba_params.solver_options & VIPE_BA_OPT_GENERAL_ACCUMULATE
+  int band2;         // two-chain band solve for long pose-only chains (off: VIPE_BA_OPT_ONE_CHAIN)
   // DROID semantics of slam_ext.ba (geom_kernels.cu:178-432, 1273-1404; see oracle/droid_ba.py for the list):
   // target / weight [M,2,P], eta [K,P] by krow, per-pixel depth prior, reduced-diagonal damping, poses free iff in
   // [t0,t1), stereo terms, MIN_DEPTH 0.25, pose t0 left out of the disparity back-substitution, dz written to dz_out
@@ -353,319 +353,9 @@ __device__ __forceinline__ float block_reduce(float (&vals)[N], float* red /* [N
   return s;
 }
 
-template <int CAM, int F>
-__global__ __launch_bounds__(TILE) void ba_accum_kernel(BAArgs a) {
-  constexpr int FF = F > 0 ? F : 1;
-  constexpr int NT = 63 + 6 * F;                          // per-term reduced values
-  constexpr int NK = 27 + 6 * F + F * (F + 1) / 2 + F;    // per-frame reduced values
-  constexpr int NRED = NT > NK ? NT : NK;
-  const vipe_ba_params& prm = a.p;
-  const BAWs& w = a.w;
-  if (a.force_simple != 1) return;  // A/B and debugging only (VIPE_BA_ACCUM_SIMPLE): the matrix-core kernels own every graph
-  const int k = blockIdx.y;
-  const int beg = w.rowptr[k], end = w.rowptr[k + 1];
-  if (beg == end) return;
-  const int P = a.P, V = prm.n_views, tid = threadIdx.x;
-  const int p_raw = blockIdx.x * TILE + tid;
-  const bool inb = p_raw < P;
-  const int p = inb ? p_raw : P - 1;
-  const int flags = w.fflags[k];
-  const bool dfree = flags & 2;
-  const int pose_i = k / V, qi = k % V;
-  const int si = w.pose_slot[pose_i];
-  const int n_free = w.info[0], nrow = w.info[3];
-  const int foff = 6 * n_free;
-
-  __shared__ TermGeom tg[TCHUNK];
-  __shared__ float red[NWAVE * NRED];
-
-  const cam::Intr Ii = cam::load_scaled(a.intr + qi * (4 + a.D), a.D, 1.0f / prm.intr_factor);
-  const float u = (float)(p % prm.wd), v = (float)(p / prm.wd);
-  const float d = a.disps[(int64_t)k * P + p];
-  float X0, Y0, dX0[FF], dY0[FF];
-  cam::iproj<CAM, F>(Ii, u, v, X0, Y0, dX0, dY0);
-
-  float C = 0.f, wz = 0.f, Ei[6] = {0, 0, 0, 0, 0, 0}, Efr[FF] = {};
-  float hii[21] = {}, vi[6] = {}, hif[6 * FF] = {}, hff[3] = {}, vf[FF] = {};
-
-  for (int c0 = beg; c0 < end; c0 += TCHUNK) {
-    const int nt = min(TCHUNK, end - c0);
-    __syncthreads();
-    if (tid < nt) {
-      TermGeom g;
-      term_setup(a, w.order[c0 + tid], g);
-      tg[tid] = g;
-    }
-    __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-      const TermGeom& G = tg[t];
-      const int e = G.e;
-      // ---- forward: X1 = T X0, projection, residual, weight
-      const float X = G.T.R[0] * X0 + G.T.R[1] * Y0 + G.T.R[2] + G.T.t[0] * d;
-      const float Y = G.T.R[3] * X0 + G.T.R[4] * Y0 + G.T.R[5] + G.T.t[1] * d;
-      const float Z = G.T.R[6] * X0 + G.T.R[7] * Y0 + G.T.R[8] + G.T.t[2] * d;
-      float x, y, Jp[2][3], Jfj[2][FF];
-      cam::proj<CAM, true, F>(G.Ij, X, Y, Z, x, y, Jp, Jfj);
-      float2 tgt, wg;
-      load_tw(a, e, p, P, tgt, wg);
-      const float val = valid_weight(a, Z, inb);  // geom.py:263, buffer.py:413
-      const float wd2[2] = {val * wg.x, val * wg.y};                     // weights of the disparity system
-      const float wc[2] = {G.merge == 2 ? 0.0f : wd2[0], G.merge == 2 ? 0.0f : wd2[1]};  // ... of the pose blocks
-      const float rc[2] = {x - tgt.x, y - tgt.y};
-      // ---- Jacobians (geom.py:114-145, 271-281)
-      float Ja[3][6] = {{d, 0, 0, 0, Z, -Y}, {0, d, 0, -Z, 0, X}, {0, 0, d, Y, -X, 0}};
-      if (G.rig_adj) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          float tmp[6];
-          adjT_apply(G.Rr, Ja[r], tmp);
-#pragma unroll
-          for (int q = 0; q < 6; ++q) Ja[r][q] = tmp[q];
-        }
-      }
-      float Jj[2][6], Ji[2][6], Jz[2], Jf[2][FF];
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-#pragma unroll
-        for (int q = 0; q < 6; ++q) Jj[c][q] = Jp[c][0] * Ja[0][q] + Jp[c][1] * Ja[1][q] + Jp[c][2] * Ja[2][q];
-        float tmp[6];
-        adjT_apply(G.G, Jj[c], tmp);
-#pragma unroll
-        for (int q = 0; q < 6; ++q) Ji[c][q] = -tmp[q];
-        Jz[c] = Jp[c][0] * G.T.t[0] + Jp[c][1] * G.T.t[1] + Jp[c][2] * G.T.t[2];
-        if constexpr (F > 0) {
-#pragma unroll
-          for (int f = 0; f < F; ++f) {
-            // Jfi = Jp . (R_T dX0/df)  (geom.py:286-288), Jfj from the target camera; J_scale 1/8 (terms.py:224-227)
-            const float ax = G.T.R[0] * dX0[f] + G.T.R[1] * dY0[f];
-            const float ay = G.T.R[3] * dX0[f] + G.T.R[4] * dY0[f];
-            const float az = G.T.R[6] * dX0[f] + G.T.R[7] * dY0[f];
-            Jf[c][f] = (Jp[c][0] * ax + Jp[c][1] * ay + Jp[c][2] * az + Jfj[c][f]) * (1.0f / prm.intr_factor);
-          }
-        }
-      }
-      if (G.merge == 1) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int q = 0; q < 6; ++q) Ji[c][q] += Jj[c][q];
-      }
-      const bool fi = si >= 0, fj = G.sj >= 0;
-      // ---- per-pixel disparity quantities (kept in registers across the walk)
-      const float wJz[2] = {wc[0] * Jz[0], wc[1] * Jz[1]};
-      if (dfree) {
-        C += wd2[0] * Jz[0] * Jz[0] + wd2[1] * Jz[1] * Jz[1];
-        wz -= wd2[0] * Jz[0] * rc[0] + wd2[1] * Jz[1] * rc[1];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) Ei[q] += Ji[0][q] * wJz[0] + Ji[1][q] * wJz[1];
-        if constexpr (F > 0) {
-#pragma unroll
-          for (int f = 0; f < F; ++f) Efr[f] += Jf[0][f] * wJz[0] + Jf[1][f] * wJz[1];
-        }
-        if (fj && inb) {
-#pragma unroll
-          for (int q = 0; q < 6; ++q)
-            w.Ej[((int64_t)e * 6 + q) * P + p] = Jj[0][q] * wJz[0] + Jj[1][q] * wJz[1];
-        }
-      }
-      // ---- frame-level Hessian pieces (pose i, intrinsics)
-      if (fi) {
-#pragma unroll
-        for (int s = 0; s < 21; ++s) {
-          const int r = SYM_R[s], c = SYM_C[s];
-          hii[s] += wc[0] * Ji[0][r] * Ji[0][c] + wc[1] * Ji[1][r] * Ji[1][c];
-        }
-#pragma unroll
-        for (int q = 0; q < 6; ++q) vi[q] -= wc[0] * rc[0] * Ji[0][q] + wc[1] * rc[1] * Ji[1][q];
-        if constexpr (F > 0) {
-#pragma unroll
-          for (int q = 0; q < 6; ++q)
-#pragma unroll
-            for (int f = 0; f < F; ++f) hif[q * F + f] += wc[0] * Ji[0][q] * Jf[0][f] + wc[1] * Ji[1][q] * Jf[1][f];
-        }
-      }
-      if constexpr (F > 0) {
-        int s = 0;
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-#pragma unroll
-          for (int f2 = 0; f2 <= f; ++f2) hff[s++] += wc[0] * Jf[0][f] * Jf[0][f2] + wc[1] * Jf[1][f] * Jf[1][f2];
-          vf[f] -= wc[0] * rc[0] * Jf[0][f] + wc[1] * rc[1] * Jf[1][f];
-        }
-      }
-      // ---- per-term blocks: H_ij, H_jj, v_j, H_jf  -> reduce over the tile, add in fp64
-      if (fj) {
-        float tv[NT];
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-          for (int c = 0; c < 6; ++c)
-            tv[r * 6 + c] = fi ? (wc[0] * Ji[0][r] * Jj[0][c] + wc[1] * Ji[1][r] * Jj[1][c]) : 0.0f;
-#pragma unroll
-        for (int s = 0; s < 21; ++s) {
-          const int r = SYM_R[s], c = SYM_C[s];
-          tv[36 + s] = wc[0] * Jj[0][r] * Jj[0][c] + wc[1] * Jj[1][r] * Jj[1][c];
-        }
-#pragma unroll
-        for (int q = 0; q < 6; ++q) tv[57 + q] = -(wc[0] * rc[0] * Jj[0][q] + wc[1] * rc[1] * Jj[1][q]);
-        if constexpr (F > 0) {
-#pragma unroll
-          for (int q = 0; q < 6; ++q)
-#pragma unroll
-            for (int f = 0; f < F; ++f)
-              tv[63 + q * F + f] = wc[0] * Jj[0][q] * Jf[0][f] + wc[1] * Jj[1][q] * Jf[1][f];
-        }
-        const float s = block_reduce<NT>(tv, red);
-        const int bj = 6 * G.sj, bi = 6 * si;
-        if (tid < 36) {
-          if (fi) s_add(w, bi + tid / 6, bj + tid % 6, (double)s);
-        } else if (tid < 57) {
-          const int r = SYM_R[tid - 36], c = SYM_C[tid - 36];
-          s_add(w, bj + r, bj + c, (double)s);
-          if (r == c) atomicAdd(&w.Hd[bj + r], (double)s);
-        } else if (tid < 63) {
-          atomicAdd(&w.S[(int64_t)nrow * w.ld + bj + (tid - 57)], (double)s);
-        } else if (tid < NT) {
-          const int q = (tid - 63) / FF, f = (tid - 63) % FF;
-          s_add(w, foff + f, bj + q, (double)s);
-        }
-      }
-    }
-  }
-
-  // ---- frame-level reduction: H_ii, v_i, H_if, H_ff, v_f
-  {
-    float kv[NK];
-#pragma unroll
-    for (int s = 0; s < 21; ++s) kv[s] = hii[s];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) kv[21 + q] = vi[q];
-    if constexpr (F > 0) {
-#pragma unroll
-      for (int q = 0; q < 6 * F; ++q) kv[27 + q] = hif[q];
-#pragma unroll
-      for (int q = 0; q < F * (F + 1) / 2; ++q) kv[27 + 6 * F + q] = hff[q];
-#pragma unroll
-      for (int f = 0; f < F; ++f) kv[27 + 6 * F + F * (F + 1) / 2 + f] = vf[f];
-    }
-    const float s = block_reduce<NK>(kv, red);
-    const int bi = 6 * si;
-    if (tid < 21) {
-      if (si >= 0) {
-        const int r = SYM_R[tid], c = SYM_C[tid];
-        s_add(w, bi + r, bi + c, (double)s);
-        if (r == c) atomicAdd(&w.Hd[bi + r], (double)s);
-      }
-    } else if (tid < 27) {
-      if (si >= 0) atomicAdd(&w.S[(int64_t)nrow * w.ld + bi + (tid - 21)], (double)s);
-    } else if (tid < NK) {
-      if constexpr (F > 0) {
-        int i2 = tid - 27;
-        if (i2 < 6 * F) {
-          if (si >= 0) s_add(w, foff + i2 % F, bi + i2 / F, (double)s);
-        } else if (i2 < 6 * F + F * (F + 1) / 2) {
-          i2 -= 6 * F;
-          const int f = i2 == 0 ? 0 : (i2 == 1 ? 1 : 1), f2 = i2 == 0 ? 0 : (i2 == 1 ? 0 : 1);
-          s_add(w, foff + f, foff + f2, (double)s);
-          if (f == f2) atomicAdd(&w.Hd[foff + f], (double)s);
-        } else {
-          i2 -= 6 * F + F * (F + 1) / 2;
-          atomicAdd(&w.S[(int64_t)nrow * w.ld + foff + i2], (double)s);
-        }
-      }
-    }
-  }
-
-  if (!dfree) return;
-  // ---- finish the disparity block of this pixel: sensor prior, damping (terms.py:258-268, buffer.py:482-489)
-  const int64_t kp = (int64_t)k * P + p;
-  finish_disp(a, k, p, P, flags, d, C, wz);
-  const float Q = inb ? 1.0f / C : 0.0f;
-  if (inb) {
-    w.C[kp] = C;
-    w.wv[kp] = wz;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) w.Ekk[((int64_t)k * 6 + q) * P + p] = Ei[q];
-    if constexpr (F > 0) {
-#pragma unroll
-      for (int f = 0; f < F; ++f) w.Ef[((int64_t)k * 2 + f) * P + p] = Efr[f];
-    }
-  }
-
-  // ---- Schur complement of frame k: S -= E_a Q E_b^T, g -= E_a Q w over all member pairs (solver.py:176-178)
-  // members: 0 = pose i, 1..deg = target poses of the terms, deg+1 = intrinsics
-  const int deg = end - beg;
-  const int nm = deg + 2;
-  for (int ma = 0; ma < nm; ++ma) {
-    float Ea[6] = {0, 0, 0, 0, 0, 0};
-    int base_a = -1, dim_a = 6;
-    if (ma == 0) {
-      if (si >= 0) { base_a = 6 * si;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) Ea[q] = Ei[q]; }
-    } else if (ma == deg + 1) {
-      if constexpr (F > 0) { base_a = foff; dim_a = F;
-#pragma unroll
-        for (int f = 0; f < F; ++f) Ea[f] = Efr[f]; }
-    } else {
-      const int e = w.order[beg + ma - 1];
-      const int pj = (int)a.pj[e];
-      const int sj = ((int)a.pi[e] == pj) ? -1 : w.pose_slot[pj];
-      if (sj >= 0) { base_a = 6 * sj;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) Ea[q] = inb ? w.Ej[((int64_t)e * 6 + q) * P + p] : 0.0f; }
-    }
-    if (base_a < 0) continue;  // wave-uniform
-    float EaQ[6];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) EaQ[q] = Ea[q] * Q;
-    {
-      float gv[6];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) gv[q] = EaQ[q] * wz;
-      const float s = block_reduce<6>(gv, red);
-      if (tid < dim_a) atomicAdd(&w.S[(int64_t)nrow * w.ld + base_a + tid], -(double)s);
-    }
-    for (int mb = ma; mb < nm; ++mb) {
-      float Eb[6] = {0, 0, 0, 0, 0, 0};
-      int base_b = -1, dim_b = 6;
-      if (mb == ma) {
-        base_b = base_a; dim_b = dim_a;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) Eb[q] = Ea[q];
-      } else if (mb == deg + 1) {
-        if constexpr (F > 0) { base_b = foff; dim_b = F;
-#pragma unroll
-          for (int f = 0; f < F; ++f) Eb[f] = Efr[f]; }
-      } else {
-        const int e = w.order[beg + mb - 1];
-        const int pj = (int)a.pj[e];
-        const int sj = ((int)a.pi[e] == pj) ? -1 : w.pose_slot[pj];
-        if (sj >= 0) { base_b = 6 * sj;
-#pragma unroll
-          for (int q = 0; q < 6; ++q) Eb[q] = inb ? w.Ej[((int64_t)e * 6 + q) * P + p] : 0.0f; }
-      }
-      if (base_b < 0) continue;
-      float pr[36];
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) pr[r * 6 + c] = EaQ[r] * Eb[c];
-      const float s = block_reduce<36>(pr, red);
-      if (tid < 36) {
-        const int r = tid / 6, c = tid % 6;
-        if (r < dim_a && c < dim_b) {
-          const int gr = base_a + r, gc = base_b + c;
-          if (ma != mb || r >= c) s_add(w, gr, gc, -(double)s);
-        }
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ accumulate (MFMA)
 //
-// Same contract as ba_accum_kernel, but every reduction over pixels runs on the matrix cores instead of DPP + LDS
+// Every reduction over pixels runs on the matrix cores instead of DPP + LDS
 // trees (the shuffle version spends ~9.5k DPP adds and ~70 workgroup barriers per tile on 1,281 reduced values):
 //   * R1, per term: the lane (= pixel) writes the rows sqrt(w_c) * [Jj_c(6); r_c; Jf_c(F)] of its pixel for both
 //     residual components c into a wave-private LDS tile [16 rows][2 x 64 pixels]; one chain of 32
@@ -701,23 +391,6 @@ constexpr size_t accum_mfma_lds() {
 
 typedef float float4m __attribute__((ext_vector_type(4)));
 
-#ifdef VIPE_BA_STAMPS
-// diagnostic build only (scratch/ba_stamps.py): per-workgroup phase stamps (s_memrealtime, 10 ns ticks)
-__device__ unsigned long long* g_ba_stamps = nullptr;
-#define BA_STAMP(k)                                                                                           \
-  do {                                                                                                        \
-    if (g_ba_stamps && threadIdx.x == 0)                                                                      \
-      g_ba_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
-  } while (0)
-#define SOLVE_STAMP(k)                                                                              \
-  do {                                                                                              \
-    if (g_ba_stamps && threadIdx.x == 0) g_ba_stamps[1 << 16 | (k)] = __builtin_amdgcn_s_memrealtime(); \
-  } while (0)
-#else
-#define BA_STAMP(k)
-#define SOLVE_STAMP(k)
-#endif
-
 template <int CAM, int F>
 __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) void ba_accum_mfma_kernel(BAArgs a) {
   constexpr int FF = F > 0 ? F : 1;
@@ -725,7 +398,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
   constexpr int TPT = 16 / RPT;        // terms per R1 tile
   const vipe_ba_params& prm = a.p;
   const BAWs& w = a.w;
-  if (a.force_simple || w.info[6] > AM_DMAX) return;  // force_simple: 1 = shuffle kernel, 2 = general walk + Schur
+  if (a.force_general || w.info[6] > AM_DMAX) return;  // force_general: the walk + Schur pair takes every graph (vipe_ba_params.solver_options)
   const int k = blockIdx.y;
   const int beg = w.rowptr[k], end = w.rowptr[k + 1];
   if (beg == end) return;
@@ -742,7 +415,6 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
   const int n_free = w.info[0], nrow = w.info[3];
   const int foff = 6 * n_free;
 
-  BA_STAMP(0);
   extern __shared__ __align__(16) float am_smem[];
   float* wbuf = am_smem + wave * AM_WBUF;       // wave-private
   float* accS = am_smem + NWAVE * AM_WBUF;      // [48][49] Schur Gram accumulators
@@ -766,7 +438,6 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     tg[tid] = m;
   }
   __syncthreads();
-  BA_STAMP(1);
 
   const cam::Intr Ii = cam::load_scaled(a.intr + qi * (4 + a.D), a.D, 1.0f / prm.intr_factor);
   const float u = (float)(p % prm.wd), v = (float)(p / prm.wd);
@@ -890,7 +561,6 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     __builtin_amdgcn_wave_barrier();
   }
 
-  BA_STAMP(2);
   // ---- finish the disparity block of this pixel: sensor prior, damping (terms.py:258-268, buffer.py:482-489)
   float sq = 0.0f;
   const int NR = 6 * (deg + 1) + F + 1;  // R2 rows: pose i, targets, intrinsics, w
@@ -977,9 +647,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         }
       }
   }
-  BA_STAMP(3);
   __syncthreads();
-  BA_STAMP(4);
 
   // ---- per-term blocks from the Gram sums (one wave per term)
   for (int t = wave; t < deg; t += NWAVE) {
@@ -1041,7 +709,6 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
-  BA_STAMP(5);
 
   // ---- frame level: H_ii, v_i, H_if, H_ff, v_f
   {
@@ -1091,7 +758,6 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
       }
     }
   }
-  BA_STAMP(6);
 }
 
 // ---- general accumulate (any number of terms per source frame): the same walk with matrix-core Gram reductions, the
@@ -1110,7 +776,7 @@ __global__ __launch_bounds__(TILE) void ba_walk_kernel(BAArgs a) {
   constexpr int TPT = 16 / RPT;        // terms per R1 tile
   const vipe_ba_params& prm = a.p;
   const BAWs& w = a.w;
-  if (a.force_simple == 1 || (a.force_simple == 0 && w.info[6] <= AM_DMAX)) return;  // low-degree graphs: the fused kernel
+  if (!a.force_general && w.info[6] <= AM_DMAX) return;  // low-degree graphs: the fused kernel
   const int k = blockIdx.y;
   const int beg = w.rowptr[k], end = w.rowptr[k + 1];
   if (beg == end) return;
@@ -1668,7 +1334,7 @@ constexpr int SC_GRID = 96;  // tile pairs processed in parallel per frame (the 
 template <int F>
 __global__ __launch_bounds__(TILE) void ba_schur_kernel(BAArgs a) {
   const BAWs& w = a.w;
-  if (!a.mv && (a.force_simple == 1 || (a.force_simple == 0 && w.info[6] <= AM_DMAX))) return;
+  if (!a.mv && !a.force_general && w.info[6] <= AM_DMAX) return;
   const int k = blockIdx.y;
   const int flags = w.fflags[k];
   const int beg = w.rowptr[k], end = w.rowptr[k + 1];
@@ -1878,9 +1544,6 @@ __device__ __forceinline__ void band_solve_body(const BAArgs& a, int lds_doubles
   const int need = RD0 + npr + 64;
   if (t == 0) w.info[5] = 0;
   if (n == 0 || need > lds_doubles || npair > 21 + UPT_ * (BAND_T - 64) || PB + ntail > BAND_T || WBP > (TWO ? 128 : 64) || F > 2) {
-#ifdef VIPE_BA_STAMPS
-    if (t == 0) printf("band solve skipped: n %d need %d lds %d npair %d PB %d ntail %d F %d bandblk %d\n", n, need, lds_doubles, npair, PB, ntail, F, bandblk);
-#endif
     return;
   }
   double* const Tl = L + TL0;
@@ -1891,7 +1554,6 @@ __device__ __forceinline__ void band_solve_body(const BAArgs& a, int lds_doubles
   const double* S = w.S;
   auto bofs = [&](int r, int c) { return r * WBP + c - 6 * (r / 6) + PB; };
   auto tref = [&](int q, int c) -> double& { return Tl[q * (n + 1) + c]; };
-  SOLVE_STAMP(0);
 
   // ---- load (with LM damping on the diagonal, matrix.py:179-186)
   if (t == 0) *failp = 0;
@@ -2009,7 +1671,6 @@ __device__ __forceinline__ void band_solve_body(const BAArgs& a, int lds_doubles
       for (int j = 0; j <= i; ++j) { Dk[i * WBP + j] = A[i][j]; blk[i * 7 + j] = A[i][j]; }
   };
   __syncthreads();
-  SOLVE_STAMP(1);
   if (t == 0 && n_free > 0) factor_diag(0);
   __syncthreads();
 
@@ -2051,7 +1712,6 @@ __device__ __forceinline__ void band_solve_body(const BAArgs& a, int lds_doubles
     }
     __syncthreads();
   }
-  SOLVE_STAMP(2);
   // ---- tail columns (intrinsics unknowns), unblocked
   for (int f = 0; f < F; ++f) {
     const int cf = npr + f;
@@ -2068,7 +1728,6 @@ __device__ __forceinline__ void band_solve_body(const BAArgs& a, int lds_doubles
   }
   // ---- back substitution L^T x = y; y = rhs row (tail row F), solved in place by wave 0
   double* y = &tref(F, 0);
-  SOLVE_STAMP(3);
   if (t < 64) {
     // column-oriented: once x of block kb is known (6x6 triangular solve, replicated in every lane from broadcast
     // LDS reads, reciprocal pivots), lane c subtracts its contribution from y of band row 6 kb - PB + c right away,
@@ -2140,7 +1799,6 @@ __device__ __forceinline__ void band_solve_body(const BAArgs& a, int lds_doubles
     }
   }
   __syncthreads();
-  SOLVE_STAMP(4);
   const bool bad = *failp != 0;
   if (t == 0) {
     if (bad) w.info[2] += 1;
@@ -2153,7 +1811,6 @@ __device__ __forceinline__ void band_solve_body(const BAArgs& a, int lds_doubles
   }
   __syncthreads();
   apply_retraction(a, t, BAND_T, n_free);
-  SOLVE_STAMP(5);
 }
 
 // Two-chain ("burn at both ends") form of the band solve for pose-only systems (no intrinsics columns): the sequential
@@ -2460,7 +2117,7 @@ __global__ __launch_bounds__(2 * BAND_T) void ba_solve_band_kernel(BAArgs a, int
 // Sets info[5] = 2 when it solved the system.
 constexpr int DN_T = 512;
 
-__global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_doubles, int dbg) {
+__global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_doubles) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* const L = reinterpret_cast<double*>(smem_raw);
   const vipe_ba_params& prm = a.p;
@@ -2480,8 +2137,6 @@ __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_
   const double* S = w.S;
   const int ld = w.ld;
   if (t == 0) *failp = 0;
-  long long tprev = dbg ? wall_clock64() : 0, tacc[6] = {0, 0, 0, 0, 0, 0};
-#define DN_STAMP(i) if (dbg && t == 0) { const long long tn = wall_clock64(); tacc[i] += tn - tprev; tprev = tn; }
   // ---- load with LM damping on the diagonal (matrix.py:179-186): one row per wave and pass, lanes over the columns;
   //      unrolled so that eight rows (x up to 4 column passes) are in flight per wave - the loop is otherwise one L2
   //      round trip per row
@@ -2551,10 +2206,8 @@ __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_
     }
   };
   __syncthreads();
-  DN_STAMP(0)
   if (t < 64) factor_diag(0);
   __syncthreads();
-  DN_STAMP(1)
   for (int kb = 0; kb < nblk; ++kb) {
     const int j0 = 6 * kb, bw = min(6, n - j0), R0 = j0 + bw;
     // panel: rows R0..n (row n = rhs)
@@ -2576,7 +2229,6 @@ __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_
       }
     }
     __syncthreads();
-    DN_STAMP(2)
     const int nbw = min(6, n - R0);  // width of the next diagonal block
     if (t < 64) {
       // wave 0: the next diagonal block's entries (i, j), j <= i < nbw, then its factorisation by lane 0
@@ -2595,7 +2247,6 @@ __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       if (kb + 1 < nblk) factor_diag(kb + 1);
-      DN_STAMP(5)
     } else {
       // waves 1..7: rows r >= R0 + nbw (the rows of the next diagonal block belong to wave 0), columns R0 <= c <= min(r, n - 1).
       // Four columns per pass: their operands are fetched together and the four dot products are independent chains
@@ -2632,7 +2283,6 @@ __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_
       }
     }
     __syncthreads();
-    DN_STAMP(3)
   }
   // ---- back substitution L^T x = y (y = row n), wave 0, column oriented: once x of block kb is known every lane
   //      subtracts its columns' contributions from y
@@ -2690,11 +2340,6 @@ __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_
     }
   }
   __syncthreads();
-  DN_STAMP(4)
-  if (dbg && t == 0)
-    printf("[ba_solve_dense n=%d] load %lld diag0 %lld panel %lld lookahead %lld wait-for-update %lld backsub %lld (x10ns)\n", n,
-           tacc[0], tacc[1], tacc[2], tacc[5], tacc[3], tacc[4]);
-#undef DN_STAMP
   const bool bad = *failp != 0;
   if (t == 0) {
     if (bad) w.info[2] += 1;
@@ -2734,7 +2379,7 @@ struct SolveLds {
 
 
 
-__global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_cap, long long* dbg) {
+__global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_cap) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   SolveLds& sh = *reinterpret_cast<SolveLds*>(smem_raw);
   double* PT = reinterpret_cast<double*>(smem_raw + ((sizeof(SolveLds) + 15) / 16) * 16);  // [NB][panel_cap]
@@ -2744,9 +2389,6 @@ __global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_c
   const int n = w.info[3], n_free = w.info[0];
   const int ld = w.ld;
   double* S = w.S;
-  long long tprev = dbg ? wall_clock64() : 0;
-  long long tacc[5] = {0, 0, 0, 0, 0};
-#define STAMP(i) if (dbg && t == 0) { long long tn = wall_clock64(); tacc[i] += tn - tprev; tprev = tn; }
   if (t == 0) sh.fail = 0;
   if (n == 0 || w.info[5] != 0 || n > CT_MIN_N) return;  // an LDS solver (band: 1, dense: 2) took the system; large ones: tiled
   // LM damping on the diagonal: += ep + lambda * diag(H)  (matrix.py:179-186)
@@ -2807,7 +2449,6 @@ __global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_c
       }
     }
     __syncthreads();
-    STAMP(0)
     // ---- 2. panel rows r0..n (row n = rhs)
     // Rows below the block that can be nonzero in these columns: the band [r0, e1) of pose rows plus the dense
     // tail [t0, n] (intrinsics rows and the rhs row).  Compact panel index pr -> global row prow(pr).
@@ -2839,7 +2480,6 @@ __global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_c
       }
     }
     __syncthreads();
-    STAMP(1)
     // ---- 3. trailing update A22 -= P P^T on the fp64 matrix cores (v_mfma_f64_16x16x4_f64): 16x16 tiles of the
     //         lower triangle, one tile per wave at a time, K = 24 = 6 MFMAs; operands straight from the
     //         transposed panel in LDS (lane l: A[row l&15][k l>>4], B[k l>>4][col l&15]).
@@ -2900,7 +2540,6 @@ __global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_c
       }
     }
     __syncthreads();
-    STAMP(2)
   }
 
   // ---- backward substitution L^T x = y (y = row n).
@@ -2937,7 +2576,6 @@ __global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_c
     }
   }
   __syncthreads();
-  STAMP(3)
   // (ii) blocks from the last to the first: x_k = Lkk^-T y_k (a 24x24 mat-vec, lane j: sum_m Linv[m][j] y[m]),
   //      then y_c -= sum_m L[k0+m][c] x_k[m] for every earlier column c (coalesced row reads).
   double* yrow = S + (int64_t)n * ld;
@@ -2971,10 +2609,6 @@ __global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_c
     }
     __syncthreads();
   }
-  STAMP(4)
-  if (dbg && t == 0)
-    printf("[ba_solve n=%d] diag %lld panel %lld trailing %lld invert %lld backsub %lld (x10ns)\n", n, tacc[0], tacc[1],
-           tacc[2], tacc[3], tacc[4]);
   const bool bad = sh.fail != 0;
   if (t == 0 && bad) w.info[2] += 1;
   for (int dd = t; dd < n; dd += SOLVE_T) {
@@ -3021,10 +2655,9 @@ __device__ __forceinline__ bool chol_active(const BAArgs& a, int& n) {
   return n > CT_MIN_N && a.w.info[5] == 0;
 }
 
-__global__ __launch_bounds__(256) void chol_potrf_kernel(BAArgs a, int k, int dbg) {
+__global__ __launch_bounds__(256) void chol_potrf_kernel(BAArgs a, int k) {
   int n;
   if (!chol_active(a, n)) return;
-  long long ts0 = dbg ? wall_clock64() : 0, ts1 = 0, ts2 = 0, ts3 = 0;
   const int c0 = CT * k;
   if (c0 >= n) return;
   const int bw = min(CT, n - c0);
@@ -3133,7 +2766,6 @@ __global__ __launch_bounds__(256) void chol_potrf_kernel(BAArgs a, int k, int db
         __syncthreads();
       }
     }
-    if (dbg) ts1 = wall_clock64();
     if (wave == 0 && bad) fail = 1;
     // the rhs row leaves for the workspace; the tile itself keeps the factor only (identity beyond bw, zeros above the
     // diagonal - the trailing updates of the diagonal 16 x 16 tiles wrote there)
@@ -3149,7 +2781,6 @@ __global__ __launch_bounds__(256) void chol_potrf_kernel(BAArgs a, int k, int db
     const int r = i >> 6, c = i & 63;
     if (r < bw && c <= r) S[(int64_t)(c0 + r) * ld + c0 + c] = Ls[r][c];
   }
-  if (dbg) ts2 = wall_clock64();
   // ---- inverse of the factor tile.  (1) the four 16 x 16 diagonal blocks, one thread per column: forward substitution,
   //      column oriented - as soon as x[i] is known every later row's partial sum takes its term, so the dependent chain
   //      per step is one multiply and one fused multiply-add (a row-oriented sum is a chain of i of them)
@@ -3203,7 +2834,6 @@ __global__ __launch_bounds__(256) void chol_potrf_kernel(BAArgs a, int k, int db
   double* Wk = w.Wi + (int64_t)k * CT * CT;
   for (int i = t; i < CT * CT; i += 256) Wk[i] = Li[i >> 6][i & 63];
   if (t == 0 && fail) w.info[7] = 1;
-  if (dbg && t == 0 && k == 1) { ts3 = wall_clock64(); printf("[chol_potrf] load+factor %lld store %lld inverse %lld (x10ns)\n", ts1 - ts0, ts2 - ts1, ts3 - ts2); }
 }
 
 // X = A L^-T for the tile rows below tile k; grid = tile rows (exits beyond the matrix)
@@ -3387,7 +3017,7 @@ inline void launch_tiled_cholesky(const BAArgs& a, hipStream_t s) {
   const int T = (nmax + 1 + CT - 1) / CT;  // tile rows incl. the rhs row
   const int Tc = (nmax + CT - 1) / CT;
   for (int k = 0; k < Tc; ++k) {
-    chol_potrf_kernel<<<1, 256, 0, s>>>(a, k, getenv("VIPE_BA_DEBUG_TIMING") ? 1 : 0);
+    chol_potrf_kernel<<<1, 256, 0, s>>>(a, k);
     const int m = T - 1 - k;
     if (m > 0) {
       chol_trsm_kernel<<<m, 256, 0, s>>>(a, k);
@@ -3529,7 +3159,7 @@ int run_iters(const BAArgs& a, hipStream_t s, int* pieces_done) {
       ba_walk_rig_kernel<CAM><<<dim3(tiles, a.nF), TILE, walk_rig_lds(), s>>>(a);
       ba_schur_kernel<0><<<dim3(SC_GRID, a.nF), TILE, 0, s>>>(a);
       if (ev && hipEventRecord(ev, s) != hipSuccess) return VIPE_EINVAL;
-      ba_solve_kernel<<<1, SOLVE_T, solve_lds, s>>>(a, panel_cap, nullptr);
+      ba_solve_kernel<<<1, SOLVE_T, solve_lds, s>>>(a, panel_cap);
       launch_tiled_cholesky(a, s);
       if (overlap) {
         const int rc = overlap_piece(a.p, ev, it, a.p.n_iters, true);
@@ -3540,18 +3170,17 @@ int run_iters(const BAArgs& a, hipStream_t s, int* pieces_done) {
       continue;
     }
     // path_hint (vipe_ba_params): what the caller learnt from an earlier call with this plan; 0 launches everything
-    const int hint = a.force_simple ? 0 : a.p.path_hint;
+    const int hint = a.force_general ? 0 : a.p.path_hint;
     if (!(hint & 2)) ba_accum_mfma_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, accum_mfma_lds(), s>>>(a);
     if (!(hint & 1)) {
       ba_walk_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, walk_lds(), s>>>(a);
       ba_schur_kernel<F><<<dim3(SC_GRID, a.nF), TILE, 0, s>>>(a);
     }
-    if (a.force_simple == 1) ba_accum_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, 0, s>>>(a);
     if (ev && hipEventRecord(ev, s) != hipSuccess) return VIPE_EINVAL;
     if (!(hint & 8)) ba_solve_band_kernel<<<1, 2 * BAND_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)));
-    if (!(hint & 16)) ba_solve_dense_kernel<<<1, DN_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)), getenv("VIPE_BA_DEBUG_TIMING") ? 1 : 0);
+    if (!(hint & 16)) ba_solve_dense_kernel<<<1, DN_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)));
     if (!(hint & 4)) {
-      ba_solve_kernel<<<1, SOLVE_T, solve_lds, s>>>(a, panel_cap, getenv("VIPE_BA_DEBUG_TIMING") ? (long long*)(a.w.Hd + nmax) : nullptr);
+      ba_solve_kernel<<<1, SOLVE_T, solve_lds, s>>>(a, panel_cap);
       launch_tiled_cholesky(a, s);
     }
     if (overlap) {
@@ -3565,13 +3194,6 @@ int run_iters(const BAArgs& a, hipStream_t s, int* pieces_done) {
 }
 
 }  // namespace
-
-#ifdef VIPE_BA_STAMPS
-VIPE_EXPORT int vipe_diag_set_ba_stamps(void* d_buf) {
-  unsigned long long* p = (unsigned long long*)d_buf;
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ba_stamps), &p, sizeof(p));
-}
-#endif
 
 VIPE_EXPORT int64_t vipe_dense_ba_workspace_bytes(const vipe_ba_params* p) {
   if (!p || p->n_poses <= 0 || p->n_views <= 0 || p->ht <= 0 || p->wd <= 0 || p->M < 0) return VIPE_EINVAL;
@@ -3602,11 +3224,8 @@ VIPE_EXPORT int vipe_dense_ba(const vipe_ba_params* p, float* d_poses, float* d_
   a.mv = is_multiview(*p) ? 1 : 0;
   a.nintr = tail_intr(*p);
   a.ntail = a.nintr + tail_rig(*p);
-  a.force_simple = getenv("VIPE_BA_ACCUM_SIMPLE") ? 1 : (getenv("VIPE_BA_ACCUM_GENERAL") ? 2 : 0);
-  {
-    const char* b2 = getenv("VIPE_BA_BAND2");
-    a.band2 = !(b2 && b2[0] == '0');
-  }
+  a.force_general = (p->solver_options & VIPE_BA_OPT_GENERAL_ACCUMULATE) != 0;
+  a.band2 = !(p->solver_options & VIPE_BA_OPT_ONE_CHAIN);
   a.droid = 0;
   a.dz_out = nullptr;
   hipStream_t s = as_stream(stream);
@@ -3687,11 +3306,8 @@ VIPE_EXPORT int vipe_ba(float* d_poses, float* d_disps, const float* d_intrinsic
   a.pi = d_ii; a.qi = zeros; a.pj = d_jj; a.qj = zeros; a.di = d_ii;
   a.P = ht * wd; a.nF = n_poses; a.D = 0;
   a.mv = 0; a.nintr = 0; a.ntail = 0;
-  a.force_simple = getenv("VIPE_BA_ACCUM_SIMPLE") ? 1 : (getenv("VIPE_BA_ACCUM_GENERAL") ? 2 : 0);
-  {
-    const char* b2 = getenv("VIPE_BA_BAND2");
-    a.band2 = !(b2 && b2[0] == '0');
-  }
+  a.force_general = 0;
+  a.band2 = 1;
   a.droid = 1;
   a.dz_out = d_dz;
   if (iterations == 0 || t1 == t0) return VIPE_OK;

@@ -1,7 +1,6 @@
 """slam_ext: projective geometry + dense BA (reference: csrc/slam_ext/slam.cpp:31-37)."""
 
 import ctypes
-import os
 
 import torch
 
@@ -88,15 +87,20 @@ def update_finish(coords1, dw, mask, target, weight, eta, du, damping):
                                    E, n_src, ht, wd, stream_ptr(coords1)), "update_finish")
 
 
+BA_OPT_ONE_CHAIN, BA_OPT_GENERAL_ACCUMULATE = 1, 2  # VIPE_BA_OPT_* (include/vipe_amd.h)
+PLAN_REUSE = True  # False: rebuild the edge plan on every call and launch every kernel of both paths (validation aid)
+
+
 def dense_ba(poses, disps, disps_sens, intrinsics, rig, target, weight, disp_damping, pi, qi, pj, qj, di, t0, t1,
              n_iters, pose_damping, pose_ep, motion_only=False, limited_disp=False, optimize_intrinsics=False,
              optimize_rig_rotation=False, camera="pinhole", alpha=0.001, n_poses=None, want_info=False, state=None,
-             plan_key=None, overlap=None):
+             plan_key=None, overlap=None, solver_options=0):
     """Live dense BA (GraphBuffer.bundle_adjustment, buffer.py:373-525), IN PLACE on poses / disps / intrinsics.
 
     `overlap` = (stream address, vipe_overlap_fn address, user address) or None: independent work of the caller that the
     library enqueues on that stream in max(n_iters, 1) pieces, each behind the start of a Gauss-Newton iteration's
-    single-workgroup solve (include/vipe_amd.h, vipe_overlap_fn).
+    single-workgroup solve (include/vipe_amd.h, vipe_overlap_fn).  `solver_options`: VIPE_BA_OPT_* bits (BA_OPT_ONE_CHAIN,
+    BA_OPT_GENERAL_ACCUMULATE) - the general forms of the specialised kernels, for validating one against the other.
 
     poses [>=n_poses,7]; disps, disps_sens, disp_damping [>=n_poses*V,ht,wd] (flattened views);
     target, weight [M,ht*wd,2]; pi..di [M] int64.  `n_poses` bounds the pose/frame indices that occur
@@ -114,7 +118,7 @@ def dense_ba(poses, disps, disps_sens, intrinsics, rig, target, weight, disp_dam
                  pose_damping=float(pose_damping), pose_ep=float(pose_ep), motion_only=int(motion_only),
                  limited_disp=int(limited_disp), optimize_intrinsics=int(optimize_intrinsics),
                  optimize_rig_rotation=int(optimize_rig_rotation), camera=CAMERA_CODE[camera], alpha=float(alpha),
-                 weight_scale=0.001, intr_factor=8.0, reuse_plan=0, path_hint=0)
+                 weight_scale=0.001, intr_factor=8.0, reuse_plan=0, path_hint=0, solver_options=int(solver_options))
     if overlap is not None:
         p.overlap_stream, p.overlap_fn, p.overlap_user = overlap
     L = lib()
@@ -134,12 +138,12 @@ def dense_ba(poses, disps, disps_sens, intrinsics, rig, target, weight, disp_dam
         key = None if plan_key is None else (plan_key, ws.data_ptr(), n_poses, V, ht, wd, M, int(t0), int(t1), int(motion_only),
                                              int(limited_disp), int(optimize_intrinsics), int(optimize_rig_rotation), camera,
                                              tuple(int(x.data_ptr()) for x in (pi, qi, pj, qj, di)))
-        p.reuse_plan = int(key is not None and state.get("key") == key and not os.environ.get("VIPE_AMD_BA_NO_PLAN_REUSE"))
+        p.reuse_plan = int(key is not None and state.get("key") == key and PLAN_REUSE)
         # a call that launches nothing (no terms / no iterations) leaves the workspace as it found it: it vouches for nothing
         state["key"] = key if (M > 0 and int(n_iters) > 0) else None
         p.path_hint = _path_hint(state, key)
     learn = state is not None and key is not None and p.path_hint == 0 and "pending" not in state and M > 0 and n_iters > 0 \
-        and not torch.cuda.is_current_stream_capturing() and not os.environ.get("VIPE_AMD_BA_NO_PLAN_REUSE")
+        and not torch.cuda.is_current_stream_capturing() and PLAN_REUSE
     info = torch.zeros(8, dtype=torch.int32, device=poses.device) if (want_info or learn) else None
     check(L.vipe_dense_ba(ctypes.byref(p), ptr(poses), ptr(disps), ptr(disps_sens), ptr(intrinsics), ptr(rig),
                           ptr(target), ptr(weight), ptr(disp_damping), ptr(_i64(pi)), ptr(_i64(qi)), ptr(_i64(pj)),
@@ -155,7 +159,7 @@ def dense_ba(poses, disps, disps_sens, intrinsics, rig, target, weight, disp_dam
 
 def _path_hint(state, key):
     """vipe_ba_params.path_hint for the plan `key` of this caller, or 0 while nothing has been learnt about it yet."""
-    if key is None or os.environ.get("VIPE_AMD_BA_NO_PLAN_REUSE"):
+    if key is None or not PLAN_REUSE:
         return 0
     hints = state.setdefault("hints", {})
     pend = state.get("pending")

@@ -86,10 +86,13 @@ class FactorGraph:
         # stream in the shadow of the previous iteration's BA; None whenever net_n / the edge set changed since
         self._gate_state = None
         self._side = None
-        self.gate_overlap_min_edges = int(os.environ.get("VIPE_AMD_GATE_OVERLAP_MIN_EDGES", "64"))
-        self.gate_overlap_mode = os.environ.get("VIPE_AMD_GATE_OVERLAP", "gated")  # "gated" | "free" (A/B)
-        self.gate_overlap_share = float(os.environ.get("VIPE_AMD_GATE_OVERLAP_SHARE", "0.5"))
-        self.gate_overlap_fractions = [float(x) for x in os.environ.get("VIPE_AMD_GATE_OVERLAP_FRACTIONS", "0.4,0.4,0.2").split(",")]
+        # tuning of that stage ("the BA's shadow"): taken from this many active edges on; released by
+        # the BA per Gauss-Newton iteration ("gated") or launched at once ("free"); share of the edges whose z|r part is
+        # staged; shares of the pieces
+        self.gate_overlap_min_edges = 64
+        self.gate_overlap_mode = "gated"
+        self.gate_overlap_share = 0.5
+        self.gate_overlap_fractions = [0.4, 0.4, 0.2]
         self.ii_inac = torch.as_tensor([], dtype=torch.long, device=device)
         self.jj_inac = torch.as_tensor([], dtype=torch.long, device=device)
         self.target_inac = torch.zeros([1, 0, ht, wd, 2], device=device, dtype=torch.float)

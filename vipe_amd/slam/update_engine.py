@@ -21,7 +21,6 @@ scratch/miopen_ab.py (diagnostic, not importable from the package).
 """
 
 import ctypes
-import os
 
 import torch
 
@@ -70,7 +69,7 @@ class UpdateEngine:
         # second stream of the natively sequenced operator (vipe_update_buffers.side_stream): worth its four event
         # operations only when the kernels are long enough, i.e. for large edge sets
         self._op_side = None
-        self.op_side_min_edges = int(os.environ.get("VIPE_AMD_OP_SIDE_MIN_EDGES", "64"))
+        self.op_side_min_edges = 64
         self._pack_all()
 
     # ------------------------------------------------------------------ weights
@@ -154,7 +153,7 @@ class UpdateEngine:
         """Initial accumulators are implemented by the tile convolutions (csrc/conv_mfma.hip): the 4 x 64 tiling for
         grids made of such tiles, the flat tiling for every other grid up to 126 columns - i.e. every grid the
         reference's resize to 384 x 512 pixels of area produces (vipe/slam/system.py:46-59: 41 x 73 for 16:9 video)."""
-        return ((wd % 64 == 0 and ht % 4 == 0) or wd <= 126) and os.environ.get("VIPE_AMD_GATE_SPLIT", "1") != "0"
+        return (wd % 64 == 0 and ht % 4 == 0) or wd <= 126
 
     def gate_context(self, xbuf):
         """The part of the three GRU gate convolutions that only depends on the context features `inp`
