@@ -317,6 +317,10 @@ int vipe_iproj(const float* d_poses, const float* d_disps, const float* d_intrin
  * ------------------------------------------------------------------------------------------- */
 int vipe_scatter(const void* d_src, const int64_t* d_index, void* d_out, int64_t* d_arg_out, int64_t outer,
                  int64_t src_dim, int64_t inner, int64_t out_dim, int reduce, int dtype, void* stream);
+/* the same with index [src_dim]: one slot per ROW of the scattered dimension (what scatter_mean's callers pass,
+ * droid_net.py:420-421) - no int64 copy of src's shape.  Rows with a slot outside [0, out_dim) are skipped by both. */
+int vipe_scatter_rows(const void* d_src, const int64_t* d_index, void* d_out, int64_t* d_arg_out, int64_t outer,
+                      int64_t src_dim, int64_t inner, int64_t out_dim, int reduce, int dtype, void* stream);
 
 /* The same reductions over HOST memory (float32 / float64), for CPU tensors handed to the Python-level scatter API
  * (vipe/ext/scatter.py:24-63 accepts them through torch.scatter_add_).  Sequential and deterministic; min / max ties

@@ -3,6 +3,7 @@
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -276,6 +277,20 @@ def test_depth_artifacts_round_trip_and_exr_layout(tmp_path):
         z.writestr("00003.exr", b"not an exr file")
     got = list(artifacts.read_depth_artifacts(str(p)))
     assert got[2][0] == 3 and got[2][1].shape == (37, 53) and bool(torch.isnan(got[2][1]).all())
+    # truncated / corrupt members (cut inside the header, the offset table, a compressed chunk) are unreadable frames too,
+    # not a crash of the whole iterator
+    good = exr.write_exr_half(d[2], exr.ZIP_COMPRESSION)
+    for cut in (6, 40, len(good) // 2, len(good) - 3):
+        with pytest.raises(OSError):
+            exr.read_exr_half(good[:cut])
+    flat = bytearray(exr.write_exr_half(np.ones((64, 64)), exr.ZIP_COMPRESSION))  # compressible: chunks are deflate streams
+    flat[-12:-4] = b"\xff" * 8  # garbage inside the last deflate stream
+    with pytest.raises(OSError):
+        exr.read_exr_half(bytes(flat))
+    with zipfile.ZipFile(p, "a") as z:
+        z.writestr("00004.exr", good[:len(good) // 2])
+    got = list(artifacts.read_depth_artifacts(str(p)))
+    assert [g_[0] for g_ in got] == [0, 2, 3, 4] and bool(torch.isnan(got[3][1]).all())
 
 
 def test_growable_store_append_and_select_match_cat_and_index():

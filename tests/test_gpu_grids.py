@@ -553,3 +553,35 @@ def test_bench_two_ranks_on_one_card_as_a_child_process():
     cfg = line["config"]
     assert cfg["result_gather"]["clips"] == 2 and cfg["result_gather"]["inside_timed_region"] and cfg["state_finite"]
     assert cfg["result_gather"]["backend"] == "gloo" and cfg["launch"].startswith("hipgraph")
+
+
+def test_staged_gate_state_survives_only_while_its_scratch_is_untouched():
+    """One UpdateEngine serves every FactorGraph of an UpdateModule, and a staged gate state (the hidden-state part of the
+    next iteration's gates, computed under the BA) lives in that engine's scratch buffers: when ANOTHER graph runs the
+    operator between two updates of the first, the staged state must be dropped, not consumed stale."""
+    import bench
+    from vipe_amd.slam.factor_graph import FactorGraph
+
+    def run(interleave):
+        g, buf, A = bench.build_problem(dev(), 10, 128, 512, 3, 0, seed=3, depth_prior=False)
+        g2, buf2, tmp = bench.build_problem(dev(), 8, 128, 512, 2, 0, seed=4, depth_prior=False)
+        B = FactorGraph(A.update_op, buf2, dev(), max_factors=-1)   # same module -> same engine, other buffers
+        B.add_factors(torch.from_numpy(g2.ii), torch.from_numpy(g2.jj))
+        del tmp
+        for gr in (A, B):
+            gr.gate_overlap_min_edges = 1
+        A.update(t0=1, t1=10, itrs=2)
+        assert A._gate_state is not None
+        if interleave:
+            B.update(t0=1, t1=8, itrs=2)     # overwrites the engine's pzr / extra / glo with B's
+            assert not A.update_op.engine(dev()).gate_state_matches(A._gate_state, A.net_n, A.pgate)
+        else:
+            assert A.update_op.engine(dev()).gate_state_matches(A._gate_state, A.net_n, A.pgate)
+        A.update(t0=1, t1=10, itrs=2)
+        torch.cuda.synchronize()
+        return buf.poses[:10].clone(), A.net_n.clone(), A.target.clone()
+
+    a, b = run(False), run(True)
+    assert (a[0] - b[0]).abs().max().item() < 1e-4
+    assert (a[1].float() - b[1].float()).abs().max().item() < 1e-2
+    assert (a[2] - b[2]).abs().max().item() < 5e-2

@@ -576,6 +576,19 @@ def test_scatter_ext_against_torch():
     assert r.data_ptr() == acc.data_ptr() and torch.allclose(acc, 1 + torch.zeros(5, 16, device=dev()).index_add_(0, ix, h.float()))
     with pytest.raises(RuntimeError):
         scatter.scatter_sum(h.float(), ix.int(), 0)  # index must be int64
+    # integer sources (Tensor.scatter_add_ in the reference's Python layer): torch's scatter, same values
+    hi = torch.randint(-5, 6, (7, 16), device=dev())
+    assert torch.equal(scatter.scatter_sum(hi, ix, dim=0, dim_size=5), torch.zeros(5, 16, dtype=hi.dtype, device=dev()).index_add_(0, ix, hi))
+    # a slot index beyond `out` writes nothing out of bounds: the rows in range land, the canary behind `out` survives
+    big = torch.zeros(6, 16, device=dev())
+    big[5] = 9.0
+    scatter_ext.scatter_sum(h.float(), torch.tensor([0, 7, 1, 2, 9, 2, 4], device=dev()), 0, big[:5], None)
+    assert (big[5] == 9.0).all() and torch.allclose(big[0], h[0].float()) and torch.allclose(big[2], (h[3] + h[5]).float(), atol=1e-3)
+    # the mean's row count comes from the [E] index, not from an int64 copy of src's shape: wide rows stay cheap
+    wide = torch.randn(7, 3, 5, 4, device=dev())
+    sm = scatter.scatter_mean(wide, ix, dim=0, dim_size=5)
+    refw = torch.zeros(5, 3, 5, 4, device=dev()).index_add_(0, ix, wide) / torch.tensor([2, 1, 3, 1, 1.0], device=dev()).view(5, 1, 1, 1)
+    assert torch.allclose(sm, refw, atol=1e-6)
 
 
 def test_corr_ext_sampler_against_torch_loops():

@@ -7,6 +7,7 @@ There is NO fallback: if the library is missing, `lib()` raises with the build c
 import ctypes
 import os
 import re
+import threading
 
 import torch
 
@@ -103,14 +104,14 @@ class VipeError(RuntimeError):
     pass
 
 
-_RESTORE_DEVICE = None  # set by stream_ptr() when it had to switch devices for one call, undone by check()
+_TLS = threading.local()  # .restore: set by stream_ptr() when it had to switch devices for one call, undone by check()
 
 
 def check(code, what):
-    global _RESTORE_DEVICE
-    if _RESTORE_DEVICE is not None:
-        torch.cuda.set_device(_RESTORE_DEVICE)
-        _RESTORE_DEVICE = None
+    restore = getattr(_TLS, "restore", None)
+    if restore is not None:
+        torch.cuda.set_device(restore)
+        _TLS.restore = None
     if code == 0:
         return
     names = {-1: "VIPE_EINVAL (bad argument)", -2: "VIPE_ENOSPACE (workspace too small)",
@@ -125,13 +126,12 @@ def stream_ptr(t=None):
     `check(lib().vipe_x(..., stream_ptr(t)), "x")`: if `t` lives on another device than the current one, that device is
     made current for the duration of the call (kernel launches and function attributes go to the CURRENT device) and
     `check` switches back - the device guard of the reference's bindings (correlation_sampler.cpp:44-58)."""
-    global _RESTORE_DEVICE
     dev = t.device if t is not None else None
     if dev is not None and dev.type == "cuda" and dev.index is not None:
         cur = torch.cuda.current_device()
         if cur != dev.index:
-            if _RESTORE_DEVICE is None:
-                _RESTORE_DEVICE = cur
+            if getattr(_TLS, "restore", None) is None:
+                _TLS.restore = cur
             torch.cuda.set_device(dev)
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 

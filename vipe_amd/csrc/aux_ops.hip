@@ -151,35 +151,41 @@ __device__ __forceinline__ void atomic_combine<half_t>(half_t* addr, half_t v, i
   } while (old != assumed);
 }
 
-template <typename T>
+// ROWS: `index` is [E] (one slot per row of the scattered dimension, the shape GraphAgg / scatter_mean callers have,
+// droid_net.py:420-421) instead of an int64 copy of src's whole shape.  Rows whose slot lies outside [0, N) are skipped
+// (torch raises for them; nothing is written out of bounds here).
+template <typename T, bool ROWS>
 __global__ void scatter_kernel(const T* __restrict__ src, const int64_t* __restrict__ index, T* __restrict__ out,
                                int64_t E, int64_t K, int64_t N, int64_t numel, int reduce) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t b = i / (E * K), k = i % K;
-    const int64_t idx = index[i];
+    const int64_t idx = ROWS ? index[(i / K) % E] : index[i];
+    if (idx < 0 || idx >= N) continue;
     atomic_combine<T>(out + b * N * K + idx * K + k, src[i], reduce);
   }
 }
-template <typename T>
+template <typename T, bool ROWS>
 __global__ void scatter_arg_kernel(const T* __restrict__ src, const int64_t* __restrict__ index, const T* __restrict__ out,
                                    int64_t* __restrict__ arg, int64_t E, int64_t K, int64_t N, int64_t numel) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t b = i / (E * K), e = (i / K) % E, k = i % K;
-    const int64_t o = b * N * K + index[i] * K + k;
+    const int64_t idx = ROWS ? index[e] : index[i];
+    if (idx < 0 || idx >= N) continue;
+    const int64_t o = b * N * K + idx * K + k;
     if (src[i] == out[o]) arg[o] = e;  // scatter_cuda.cu:50-52 (ties: last writer wins)
   }
 }
 
-template <typename T>
+template <typename T, bool ROWS>
 int run_scatter(const void* src, const int64_t* index, void* out, int64_t* arg, int64_t outer, int64_t E, int64_t K,
                 int64_t N, int reduce, hipStream_t s) {
   const int64_t numel = outer * E * K;
   if (numel == 0) return VIPE_OK;
   const int blocks = (int)std::min<int64_t>((numel + 255) / 256, 8192);
-  scatter_kernel<T><<<blocks, 256, 0, s>>>((const T*)src, index, (T*)out, E, K, N, numel, reduce);
+  scatter_kernel<T, ROWS><<<blocks, 256, 0, s>>>((const T*)src, index, (T*)out, E, K, N, numel, reduce);
   if (reduce >= 3) {
     if (!arg) return VIPE_EINVAL;
-    scatter_arg_kernel<T><<<blocks, 256, 0, s>>>((const T*)src, index, (const T*)out, arg, E, K, N, numel);
+    scatter_arg_kernel<T, ROWS><<<blocks, 256, 0, s>>>((const T*)src, index, (const T*)out, arg, E, K, N, numel);
   }
   return vipe_launch_status();
 }
@@ -314,9 +320,23 @@ VIPE_EXPORT int vipe_scatter(const void* d_src, const int64_t* d_index, void* d_
   VIPE_CHECK_ARG(d_src && d_index && d_out);
   hipStream_t s = as_stream(stream);
   switch (dtype) {
-    case VIPE_F16: return run_scatter<half_t>(d_src, d_index, d_out, d_arg_out, outer, src_dim, inner, out_dim, reduce, s);
-    case VIPE_F32: return run_scatter<float>(d_src, d_index, d_out, d_arg_out, outer, src_dim, inner, out_dim, reduce, s);
-    case VIPE_F64: return run_scatter<double>(d_src, d_index, d_out, d_arg_out, outer, src_dim, inner, out_dim, reduce, s);
+    case VIPE_F16: return run_scatter<half_t, false>(d_src, d_index, d_out, d_arg_out, outer, src_dim, inner, out_dim, reduce, s);
+    case VIPE_F32: return run_scatter<float, false>(d_src, d_index, d_out, d_arg_out, outer, src_dim, inner, out_dim, reduce, s);
+    case VIPE_F64: return run_scatter<double, false>(d_src, d_index, d_out, d_arg_out, outer, src_dim, inner, out_dim, reduce, s);
+  }
+  return VIPE_EINVAL;
+}
+
+VIPE_EXPORT int vipe_scatter_rows(const void* d_src, const int64_t* d_index, void* d_out, int64_t* d_arg_out, int64_t outer,
+                                  int64_t src_dim, int64_t inner, int64_t out_dim, int reduce, int dtype, void* stream) {
+  VIPE_CHECK_ARG(outer >= 0 && src_dim >= 0 && inner >= 0 && out_dim >= 0 && reduce >= 0 && reduce <= 4);
+  if (outer * src_dim * inner == 0) return VIPE_OK;
+  VIPE_CHECK_ARG(d_src && d_index && d_out);
+  hipStream_t s = as_stream(stream);
+  switch (dtype) {
+    case VIPE_F16: return run_scatter<half_t, true>(d_src, d_index, d_out, d_arg_out, outer, src_dim, inner, out_dim, reduce, s);
+    case VIPE_F32: return run_scatter<float, true>(d_src, d_index, d_out, d_arg_out, outer, src_dim, inner, out_dim, reduce, s);
+    case VIPE_F64: return run_scatter<double, true>(d_src, d_index, d_out, d_arg_out, outer, src_dim, inner, out_dim, reduce, s);
   }
   return VIPE_EINVAL;
 }
@@ -536,7 +556,7 @@ __global__ __launch_bounds__(256) void nearest_kernel(const float* __restrict__ 
 }
 }  // namespace
 
-extern "C" VIPE_EXPORT int vipe_nearest_neighbours(const float* d_query, int qdim, const float* d_tree, int tdim, int64_t M,
+VIPE_EXPORT int vipe_nearest_neighbours(const float* d_query, int qdim, const float* d_tree, int tdim, int64_t M,
                                                    int64_t N, int knn, float* d_dist, int* d_idx, void* stream) {
   VIPE_CHECK_ARG(M >= 0 && N >= 0 && qdim >= 1 && qdim <= 3 && tdim >= 1 && tdim <= 3 && knn >= 1 && knn <= NN_KMAX);
   VIPE_CHECK_ARG(N >= knn && N <= 0x7fffffff);

@@ -3133,15 +3133,18 @@ int run_iters(const BAArgs& a, hipStream_t s, int* pieces_done) {
   const size_t solve_lds = fixed + (size_t)NB * panel_cap * sizeof(double);
   const size_t band_lds = 158 * 1024;
   static std::atomic<uint64_t> attr_set{0};  // bit d: set on device d
-  if (vipe_first_on_device(attr_set)) {
+  vipe_once_per_device(attr_set, [] {
     (void)hipFuncSetAttribute((const void*)ba_solve_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ba_solve_dense_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)chol_backsub_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-  }
-  (void)hipFuncSetAttribute((const void*)ba_accum_mfma_kernel<CAM, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_mfma_lds());
-  (void)hipFuncSetAttribute((const void*)ba_walk_kernel<CAM, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds());
-  (void)hipFuncSetAttribute((const void*)ba_walk_rig_kernel<CAM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_rig_lds());
+  });
+  static std::atomic<uint64_t> tmpl_set{0};  // one per <CAM, F> instantiation of this function
+  vipe_once_per_device(tmpl_set, [] {
+    (void)hipFuncSetAttribute((const void*)ba_accum_mfma_kernel<CAM, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_mfma_lds());
+    (void)hipFuncSetAttribute((const void*)ba_walk_kernel<CAM, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds());
+    (void)hipFuncSetAttribute((const void*)ba_walk_rig_kernel<CAM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_rig_lds());
+  });
   // S / Hd start each accumulation zeroed: by ba_retract_kernel of the previous iteration when it runs (not motion_only),
   // also across calls when the caller vouches for the workspace (reuse_plan: same key, hence the same motion_only), else
   // by memsets

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <mutex>
 
 #include "../../include/vipe_amd.h"
 
@@ -20,13 +21,21 @@ static inline int vipe_launch_status() {
   return e == hipSuccess ? VIPE_OK : (int)e;
 }
 
-// true exactly once per (call site, device): hipFuncSetAttribute is a per-device setting, and a process may drive
-// several devices (one process per GPU is the deployment model, but the library must not depend on it)
-static inline bool vipe_first_on_device(std::atomic<uint64_t>& seen) {
+// Runs `fn` exactly once per (call site, device) and returns only when it HAS run: hipFuncSetAttribute is a per-device
+// setting (a process may drive several devices; one process per GPU is the deployment model, but the library must not
+// depend on it), and a second host thread must not launch a kernel that needs > 64 KiB of dynamic LDS before the first
+// one has raised the limit - the bit is published after `fn`, under a lock.
+template <typename F>
+static inline void vipe_once_per_device(std::atomic<uint64_t>& done, F&& fn) {
   int d = 0;
   (void)hipGetDevice(&d);
   const uint64_t bit = 1ull << (d & 63);
-  return !(seen.fetch_or(bit) & bit);
+  if (done.load(std::memory_order_acquire) & bit) return;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.load(std::memory_order_relaxed) & bit) return;
+  fn();
+  done.fetch_or(bit, std::memory_order_release);
 }
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }

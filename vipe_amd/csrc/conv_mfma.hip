@@ -1254,7 +1254,7 @@ namespace {
 // one hipFuncSetAttribute per (kernel, device): the dynamic-LDS ceiling of every kernel that may ask for > 64 KiB
 template <typename K>
 void allow_lds(K kernel, std::atomic<uint64_t>& seen, size_t bytes) {
-  if (vipe_first_on_device(seen)) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  vipe_once_per_device(seen, [&] { (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); });
 }
 constexpr size_t MAX_LDS = 160 * 1024;
 

@@ -417,11 +417,11 @@ static int build_impl(const void* d_f1, const void* d_f2, const int64_t* d_idx1,
   for (int i = 0; i < 4; ++i) a.lv[i] = i < num_levels ? (half_t*)h_levels[i] : nullptr;
   a.B = B; a.h = h; a.w = w; a.nlev = num_levels; a.base = base;
   static std::atomic<uint64_t> attr{0};  // bit d: set on device d
-  if (vipe_first_on_device(attr)) {
+  vipe_once_per_device(attr, [] {
     (void)hipFuncSetAttribute((const void*)corr_pyramid_build_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS);
     (void)hipFuncSetAttribute((const void*)corr_pyramid_build_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS);
     (void)hipFuncSetAttribute((const void*)corr_pyramid_build_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS);
-  }
+  });
   const dim3 grid((unsigned)nwg);
   if (prepared) corr_pyramid_build_kernel<true, true><<<grid, 512, PB_LDS, as_stream(stream)>>>(a);
   else if (layout == VIPE_PYRAMID_BLOCKED) corr_pyramid_build_kernel<true><<<grid, 512, PB_LDS, as_stream(stream)>>>(a);

@@ -79,7 +79,15 @@ def write_exr_half(depth, compression=ZIP_COMPRESSION):
 
 
 def read_exr_half(blob):
-    """bytes of a single-part scan-line OpenEXR file with a channel `Z` (HALF or FLOAT) -> float16 / float32 [H,W]"""
+    """bytes of a single-part scan-line OpenEXR file with a channel `Z` (HALF or FLOAT) -> float16 / float32 [H,W].
+    Truncated or corrupt data raises OSError (whatever the parser tripped over), so that callers have ONE failure to catch."""
+    try:
+        return _read_exr_half(blob)
+    except (struct.error, zlib.error, IndexError, KeyError, ValueError) as e:
+        raise OSError(f"unreadable EXR data: {type(e).__name__}: {e}") from e
+
+
+def _read_exr_half(blob):
     magic, version = struct.unpack_from("<ii", blob, 0)
     if magic != MAGIC or (version & 0xFF) != 2 or (version & 0x1E00):
         raise OSError("not a single-part scan-line OpenEXR file")

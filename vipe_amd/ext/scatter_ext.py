@@ -25,10 +25,20 @@ def _expand_index(index, src, dim):
     if index.dim() == 1 and src.dim() > 1:
         index = index.view((1,) * dim + (-1,))
     index = index.view(tuple(index.shape) + (1,) * (src.dim() - index.dim()))
-    return index.expand(src.shape).contiguous()
+    return index.expand(src.shape)
 
 
-def _launch(src, index, out, arg, dim, reduce):
+def _row_index(index, src, dim):
+    """the index as one slot per row of `dim` ([src.shape[dim]] int64) when that is all it says - a 1-D index, or one
+    whose other dimensions are 1 (what scatter_mean / scatter_add callers pass: droid_net.py:420-421) - else None"""
+    if index.dim() == 1:
+        return index.contiguous() if index.shape[0] == src.shape[dim] else None
+    if index.dim() <= src.dim() and all(int(s) == 1 for i, s in enumerate(index.shape) if i != dim) and index.shape[dim] == src.shape[dim]:
+        return index.reshape(-1).contiguous()
+    return None
+
+
+def _launch(src, index, out, arg, dim, reduce, rows):
     outer = 1
     for s in src.shape[:dim]:
         outer *= int(s)
@@ -37,10 +47,13 @@ def _launch(src, index, out, arg, dim, reduce):
         inner *= int(s)
     L = lib()
     if src.is_cuda:
-        check(L.vipe_scatter(ptr(src), ptr(index), ptr(out), ptr(arg), outer, src.shape[dim], inner, out.shape[dim],
-                             _REDUCE[reduce], DTYPE_CODE[src.dtype], stream_ptr(src)), "scatter_" + reduce)
+        fn = L.vipe_scatter_rows if rows else L.vipe_scatter
+        check(fn(ptr(src), ptr(index), ptr(out), ptr(arg), outer, src.shape[dim], inner, out.shape[dim],
+                 _REDUCE[reduce], DTYPE_CODE[src.dtype], stream_ptr(src)), "scatter_" + reduce)
     else:
         require(src.dtype in (torch.float32, torch.float64), "scatter on CPU tensors: float32 / float64")
+        if rows:
+            index = _expand_index(index, src, dim).contiguous()
         check(L.vipe_scatter_host(ptr(src), ptr(index), ptr(out), ptr(arg), outer, src.shape[dim], inner, out.shape[dim],
                                   _REDUCE[reduce], DTYPE_CODE[src.dtype]), "scatter_" + reduce)
 
@@ -52,14 +65,19 @@ class _Scatter(torch.autograd.Function):
         require(index.dtype == torch.int64 and index.device == src.device, "index: int64 on src's device")
         dim = dim + src.dim() if dim < 0 else dim
         src_c = src.contiguous()
-        index_x = _expand_index(index, src_c, dim)
+        # one slot per row of `dim` (the usual call): the kernel takes the [E] index as it is; a general index is expanded
+        # to src's shape as the reference does (scatter.cpp:19-26)
+        idx = _row_index(index, src_c, dim)
+        rows = idx is not None
+        if not rows:
+            idx = _expand_index(index, src_c, dim).contiguous()
         fresh = out is None
         if fresh:
             sizes = list(src.shape)
             if dim_size is not None:
                 sizes[dim] = int(dim_size)
             else:  # scatter_cuda.cu:80-85 - the one host read-back of this op
-                sizes[dim] = int(index_x.max()) + 1 if index_x.numel() else 0
+                sizes[dim] = int(idx.max()) + 1 if idx.numel() else 0
             out = torch.full(sizes, _FILL[reduce], dtype=src.dtype, device=src.device)
         else:
             require(out.is_contiguous() and out.dtype == src.dtype and out.device == src.device, "out: contiguous, like src")
@@ -67,26 +85,33 @@ class _Scatter(torch.autograd.Function):
         arg = None
         if reduce in ("min", "max"):
             arg = torch.full(out.shape, src.shape[dim], dtype=torch.int64, device=src.device)
-        _launch(src_c, index_x, out, arg, dim, reduce)
+        _launch(src_c, idx, out, arg, dim, reduce, rows)
         count = None
         if reduce == "mean":  # rows per slot through the same kernel (scatter.cpp:117-122)
-            count = torch.zeros(out.shape, dtype=src.dtype, device=src.device)
-            _launch(torch.ones_like(src_c), index_x, count, None, dim, "sum")
-            count.clamp_(min=1)
+            if rows:  # counted on the index's own shape: a vector [out_dim], broadcast along every other dimension
+                cnt = torch.zeros(out.shape[dim], dtype=torch.float32, device=src.device)
+                _launch(torch.ones(src.shape[dim], dtype=torch.float32, device=src.device), idx, cnt, None, 0, "sum", True)
+                count = cnt.clamp_(min=1).to(src.dtype).view((1,) * dim + (-1,) + (1,) * (src.dim() - dim - 1))
+            else:
+                count = torch.zeros(out.shape, dtype=src.dtype, device=src.device)
+                _launch(torch.ones_like(src_c), idx, count, None, dim, "sum", False)
+                count.clamp_(min=1)
             out.div_(count)
         if arg is not None:
             if fresh:
                 out.masked_fill_(arg == src.shape[dim], 0)  # scatter_cuda.cu:141-142: untouched slots read 0
             ctx.mark_non_differentiable(arg)
-        ctx.dim, ctx.reduce, ctx.n_src = dim, reduce, src.shape[dim]
-        ctx.save_for_backward(index_x, *(t for t in {"sum": (), "mean": (count,), "mul": (src_c, out),
-                                                    "min": (arg,), "max": (arg,)}[reduce]))
+        ctx.dim, ctx.reduce, ctx.n_src, ctx.rows, ctx.src_shape = dim, reduce, src.shape[dim], rows, tuple(src.shape)
+        ctx.save_for_backward(idx, *(t for t in {"sum": (), "mean": (count,), "mul": (src_c, out),
+                                                 "min": (arg,), "max": (arg,)}[reduce]))
         return (out, arg) if arg is not None else out
 
     @staticmethod
     def backward(ctx, g, *_):
         index, *saved = ctx.saved_tensors
         dim, reduce = ctx.dim, ctx.reduce
+        if ctx.rows:  # a stride-0 view of the [E] index in src's shape: gather reads it without a copy
+            index = index.view((1,) * dim + (-1,) + (1,) * (len(ctx.src_shape) - dim - 1)).expand(ctx.src_shape)
         if reduce == "sum":
             gi = g.gather(dim, index)
         elif reduce == "mean":
@@ -102,7 +127,25 @@ class _Scatter(torch.autograd.Function):
         return gi, None, None, None, None, None
 
 
+def _integer_scatter(src, index, dim, out, dim_size, mean):
+    """integer sources (the reference's Python layer accepts them through Tensor.scatter_add_, vipe/ext/scatter.py:24-63;
+    the atomic kernel covers half / float / double): torch's own scatter, no gradient to carry"""
+    dim = dim + src.dim() if dim < 0 else dim
+    idx = _expand_index(index, src, dim)
+    if out is None:
+        sizes = list(src.shape)
+        sizes[dim] = int(dim_size) if dim_size is not None else (int(idx.max()) + 1 if idx.numel() else 0)
+        out = torch.zeros(sizes, dtype=src.dtype, device=src.device)
+    out.scatter_add_(dim, idx, src)
+    if mean:
+        cnt = torch.zeros_like(out).scatter_add_(dim, idx, torch.ones_like(src)).clamp_(min=1)
+        out.copy_(torch.div(out, cnt, rounding_mode="floor"))
+    return out
+
+
 def scatter_sum(src, index, dim, out=None, dim_size=None):
+    if not src.is_floating_point():
+        return _integer_scatter(src, index, dim, out, dim_size, False)
     return _Scatter.apply(src, index, dim, out, dim_size, "sum")
 
 
@@ -111,6 +154,8 @@ def scatter_mul(src, index, dim, out=None, dim_size=None):
 
 
 def scatter_mean(src, index, dim, out=None, dim_size=None):
+    if not src.is_floating_point():
+        return _integer_scatter(src, index, dim, out, dim_size, True)
     return _Scatter.apply(src, index, dim, out, dim_size, "mean")
 
 

@@ -108,10 +108,10 @@ class SLAMSystem:
                 b.disps_sens[k, v] = torch.where(d > 0, d.reciprocal(), d)
             if f.pose is not None and phase == 1:
                 b.poses[k] = (SE3(b.rig[v]) * f.pose.inv()).data
+                b.touch()  # geometry of slot k rewritten from outside: prefetched frame distances are stale
         if phase == 1:
             b.update_disps_sens(self.metric_depth, frame_idx=k)
         b.n_frames += 1
-        b.touch()
 
     @torch.no_grad()
     def run(self, frames, rig=None, camera_type="pinhole"):

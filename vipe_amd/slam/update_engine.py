@@ -70,6 +70,10 @@ class UpdateEngine:
         # operations only when the kernels are long enough, i.e. for large edge sets
         self._op_side = None
         self.op_side_min_edges = 64
+        # A staged gate state (hidden_gate_state / gate_state_job) lives in THIS engine's scratch buffers (pzr, extra, glo),
+        # and one engine serves every FactorGraph of an UpdateModule (frontend, backend, infill): any later call that
+        # writes those buffers bumps the generation, and a state of an older generation no longer matches
+        self._gate_gen = 0
         self._pack_all()
 
     # ------------------------------------------------------------------ weights
@@ -175,6 +179,7 @@ class UpdateEngine:
         the operator, so that it runs while the dense BA (one busy workgroup for most of its time) has the chip."""
         E, H, W, _ = net.shape
         Es = E if n_staged is None else max(1, min(E, int(n_staged)))  # the z|r part is staged for the first Es edges
+        self._gate_gen += 1
         glo = self._buf("glo", (E, 128), torch.float32)
         extra = self._buf("extra", (E, 384), torch.float32)
         pzr = self._buf("pzr", (Es, H, W, 256), torch.float32)
@@ -196,7 +201,7 @@ class UpdateEngine:
             if parts & 2:
                 self._conv(self.zr_n, net, 0, Es, H, W, mode="partial", fout=pzr, accinit=pgate, ai_coff=0)
         return dict(net_ptr=net.data_ptr(), pgate_ptr=pgate.data_ptr(), shape=tuple(net.shape), pzr=pzr, extra=extra,
-                    n_staged=Es)
+                    n_staged=Es, gen=self._gate_gen)
 
     def gate_state_job(self, net, pgate, fractions=None, n_staged=None):
         """The z|r part of `hidden_gate_state(net, pgate)` (parts = 2), not launched: (gate_state dict, overlap triple) for
@@ -206,6 +211,7 @@ class UpdateEngine:
         been joined AND `hidden_gate_state(net, pgate, parts=1)` has run; it keeps the descriptors alive."""
         E_all, H, W, _ = net.shape
         E = E_all if n_staged is None else max(1, min(E_all, int(n_staged)))  # the job covers the first E edges
+        self._gate_gen += 1
         glo = self._buf("glo", (E_all, 128), torch.float32)
         extra = self._buf("extra", (E_all, 384), torch.float32)
         pzr = self._buf("pzr", (E, H, W, 256), torch.float32)
@@ -225,13 +231,12 @@ class UpdateEngine:
             job.bounds, job.n_bounds = ctypes.addressof(bounds), len(cum)
         fn = ctypes.cast(lib().vipe_update_gate_state_piece, ctypes.c_void_p).value
         gs = dict(net_ptr=net.data_ptr(), pgate_ptr=pgate.data_ptr(), shape=tuple(net.shape), pzr=pzr, extra=extra,
-                  n_staged=E, keep=(b, job, bounds))
+                  n_staged=E, keep=(b, job, bounds), gen=self._gate_gen)
         return gs, (lambda stream: (stream.cuda_stream, fn, ctypes.addressof(job)))
 
-    @staticmethod
-    def gate_state_matches(gs, net, pgate):
+    def gate_state_matches(self, gs, net, pgate):
         return (gs is not None and pgate is not None and gs["net_ptr"] == net.data_ptr() and
-                gs["pgate_ptr"] == pgate.data_ptr() and gs["shape"] == tuple(net.shape))
+                gs["pgate_ptr"] == pgate.data_ptr() and gs["shape"] == tuple(net.shape) and gs.get("gen") == self._gate_gen)
 
     def _buf(self, name, shape, dtype=torch.float16):
         t = self._bufs.get(name)
@@ -257,6 +262,8 @@ class UpdateEngine:
         E, H, W, _ = net.shape
         if not self.gate_state_matches(gate_state, net, pgate):
             gate_state = None
+        if gate_state is None:
+            self._gate_gen += 1  # this call writes the global-context scratch (extra, glo) a staged state of another graph reads
         c1 = self._buf("c1", (E, H, W, 128))
         f1 = self._buf("f1", (E, H, W, 128))
         zb = self._buf("z", (E, H, W, 128))
