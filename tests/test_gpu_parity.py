@@ -522,6 +522,23 @@ def test_altcorr_forward_matches_oracle_and_volume_lookup():
     ref = ocorr.altcorr_forward(f1, f2, coords, 3)
     assert out.shape == (B, 2, 49, H, W)
     assert np.abs(out.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+    # the tiled kernel's paths: smooth flow on a ragged grid (windows of a 4 x 8 tile staged in LDS as one box), tiles
+    # whose windows are scattered over the whole map (direct taps), tiles entirely outside it, channel counts that are not
+    # multiples of 32 / 4, and fp16 maps (fp32 accumulation)
+    for (H1, W1, H2, W2, C, spread) in ((41, 73, 41, 73, 128, 1.5), (10, 18, 5, 9, 128, 1.0), (13, 11, 40, 60, 96, 30.0),
+                                        (6, 9, 12, 12, 50, 2.0)):
+        f1 = rng.normal(0, 1, (2, H1, W1, C)).astype(np.float32)
+        f2 = rng.normal(0, 1, (2, H2, W2, C)).astype(np.float32)
+        u, v = np.meshgrid(np.arange(W1, dtype=np.float32) * (W2 / W1), np.arange(H1, dtype=np.float32) * (H2 / H1))
+        coords = (np.stack([u, v], -1)[None, None] + rng.normal(0, spread, (2, 2, H1, W1, 2))).astype(np.float32)
+        coords[1, 1] += 500.0  # one coordinate set far outside the map: all zeros
+        (out,) = droid_net_ext.altcorr_forward(T(f1), T(f2), T(coords), 3)
+        ref = ocorr.altcorr_forward(f1, f2, coords, 3)
+        assert np.abs(out.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max(), (H1, W1, C)
+        assert not out[1, 1].any()
+        (outh,) = droid_net_ext.altcorr_forward(T(f1).half(), T(f2).half(), T(coords), 3)
+        refh = ocorr.altcorr_forward(f1.astype(np.float16).astype(np.float32), f2.astype(np.float16).astype(np.float32), coords, 3)
+        assert np.abs(outh.float().cpu().numpy() - refh).max() <= 2e-3 * np.abs(refh).max(), (H1, W1, C)
 
 
 def test_altcorr_block_matches_corr_block():

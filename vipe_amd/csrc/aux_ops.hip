@@ -10,50 +10,139 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------ altcorr
-// one lane per (b, n, pixel); channels in slabs of 32 (fmap1 slab in registers), each slab's partial dot product
-// is splatted on its own, exactly as the reference kernel orders the additions (altcorr_kernel.cu:50,95-133).
-template <typename T, int R>
-__global__ __launch_bounds__(128) void altcorr_forward_kernel(const T* __restrict__ f1, const T* __restrict__ f2,
-                                                              const float* __restrict__ coords, T* __restrict__ corr,
-                                                              int H1, int W1, int H2, int W2, int N, int C) {
-  constexpr int RD = 2 * R + 1;
-  const int P = H1 * W1;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = blockIdx.y, b = blockIdx.z;
-  if (p >= P) return;
-  const float2 c = reinterpret_cast<const float2*>(coords)[((int64_t)b * N + n) * P + p];
-  const float fx = floorf(c.x), fy = floorf(c.y);
-  const float dx = c.x - fx, dy = c.y - fy;
-  const int bx = (int)fx - R, by = (int)fy - R;
-  float acc[RD * RD];
-#pragma unroll
-  for (int q = 0; q < RD * RD; ++q) acc[q] = 0.0f;
-  const T* a = f1 + ((int64_t)b * P + p) * C;
-  for (int c0 = 0; c0 < C; c0 += 32) {
-    float av[32];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) av[k] = (c0 + k < C) ? (float)a[c0 + k] : 0.0f;
-#pragma unroll
-    for (int iy = 0; iy <= RD; ++iy) {
-#pragma unroll
-      for (int ix = 0; ix <= RD; ++ix) {
-        const int h2 = by + iy, w2 = bx + ix;
-        float s = 0.0f;
-        if (h2 >= 0 && h2 < H2 && w2 >= 0 && w2 < W2) {
-          const T* g = f2 + (((int64_t)b * H2 + h2) * W2 + w2) * C + c0;
-#pragma unroll
-          for (int k = 0; k < 32; ++k) s += av[k] * ((c0 + k < C) ? (float)g[k] : 0.0f);
-        }
-        if (iy > 0 && ix > 0) acc[(iy - 1) + RD * (ix - 1)] += s * (dy * dx);
-        if (iy > 0 && ix < RD) acc[(iy - 1) + RD * ix] += s * (dy * (1 - dx));
-        if (iy < RD && ix > 0) acc[iy + RD * (ix - 1)] += s * ((1 - dy) * dx);
-        if (iy < RD && ix < RD) acc[iy + RD * ix] += s * ((1 - dy) * (1 - dx));
-      }
+// altcorr_forward (altcorr_kernel.cu:26-138): the 7 x 7 bilinear window of a source pixel correlated against the target
+// map WITHOUT a volume - per tap a C-channel dot product.  Workgroup = a 4 x 8 tile of source pixels (the reference's
+// tile) x 8 lanes per pixel, lane j = tap row j of the 8 x 8 integer taps.  Per coordinate set and 32-channel slab:
+//   * the bounding box of the tile's 32 windows (smooth flow: ~11 x 15 positions for 2048 tap reads) is staged in LDS ONCE,
+//     as [4-channel chunk][position] float4 rows (odd pitch: the 8 chunk writes of a position and the 64 lanes' tap reads
+//     spread over the banks) - 128 contiguous bytes per position from L2 instead of a re-gather per tap and pixel;
+//   * lane (pixel, j) forms the 8 dot products of its tap row against the pixel's slab held in registers, takes row j + 1
+//     from its neighbour lane by shuffle and owns output row j: out[j][ox] accumulates the four bilinear contributions in
+//     the reference's order - taps (j, ox), (j, ox + 1), (j + 1, ox), (j + 1, ox + 1), slab after slab (:50, 95-133) -
+//     so every output is written once, from registers (the reference: 4 global read-modify-writes per tap and slab).
+// Windows scattered too widely for the LDS box (> ALT_BOX positions) read their taps straight from L2 with the same
+// arithmetic.  fp32 accumulation for both dtypes; -ffp-contract=off keeps mul and add apart.
+constexpr int ALT_BOX = 383;  // positions of a staged box (odd: it is also the largest pitch)
+
+template <typename T>
+__device__ __forceinline__ float4 alt_load4(const T* p, int c, int C) {
+  // channels c .. c + 3 of a channels-last pixel (zero beyond C)
+  if (c + 4 <= C && (C & 3) == 0) {
+    if constexpr (sizeof(T) == 4) {
+      return *reinterpret_cast<const float4*>(p + c);
+    } else {
+      typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+      const half4 h = *reinterpret_cast<const half4*>(p + c);
+      return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
     }
   }
-  T* o = corr + (((int64_t)b * N + n) * RD * RD) * P + p;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < C) v.x = (float)p[c];
+  if (c + 1 < C) v.y = (float)p[c + 1];
+  if (c + 2 < C) v.z = (float)p[c + 2];
+  if (c + 3 < C) v.w = (float)p[c + 3];
+  return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void altcorr_forward_kernel(const T* __restrict__ f1, const T* __restrict__ f2,
+                                                              const float* __restrict__ coords, T* __restrict__ corr,
+                                                              int H1, int W1, int H2, int W2, int N, int C) {
+  constexpr int R = 3, RD = 7;
+  __shared__ float4 box[8 * ALT_BOX];
+  __shared__ int bb[4];  // box: min x, min y, max x, max y of the windows' first taps
+  const int tid = threadIdx.x, j = tid & 7, pl = tid >> 3;
+  const int tiles_x = (W1 + 7) >> 3;
+  const int ty0 = (blockIdx.x / tiles_x) * 4, tx0 = (blockIdx.x % tiles_x) * 8;
+  const int b = blockIdx.y;
+  const int py = ty0 + (pl >> 3), px = tx0 + (pl & 7);
+  const bool pok = py < H1 && px < W1;
+  const int P = H1 * W1, p = py * W1 + px;
+  const T* a = f1 + ((int64_t)b * P + (pok ? p : 0)) * C;
+  const T* f2b = f2 + (int64_t)b * H2 * W2 * C;
+  for (int n = 0; n < N; ++n) {
+    float2 c = make_float2(0.f, 0.f);
+    if (pok) c = reinterpret_cast<const float2*>(coords)[((int64_t)b * N + n) * P + p];
+    const float fx = floorf(c.x), fy = floorf(c.y);
+    const float dx = c.x - fx, dy = c.y - fy;
+    // keep absurd coordinates (the operator clamps flow to +-64 px, not positions) inside int range
+    const int bx = (int)fminf(fmaxf(fx, -1.0e6f), 1.0e6f) - R, by = (int)fminf(fmaxf(fy, -1.0e6f), 1.0e6f) - R;
+    // ---- bounding box of the tile's windows, clipped to the target map
+    __syncthreads();  // previous coordinate set done with bb / box
+    if (tid == 0) { bb[0] = 1 << 30; bb[1] = 1 << 30; bb[2] = -(1 << 30); bb[3] = -(1 << 30); }
+    __syncthreads();
+    if (pok && j == 0) {
+      atomicMin(&bb[0], bx); atomicMin(&bb[1], by); atomicMax(&bb[2], bx); atomicMax(&bb[3], by);
+    }
+    __syncthreads();
+    const int x0 = max(bb[0], 0), y0 = max(bb[1], 0);
+    const int x1 = min(bb[2] + RD, W2 - 1), y1 = min(bb[3] + RD, H2 - 1);
+    const int BW = x1 - x0 + 1, BH = y1 - y0 + 1;
+    const bool empty = BW <= 0 || BH <= 0;                               // every tap of the tile lies outside the map
+    const bool staged = !empty && (int64_t)BW * BH <= ALT_BOX;
+    const int pitch = (BW * BH) | 1;
+    float acc[RD];
 #pragma unroll
-  for (int q = 0; q < RD * RD; ++q) o[(int64_t)q * P] = (T)acc[q];
+    for (int q = 0; q < RD; ++q) acc[q] = 0.0f;
+    const float w_se = (1 - dy) * (1 - dx), w_sw = (1 - dy) * dx, w_ne = dy * (1 - dx), w_nw = dy * dx;
+    const int ty = by + j;  // this lane's tap row
+    for (int c0 = 0; c0 < C && !empty; c0 += 32) {
+      if (staged) {
+        __syncthreads();  // previous slab's readers are done
+        for (int i = tid; i < BW * BH * 8; i += 256) {
+          const int pos = i >> 3, k4 = i & 7;
+          const int yy = y0 + pos / BW, xx = x0 + pos % BW;
+          box[k4 * pitch + pos] = alt_load4(f2b + ((int64_t)yy * W2 + xx) * C, c0 + 4 * k4, C);
+        }
+        __syncthreads();
+      }
+      float av[32];
+#pragma unroll
+      for (int k4 = 0; k4 < 8; ++k4) {
+        const float4 v = pok ? alt_load4(a, c0 + 4 * k4, C) : make_float4(0.f, 0.f, 0.f, 0.f);
+        av[4 * k4] = v.x; av[4 * k4 + 1] = v.y; av[4 * k4 + 2] = v.z; av[4 * k4 + 3] = v.w;
+      }
+      float s[RD + 1];
+      const bool rowin = ty >= 0 && ty < H2;
+#pragma unroll
+      for (int ix = 0; ix <= RD; ++ix) {
+        const int tx = bx + ix;
+        float t = 0.0f;
+        if (pok && rowin && tx >= 0 && tx < W2) {
+          if (staged) {
+            const float4* g = box + (ty - y0) * BW + (tx - x0);
+#pragma unroll
+            for (int k4 = 0; k4 < 8; ++k4) {
+              const float4 v = g[k4 * pitch];
+              t += av[4 * k4] * v.x; t += av[4 * k4 + 1] * v.y; t += av[4 * k4 + 2] * v.z; t += av[4 * k4 + 3] * v.w;
+            }
+          } else {
+            const T* g = f2b + ((int64_t)ty * W2 + tx) * C;
+#pragma unroll
+            for (int k4 = 0; k4 < 8; ++k4) {
+              const float4 v = alt_load4(g, c0 + 4 * k4, C);
+              t += av[4 * k4] * v.x; t += av[4 * k4 + 1] * v.y; t += av[4 * k4 + 2] * v.z; t += av[4 * k4 + 3] * v.w;
+            }
+          }
+        }
+        s[ix] = t;
+      }
+      // output row j of this pixel: rows j (own) and j + 1 (lane j + 1 of the 8-lane group)
+#pragma unroll
+      for (int ox = 0; ox < RD; ++ox) {
+        const float n0 = __shfl_down(s[ox], 1, 8), n1 = __shfl_down(s[ox + 1], 1, 8);
+        acc[ox] += s[ox] * w_se;
+        acc[ox] += s[ox + 1] * w_sw;
+        acc[ox] += n0 * w_ne;
+        acc[ox] += n1 * w_nw;
+      }
+    }
+    if (pok && j < RD) {
+      T* o = corr + (((int64_t)b * N + n) * RD * RD) * P + p;
+#pragma unroll
+      for (int ox = 0; ox < RD; ++ox) o[(int64_t)(j + RD * ox) * P] = (T)acc[ox];
+    }
+  }
 }
 
 // adjoint of altcorr_forward with respect to both feature maps (altcorr_kernel.cu:140-264): one wave per (b, n, pixel),
@@ -287,14 +376,14 @@ VIPE_EXPORT int vipe_altcorr_forward(const void* d_fmap1, const void* d_fmap2, c
   if (B == 0 || N == 0) return VIPE_OK;
   VIPE_CHECK_ARG(d_fmap1 && d_fmap2 && d_coords && d_corr);
   if (radius != 3) return VIPE_EUNSUPPORTED;
-  dim3 grid((H1 * W1 + 127) / 128, N, B);
+  dim3 grid(((H1 + 3) / 4) * ((W1 + 7) / 8), B);
   hipStream_t s = as_stream(stream);
   if (dtype == VIPE_F32)
-    altcorr_forward_kernel<float, 3><<<grid, 128, 0, s>>>((const float*)d_fmap1, (const float*)d_fmap2, d_coords,
-                                                          (float*)d_corr, H1, W1, H2, W2, N, C);
+    altcorr_forward_kernel<float><<<grid, 256, 0, s>>>((const float*)d_fmap1, (const float*)d_fmap2, d_coords,
+                                                       (float*)d_corr, H1, W1, H2, W2, N, C);
   else if (dtype == VIPE_F16)
-    altcorr_forward_kernel<half_t, 3><<<grid, 128, 0, s>>>((const half_t*)d_fmap1, (const half_t*)d_fmap2, d_coords,
-                                                           (half_t*)d_corr, H1, W1, H2, W2, N, C);
+    altcorr_forward_kernel<half_t><<<grid, 256, 0, s>>>((const half_t*)d_fmap1, (const half_t*)d_fmap2, d_coords,
+                                                        (half_t*)d_corr, H1, W1, H2, W2, N, C);
   else return VIPE_EINVAL;
   return vipe_launch_status();
 }
