@@ -231,7 +231,7 @@ class Dist:
 
 
 # ---------------------------------------------------------------------------------------------- video clips
-def make_clip_runner(device, features=False, pipelined=True):
+def make_clip_runner(device, features=False, pipelined=True, height=384, width=512):
     """-> run_clip(seed, n_frames, with_backend) -> dict.  One DroidNet (random-init weights, no checkpoint offline) is
     shared by all clips of this rank; every clip gets a fresh buffer / frontend (per-clip isolation, run.py:17-26)."""
     from vipe_amd.slam.buffer import GraphBuffer
@@ -246,22 +246,23 @@ def make_clip_runner(device, features=False, pipelined=True):
     def run_clip(seed, n_frames, with_backend=False, with_infill=False):
         from vipe_amd.slam import factor_graph as _fg
         work0 = dict(_fg.WORK)
-        buf = GraphBuffer(384, 512, buffer_size=n_frames + 16, device=device)
-        buf.intrinsics[:] = torch.tensor([460.8, 460.8, 256.0, 192.0], device=device)
+        ht, wd = height // 8, width // 8
+        buf = GraphBuffer(height, width, buffer_size=n_frames + 16, device=device)
+        buf.intrinsics[:] = torch.tensor([0.9 * width, 0.9 * width, width / 2.0, height / 2.0], device=device)
         # keyframe_thresh = 0: every synthetic frame stays a keyframe (random-weight flow would otherwise make the
         # distance test drop about half of them and the window would hold ~16 instead of <= 48 edges)
         fe = SLAMFrontend(um, buf, FrontendArgs(keyframe_thresh=0.0), device)
         gen = torch.Generator(device="cpu").manual_seed(99 + seed)
-        pool_d = (1.0 / (1.0 + 4.0 * torch.rand(32, 48, 64, generator=gen))).to(device)
+        pool_d = (1.0 / (1.0 + 4.0 * torch.rand(32, ht, wd, generator=gen))).to(device)
         if features:  # legacy variant: seeded feature maps instead of RGB frames (motion filter + encoders skipped)
-            pool_f = torch.randn(32, 128, 48, 64, generator=gen).half().to(device)
-            pool_n = torch.randn(32, 128, 48, 64, generator=gen).tanh().half().to(device)
-            pool_i = torch.randn(32, 128, 48, 64, generator=gen).relu().half().to(device)
+            pool_f = torch.randn(32, 128, ht, wd, generator=gen).half().to(device)
+            pool_n = torch.randn(32, 128, ht, wd, generator=gen).tanh().half().to(device)
+            pool_i = torch.randn(32, 128, ht, wd, generator=gen).relu().half().to(device)
         else:
             # decoded RGB frames resident in HBM before the timed region (decode / resize are host work outside the
             # path); every frame goes through the motion filter: feature encoder, one flow-update application against
             # the last keyframe, context encoder (thresh 0: every frame becomes a keyframe)
-            pool_img = torch.rand(32, 1, 3, 384, 512, generator=gen).to(device)
+            pool_img = torch.rand(32, 1, 3, height, width, generator=gen).to(device)
             mf = MotionFilter(dn, thresh=0.0, device=device)
         torch.cuda.synchronize()
         # the collector's generation-2 sweeps (tens of thousands of small tensor / numpy objects per clip) land at random
@@ -387,7 +388,8 @@ def video_mode(args, D):
 
     dev, world, rank = D.device, D.world, D.rank
     D.init()
-    run_clip = make_clip_runner(dev, features=args.video_features, pipelined=not args.no_pipeline)
+    run_clip = make_clip_runner(dev, features=args.video_features, pipelined=not args.no_pipeline, height=args.height,
+                                width=args.width)
     run_clip(seed=10_000 + rank, n_frames=24)  # untimed warm-up clip: code objects, workspaces, allocator pools
     n_clips = args.clips or world
     stats = []
@@ -413,13 +415,13 @@ def video_mode(args, D):
         mine = stats[0] if stats else {}
         frames = n_clips * args.frames
         print(json.dumps({
-            "metric": "frames/s, synthetic 512x384xN video clips through the keyframe frontend"
+            "metric": f"frames/s, synthetic {args.width}x{args.height}xN video clips through the keyframe frontend"
                       + (" + global BA" if args.with_backend else "") + " (every frame a keyframe)",
             "value": frames / dt, "unit": "frames/s", "n_gpus": D.n_ranks_seen(), "steps": frames, "warmup": 24,
             "ms_per_step": 1e3 * dt / max(1, args.frames * ((n_clips + world - 1) // world)),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[3]-shaped: {n_clips} independent {args.frames}-frame 512x384 clips, "
+            "config": {"workload": f"BASELINE configs[3]-shaped: {n_clips} independent {args.frames}-frame {args.width}x{args.height} clips, "
                                    f"clip-sharded over {world} rank(s), frontend window <= 48 edges, 4+2 update "
                                    f"iterations per keyframe, one all_gather of the results, artifacts by rank 0",
                        "clips_ok": sum(r.ok for r in results), "clips": len(results), "artifacts_written": len(written),
@@ -676,6 +678,19 @@ def secondary_figures(args, device, graph, step, headline_px_rate=None):
     except Exception as e:  # noqa: BLE001
         out["frames_per_s"] = f"failed: {type(e).__name__}: {e}"
     _log("secondary: video done")
+    # (4) the same clip at the size the reference's resize gives 16:9 video (1280 x 720 -> 584 x 328, 41 x 73 grid): what
+    # BASELINE configs[1] (assets/examples) actually runs at
+    try:
+        run169 = make_clip_runner(device, height=328, width=584)
+        run169(seed=10_000, n_frames=24)
+        r = run169(seed=0, n_frames=args.frames, with_backend=True)
+        out["frames_per_s_584x328"] = {
+            "frontend_only": r["frames"] / r["frontend_seconds"], "with_global_ba": r["frames"] / r["seconds_without_infill"],
+            "frames": r["frames"], "update_iterations": r["update_iterations"], "backend_edges": r["backend_edges"],
+            "state_finite": r["finite"], "grid": [41, 73]}
+    except Exception as e:  # noqa: BLE001
+        out["frames_per_s_584x328"] = f"failed: {type(e).__name__}: {e}"
+    _log("secondary: 16:9 video done")
     return out
 
 

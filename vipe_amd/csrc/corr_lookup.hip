@@ -315,10 +315,11 @@ typedef _Float16 half8v __attribute__((ext_vector_type(8)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
+template <bool BLK>  // BLK: levels in VIPE_PYRAMID_BLOCKED (padded grid), else the reference layout
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void corr_lookup_conv_kernel(
     LevelPtrs lv, const float* __restrict__ coords, const half_t* __restrict__ wpk, const float* __restrict__ bias,
     half_t* __restrict__ out, int out_ctot, int out_coff, int h1, int w1, int h2, int w2, int B, int cout_pad, int act,
-    const int* __restrict__ slots, int blocked) {
+    const int* __restrict__ slots) {
   constexpr int R = 3, RD = 7, L = 4;
   using A = Acc<half_t>;
   __shared__ __align__(16) half_t stage[32 * LKC_PITCH];
@@ -362,11 +363,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const int y1 = by + j, c0 = bx >> 3;
       // 8-column pieces of a row: whole ones in the reference layout; in the blocked layout the last one may be partial
       // (columns >= w2l stored as zero by the build kernel)
-      const int nchunks = blocked ? (w2l + 7) >> 3 : w2l >> 3;
+      const int nchunks = BLK ? (w2l + 7) >> 3 : w2l >> 3;
       const bool rowok = (y1 >= 0) & (y1 < h2l);
       lo[l] = uint4v{0, 0, 0, 0};
       hi[l] = uint4v{0, 0, 0, 0};
-      if (blocked && l < 2) {
+      if (BLK && l < 2) {
         // VIPE_PYRAMID_BLOCKED (include/vipe_amd.h): 16-byte piece (row y1, columns 8 c ..) of source pixel pc lives in
         // run ((x-strip) * (R >> l) + y1 / 4) of the pixel's group of 64, tile c % T, tile row y1 % 4
         const int T = 4 >> l, rgs = bR >> l;
@@ -379,17 +380,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         };
         if (rowok & (c0 >= 0) & (c0 < nchunks)) lo[l] = piece(c0);
         if (rowok & (c0 + 1 >= 0) & (c0 + 1 < nchunks)) hi[l] = piece(c0 + 1);
-      } else if (blocked) {
-        // levels 2 / 3 of the blocked layout: one slab per source pixel of every group, R >> (l - 2) rows of
-        // 8 S / round_up(4 S, 8) entries
-        const int hlp = bR >> (l - 2), wlp = l == 2 ? 8 * bS : ((4 * bS + 7) & ~7);
-        const half_t* slab = reinterpret_cast<const half_t*>(lv.p[l]) + ((int64_t)ns * bG * 64 + pc) * ((int64_t)hlp * wlp);
-        const uint4v* rowp = reinterpret_cast<const uint4v*>(slab + (int64_t)(rowok ? y1 : 0) * wlp);
-        if (rowok & (c0 >= 0) & (c0 < nchunks)) lo[l] = rowp[c0];
-        if (rowok & (c0 + 1 >= 0) & (c0 + 1 < nchunks)) hi[l] = rowp[c0 + 1];
       } else {
-        const half_t* slab = reinterpret_cast<const half_t*>(lv.p[l]) + ((int64_t)ns * P + pc) * ((int64_t)h2l * w2l);
-        const uint4v* rowp = reinterpret_cast<const uint4v*>(slab + (int64_t)(rowok ? y1 : 0) * w2l);
+        // one slab per source pixel: [h >> l][w >> l] (reference), or levels 2 / 3 of the blocked layout - a slab for every
+        // pixel of every group of 64, R >> (l - 2) rows of 8 S / round_up(4 S, 8) entries
+        const int hlp = BLK ? bR >> (l - 2) : h2l, wlp = BLK ? (l == 2 ? 8 * bS : ((4 * bS + 7) & ~7)) : w2l;
+        const half_t* slab = reinterpret_cast<const half_t*>(lv.p[l]) + ((int64_t)ns * (BLK ? bG * 64 : P) + pc) * ((int64_t)hlp * wlp);
+        const uint4v* rowp = reinterpret_cast<const uint4v*>(slab + (int64_t)(rowok ? y1 : 0) * wlp);
         if (rowok & (c0 >= 0) & (c0 < nchunks)) lo[l] = rowp[c0];
         if (rowok & (c0 + 1 >= 0) & (c0 + 1 < nchunks)) hi[l] = rowp[c0 + 1];
       }
@@ -636,8 +632,13 @@ VIPE_EXPORT int vipe_corr_lookup_conv1x1(const void* const* h_levels, const floa
   }
   const int64_t ngroups = (int64_t)B * ((h1 * w1 + 31) / 32);
   const int blocks = (int)std::min<int64_t>(ngroups, 256 * 4);
-  corr_lookup_conv_kernel<<<blocks, 256, 0, as_stream(stream)>>>(lv, d_coords, (const half_t*)d_w_packed, d_bias,
-                                                                 (half_t*)d_out, out_ctot, out_coff, h1, w1, h2, w2, B,
-                                                                 128, act, d_slots, layout);
+  if (layout == VIPE_PYRAMID_BLOCKED)
+    corr_lookup_conv_kernel<true><<<blocks, 256, 0, as_stream(stream)>>>(lv, d_coords, (const half_t*)d_w_packed, d_bias,
+                                                                         (half_t*)d_out, out_ctot, out_coff, h1, w1, h2, w2,
+                                                                         B, 128, act, d_slots);
+  else
+    corr_lookup_conv_kernel<false><<<blocks, 256, 0, as_stream(stream)>>>(lv, d_coords, (const half_t*)d_w_packed, d_bias,
+                                                                          (half_t*)d_out, out_ctot, out_coff, h1, w1, h2, w2,
+                                                                          B, 128, act, d_slots);
   return vipe_launch_status();
 }
