@@ -507,6 +507,23 @@ def plumbing_mode(args, D):
 
 
 # ---------------------------------------------------------------------------------------------- roofline helper
+def profile_traffic(names, flat):
+    """HBM traffic of the dominant kernel per launch: FETCH_SIZE x2 + WRITE_SIZE from the builder's own rocprofv3 --pmc
+    passes of the bench command (profiles/rNN_summary*.json, committed) - counters cannot be collected from inside the
+    timed process, so this is NOT a measurement of the run that prints it.  -> (bytes or None, source or None)"""
+    keys = (f"void conv_halo32_kernel<128, 3, true, 0, {'true' if flat else 'false'}>", "void conv_halo32_kernel<128, 3, true, 0>",
+            "void conv_halo32_kernel<128, 3, true>")
+    for name in names:
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", name)))
+            row = next(prof[k] for k in keys if k in prof)
+            return ((row["hbm_read_MB_per_launch"] + row["hbm_write_MB_per_launch"]) * 1e6,
+                    f"profiles/{name}: builder-side rocprofv3 --pmc passes of this command, not this run")
+        except Exception:  # noqa: BLE001
+            pass
+    return None, None
+
+
 def conv_roofline(graph, step, device, prof_steps):
     """Roofline of the dominant kernel: conv_halo32_kernel<128, 3, true, 0, FLAT> (every 3x3 convolution of the flow-update
     operator with >= 128 output channels: corr2, z|r, q, delta0|weight0|agg1, agg2 - 5 launches per step, ~50 % of the
@@ -600,6 +617,8 @@ def grid_figure(device, height, width, n_kf, steps, prof_steps, headline_px_rate
                   and torch.isfinite(graph.target).all())
     ms, fpl, ach, lps = conv_roofline(graph, step, device, prof_steps)
     P = g.ht * g.wd
+    flat = not (g.wd % 64 == 0 and g.ht % 4 == 0)
+    traffic, traffic_src = profile_traffic(("r03_summary_41x73.json",), True) if (g.ht, g.wd) == (41, 73) else (None, None)
     out = {"value": n / dt, "unit": "iters/s", "ms_per_step": 1e3 * dt / n, "steps": n, "grid": [g.ht, g.wd], "pixels": P,
            "keyframes": n_kf, "edges": E, "launch": launch, "state_finite": finite,
            "edge_pixels_per_s": n / dt * E * P,
@@ -607,9 +626,10 @@ def grid_figure(device, height, width, n_kf, steps, prof_steps, headline_px_rate
                             "pyramid_store": "blocked" if getattr(graph.corr, "blocked", False) else "reference",
                             "staged_gates": getattr(graph, "_gate_state", None) is not None},
            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / PEAK_FP16_TFLOPS, "traffic": None, "avg_launch_ms": ms, "flops_per_launch": fpl,
-                        "launches_per_step": lps,
-                        "kernel": "conv_halo32_kernel<128, 3, true, 0, FLAT> on this grid (event-timed launches)"}}
+                        "frac": ach / PEAK_FP16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": ms,
+                        "flops_per_launch": fpl, "launches_per_step": lps,
+                        "kernel": f"conv_halo32_kernel<128, 3, true, 0, {'true' if flat else 'false'}> on this grid "
+                                  f"({'flat' if flat else '4 x 64'} tiling; event-timed launches)"}}
     if headline_px_rate:
         out["per_pixel_throughput_vs_48x64"] = out["edge_pixels_per_s"] / headline_px_rate
     del graph, buf
@@ -762,26 +782,20 @@ def update_mode(args, D):
     # HBM traffic of the dominant kernel per launch: FETCH_SIZE x2 + WRITE_SIZE from the builder's own rocprofv3 --pmc
     # passes of this command (profiles/rNN_summary.json, committed) - counters cannot be collected from inside the
     # timed process, so this is NOT a measurement of this run
-    traffic, traffic_src = None, None
-    for name in ("r02_summary.json", "r01_summary.json"):
+    traffic, traffic_src = profile_traffic(("r03_summary.json", "r02_summary.json", "r01_summary.json"), False)
+
+    # matrix-core utilisation of the same kernel from the builder's SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE pass
+    # (profiles/r03_mfma_util.json) - like `traffic`, evidence collected beside this run, not by it
+    mfma_pmc = None
+    for name in ("r03_mfma_util.json", "r02_mfma_util.json"):
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", name)))
-            prof = prof.get("void conv_halo32_kernel<128, 3, true, 0>") or prof["void conv_halo32_kernel<128, 3, true>"]
-            traffic = (prof["hbm_read_MB_per_launch"] + prof["hbm_write_MB_per_launch"]) * 1e6
-            traffic_src = f"profiles/{name}: builder-side rocprofv3 --pmc passes of this command, not this run"
+            mu = json.load(open(os.path.join(ROOT, "profiles", name)))
+            mu = mu.get("void conv_halo32_kernel<128, 3, true, 0, false>") or mu["void conv_halo32_kernel<128, 3, true, 0>"]
+            mfma_pmc = {"mfma_busy_frac": mu["mfma_util"], "effective_clock_GHz": mu["effective_clock_GHz"],
+                        "avg_launch_ms": mu["avg_us"] / 1e3, "source": f"profiles/{name} (builder-side --pmc pass)"}
             break
         except Exception:  # noqa: BLE001
             pass
-
-    # matrix-core utilisation of the same kernel from the builder's SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE pass
-    # (profiles/r02_mfma_util.json) - like `traffic`, evidence collected beside this run, not by it
-    mfma_pmc = None
-    try:
-        mu = json.load(open(os.path.join(ROOT, "profiles", "r02_mfma_util.json")))["void conv_halo32_kernel<128, 3, true, 0>"]
-        mfma_pmc = {"mfma_busy_frac": mu["mfma_util"], "effective_clock_GHz": mu["effective_clock_GHz"],
-                    "avg_launch_ms": mu["avg_us"] / 1e3, "source": "profiles/r02_mfma_util.json (builder-side --pmc pass)"}
-    except Exception:  # noqa: BLE001
-        pass
 
     if rank == 0:
         out = {
