@@ -585,3 +585,39 @@ def test_staged_gate_state_survives_only_while_its_scratch_is_untouched():
     assert (a[0] - b[0]).abs().max().item() < 1e-4
     assert (a[1].float() - b[1].float()).abs().max().item() < 1e-2
     assert (a[2] - b[2]).abs().max().item() < 5e-2
+
+
+def test_slam_system_on_16_9_frames():
+    """BASELINE configs[1]'s real input: `SLAMSystem.run` (system.py:186-316) over 584 x 328 frames (1280 x 720 through the
+    reference's resize; 41 x 73 grid) - motion filter, encoders, keyframe frontend with proximity edges, the backend's
+    global BA on the volume path, pass 2 through the InnerFiller, the map.  Random-init weights: pinned is the bookkeeping
+    (keyframes, one unit-quaternion pose per frame, map timestamps) and that every tile kernel is the one that ran."""
+    from vipe_amd.ext.lietorch import SE3
+    from vipe_amd.slam.frontend import FrontendArgs
+    from vipe_amd.slam.inner_filler import InfillArgs
+    from vipe_amd.slam.system import Frame, SLAMConfig, SLAMSystem
+
+    gen = torch.Generator().manual_seed(5)
+    T, H, W = 20, 328, 584
+    rgb = torch.rand(T, H, W, 3, generator=gen).to(dev())
+    depth = (1.0 + 4.0 * torch.rand(T, H, W, generator=gen)).to(dev())
+    intr = torch.tensor([525.6, 525.6, 292.0, 164.0])
+    frames = []
+    for t in range(T):
+        pose = SE3(torch.tensor([[-0.05 * t, 0, 0, 0, 0, 0, 1.0]], device=dev())).inv()  # camera -> world
+        frames.append(Frame(rgb=rgb[t], metric_depth=depth[t], intrinsics=intr, pose=SE3(pose.data[0]),
+                            mask=torch.ones(H, W, dtype=torch.bool, device=dev())))
+    torch.manual_seed(0)
+    cfg = SLAMConfig(buffer=48, filter_thresh=0.0, frontend_backend_iters=(10,),
+                     frontend=FrontendArgs(keyframe_thresh=0.0), infill=InfillArgs(infill_chunk_size=8))
+    sysm = SLAMSystem(dev(), cfg)
+    out = sysm.run(frames)
+    torch.cuda.synchronize()
+    assert out.keyframe_ids.tolist() == list(range(T))
+    assert out.trajectory.data.shape == (T, 7) and bool(torch.isfinite(out.trajectory.data).all())
+    assert (out.trajectory.data[:, 3:].norm(dim=-1) - 1).abs().max().item() < 1e-4
+    assert torch.allclose(out.intrinsics[0].cpu(), intr)
+    g = sysm.frontend.graph
+    assert (g.ht, g.wd) == (41, 73) and g.corr.blocked and g.pgate is not None and g.corr.pool[0].dim() == 7
+    assert tuple(sysm.buffer.fmaps.shape[-2:]) == (41, 73)
+    assert out.slam_map is not None and len(out.slam_map.dense_disp_frame_inds) > 0
