@@ -249,7 +249,7 @@ typedef struct {
   int limited_disp;
   int optimize_intrinsics;
   int optimize_rig_rotation; /* rotation-only blocks for the views >= 1 of a rig (view 0 is always fixed, buffer.py:497-506,
-                                retractor.py:32-37); no effect for n_views == 1.  Rigs of up to 4 views. */
+                                retractor.py:32-37); no effect for n_views == 1.  Rigs of up to 8 views. */
   int camera;        /* VIPE_CAM_* */
   float alpha;       /* ba.dense_disp_alpha, configs/slam/default.yaml:48-49 */
   float weight_scale;/* 0.001, buffer.py:396 */

@@ -261,7 +261,7 @@ def run_hip_ba_rig(g, bk):
 
 @pytest.mark.parametrize("name", sorted(BA_RIG_CASES))
 def test_dense_ba_rig_matches_reference_solver(name):
-    """Multi-view rigs in the fused BA (SURVEY 8 BA-diff "optional intrinsics / rig groups"): V = 2 and 3 views,
+    """Multi-view rigs in the fused BA (SURVEY 8 BA-diff "optional intrinsics / rig groups"): V = 2, 3, 5 and 6 views,
     cross-view self edges, one intrinsics block per view, the rig-rotation group (view 0 fixed, rotation-only
     retraction) - against the reference's own Solver (ba_rig_reference.npz) at the north_star tolerance, 1e-4 relative."""
     from vipe_amd.synth import make_rig_graph

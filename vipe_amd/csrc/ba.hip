@@ -74,7 +74,8 @@ struct BAArgs {
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
-constexpr int RG_VMAX = 4;  // views of a rig the multi-view kernels handle
+constexpr int RG_VMAX = 8;  // views of a rig the multi-view kernels handle: the per-view tail rows of a pixel live in registers
+                            // (instantiations for <= 4 and <= 8 views; the reference's Solver is generic in V, buffer.py:404-506)
 inline bool is_multiview(const vipe_ba_params& p) { return p.n_views > 1; }  // a mono rig has no rig unknowns (view 0 is the gauge)
 inline int tail_intr(const vipe_ba_params& p) {
   const int F = 1 + (p.camera == VIPE_CAM_MEI ? 1 : 0);
@@ -1074,7 +1075,7 @@ constexpr size_t walk_rig_lds() {
 }
 __device__ __forceinline__ int rg_tile_row(int b) { return b < 6 ? b : b + 1; }
 
-template <int CAM>
+template <int CAM, int VM>
 __global__ __launch_bounds__(TILE) void ba_walk_rig_kernel(BAArgs a) {
   constexpr int WBUF = 16 * AM_P1;
   constexpr int F = CAM == VIPE_CAM_MEI ? 2 : 1;
@@ -1108,7 +1109,7 @@ __global__ __launch_bounds__(TILE) void ba_walk_rig_kernel(BAArgs a) {
   cam::iproj<CAM, F>(Ii, u, v, X0, Y0, dX0, dY0);
   float C = 0.f, wz = 0.f, Ei[6] = {0, 0, 0, 0, 0, 0};
   float EfA[F] = {}, ErA[6] = {0, 0, 0, 0, 0, 0};      // tail rows of the source view qi
-  float Efv[RG_VMAX][F] = {}, Erv[RG_VMAX][6] = {};    // ... of the target views (selected by predicate)
+  float Efv[VM][F] = {}, Erv[VM][6] = {};              // ... of the target views (selected by predicate)
   const int l16 = lane & 15, kq = lane >> 4;
 
   for (int cb = 0; cb < deg_all; cb += WK_CH) {
@@ -1228,7 +1229,7 @@ __global__ __launch_bounds__(TILE) void ba_walk_rig_kernel(BAArgs a) {
 #pragma unroll
           for (int f = 0; f < F; ++f) EfA[f] += JfA[f] * wJz;
 #pragma unroll
-          for (int vv = 0; vv < RG_VMAX; ++vv) {
+          for (int vv = 0; vv < VM; ++vv) {
             if (vv == qj) {
 #pragma unroll
               for (int f = 0; f < F; ++f) Efv[vv][f] += JfB[f] * wJz;
@@ -1304,7 +1305,7 @@ __global__ __launch_bounds__(TILE) void ba_walk_rig_kernel(BAArgs a) {
       float* et = w.Et + (int64_t)k * a.ntail * P + p;
       if (oi) {
 #pragma unroll
-        for (int vv = 0; vv < RG_VMAX; ++vv) {
+        for (int vv = 0; vv < VM; ++vv) {
           if (vv < V) {
 #pragma unroll
             for (int f = 0; f < F; ++f) et[(int64_t)(vv * F + f) * P] = Efv[vv][f] + (vv == qi ? EfA[f] : 0.0f);
@@ -1313,7 +1314,7 @@ __global__ __launch_bounds__(TILE) void ba_walk_rig_kernel(BAArgs a) {
       }
       if (orr) {
 #pragma unroll
-        for (int vv = 1; vv < RG_VMAX; ++vv) {
+        for (int vv = 1; vv < VM; ++vv) {
           if (vv < V) {
 #pragma unroll
             for (int q = 0; q < 6; ++q)
@@ -3143,7 +3144,8 @@ int run_iters(const BAArgs& a, hipStream_t s, int* pieces_done) {
   vipe_once_per_device(tmpl_set, [] {
     (void)hipFuncSetAttribute((const void*)ba_accum_mfma_kernel<CAM, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_mfma_lds());
     (void)hipFuncSetAttribute((const void*)ba_walk_kernel<CAM, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds());
-    (void)hipFuncSetAttribute((const void*)ba_walk_rig_kernel<CAM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_rig_lds());
+    (void)hipFuncSetAttribute((const void*)ba_walk_rig_kernel<CAM, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_rig_lds());
+    (void)hipFuncSetAttribute((const void*)ba_walk_rig_kernel<CAM, RG_VMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_rig_lds());
   });
   // S / Hd start each accumulation zeroed: by ba_retract_kernel of the previous iteration when it runs (not motion_only),
   // also across calls when the caller vouches for the workspace (reuse_plan: same key, hence the same motion_only), else
@@ -3159,7 +3161,8 @@ int run_iters(const BAArgs& a, hipStream_t s, int* pieces_done) {
     }
     if (a.mv) {
       // multi-view rigs: local-block walk, Schur Gram over the stacked E rows, global-memory Cholesky with the dense tail
-      ba_walk_rig_kernel<CAM><<<dim3(tiles, a.nF), TILE, walk_rig_lds(), s>>>(a);
+      if (a.p.n_views <= 4) ba_walk_rig_kernel<CAM, 4><<<dim3(tiles, a.nF), TILE, walk_rig_lds(), s>>>(a);
+      else ba_walk_rig_kernel<CAM, RG_VMAX><<<dim3(tiles, a.nF), TILE, walk_rig_lds(), s>>>(a);
       ba_schur_kernel<0><<<dim3(SC_GRID, a.nF), TILE, 0, s>>>(a);
       if (ev && hipEventRecord(ev, s) != hipSuccess) return VIPE_EINVAL;
       ba_solve_kernel<<<1, SOLVE_T, solve_lds, s>>>(a, panel_cap);
@@ -3213,7 +3216,7 @@ VIPE_EXPORT int vipe_dense_ba(const vipe_ba_params* p, float* d_poses, float* d_
   VIPE_CHECK_ARG(p->t0 <= p->t1 && p->intr_factor > 0);
   VIPE_CHECK_ARG(p->camera == VIPE_CAM_PINHOLE || p->camera == VIPE_CAM_MEI);
   VIPE_CHECK_ARG(p->M == 0 || (d_target && d_weight && d_pi && d_qi && d_pj && d_qj && d_di));
-  if (is_multiview(*p) && p->n_views > RG_VMAX) return VIPE_EUNSUPPORTED;  // rigs of up to 4 cameras
+  if (is_multiview(*p) && p->n_views > RG_VMAX) return VIPE_EUNSUPPORTED;  // rigs of up to 8 cameras
   if ((int64_t)p->n_poses * p->n_views > 65535) return VIPE_EINVAL;
   BAArgs a;
   a.p = *p;
