@@ -552,7 +552,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const unsigned ldsX_u = __builtin_amdgcn_readfirstlane(ldsX_a + wave * 1024);
   auto issueW2 = [&](int tap, int c, int slot, auto ONC, bool more_) {  // weights of K-step (tap, c) into ring slot `slot`
     const unsigned off = (unsigned)tap * tstride + ((unsigned)(c >> 1) * (unsigned)a.Cout_pad * BK + (unsigned)(c & 1) * H32_BK) * 2u;
-    if constexpr (false) {
+    if constexpr (decltype(ONC)::value && WPIECES == 8) {
       dma16s(wbase + off, woff, wdst_u + slot * WSTAGE);  // every wave carries a piece and the step exists: nothing to select
     } else {
       const bool on = (decltype(ONC)::value || more_) && wreal;

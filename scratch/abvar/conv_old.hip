@@ -53,7 +53,7 @@ struct ConvArgs {
   // flat tiling (FLAT kernels, any H x W): a tile is 256 consecutive positions q = y * Wp + x of the image padded to
   // pitch Wp = W + pad columns (zeros); filled by launch_conv
   int f_wp, f_hwp, f_tiles, f_pieces, f_xbytes, f_p1lo, f_p1hi;
-  unsigned f_magic;  // ceil(2^32 / f_wp)
+  float f_rcp;
 };
 
 constexpr int BNP = 128;  // pixels per tile
@@ -389,33 +389,6 @@ __device__ __forceinline__ void glds16_off(const void* base, unsigned voff_bytes
 #endif
 }
 
-// Branch-free forms for the K loop of the halo kernels: the source base (or, per lane, the whole pointer), the lane offset
-// and the LDS piece are SELECTED (s_cselect / v_cndmask) between the real transfer and a dummy read of the zero page into
-// the sink, so that a tap's DMA issue is a dozen straight-line scalar instructions the scheduler can place between its
-// matrix instructions - as `if (...) issue else dummy` it was four basic blocks and ~45 scalar instructions per tap that
-// every wave executed between the barrier and its first fragment read (round-3 ISA reading).
-__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
-  return ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-}
-__device__ __forceinline__ void dma16s(uint64_t sbase, unsigned voff_bytes, unsigned lds_addr) {  // sbase, lds_addr wave-uniform
-#if defined(__HIP_DEVICE_COMPILE__)
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff_bytes), "s"(sbase), "s"(lds_addr)
-               : "memory");
-#endif
-}
-__device__ __forceinline__ void dma16v(uint64_t lane_ptr, unsigned lds_addr) {  // per-lane source, lds_addr wave-uniform
-#if defined(__HIP_DEVICE_COMPILE__)
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(lane_ptr), "s"(lds_addr)
-               : "memory");
-#endif
-}
-
 // ---- Halo-tile kernel, K step 32: TWO workgroups per CU.
 // Same tile (8 waves: 4 image rows x 64 px x BMC couts) and the same halo idea as above, but the channel chunk is 32
 // (64-byte LDS rows): halo double buffer 2 x 25 KiB + weight ring 3 x 8 KiB = 75 KiB, so two workgroups share a CU
@@ -441,12 +414,12 @@ __device__ __forceinline__ int swz32(int row, int c) { return row * 64 + ((c ^ s
 
 
 // position q of a flat tile -> pixel index of image e ((e * H + y) * W + x), or -1 for the pad column / beyond the image
-// (q / wp by the multiply-high of a 32-bit reciprocal, exact for q < 2^32 / wp: three integer instructions and no temporaries
-// the K loop would have to keep live - this runs at every halo-piece issue)
-__device__ __forceinline__ int flat_pixel(int q, int e, int H, int W, int wp, int hwp, unsigned magic) {
-  if ((unsigned)q >= (unsigned)hwp) return -1;  // also q < 0
-  const int y = (int)__umulhi((unsigned)q, magic);
-  const int x = q - y * wp;
+__device__ __forceinline__ int flat_pixel(int q, int e, int H, int W, int wp, int hwp, float rcp) {
+  if (q < 0 || q >= hwp) return -1;
+  int y = (int)(((float)q + 0.5f) * rcp);
+  int x = q - y * wp;
+  if (x < 0) { --y; x += wp; }
+  if (x >= wp) { ++y; x -= wp; }
   return x < W ? (e * H + y) * W + x : -1;
 }
 
@@ -481,7 +454,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int npieces = FLAT ? a.f_pieces : H32_PIECES;
   // pixel index of tile pixel pl (row pl / 64, column pl % 64; FLAT: position q0 + pl, -1 when it is no pixel)
   auto pix_of = [&](int pl) -> int64_t {
-    if constexpr (FLAT) return flat_pixel(q0 + pl, e, a.H, a.W, a.f_wp, a.f_hwp, a.f_magic);
+    if constexpr (FLAT) return flat_pixel(q0 + pl, e, a.H, a.W, a.f_wp, a.f_hwp, a.f_rcp);
     else return ((int64_t)(e * a.H + y0 + (pl >> 6))) * a.W + x0 + (pl & 63);
   };
   const int cs32 = a.Cin_pad / H32_BK, cs64 = a.Cin_pad / 64;
@@ -529,7 +502,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int ctot = s0 ? a.x0_ctot : a.x1_ctot;
     const int cb = (s0 ? a.x0_coff : a.x1_coff - a.split) + c0;
     int xp;
-    if constexpr (FLAT) xp = flat_pixel(q0 - pitch - 1 + (wave + 8 * i) * 16 + r16, e, a.H, a.W, a.f_wp, a.f_hwp, a.f_magic);
+    if constexpr (FLAT) xp = flat_pixel(q0 - pitch - 1 + (wave + 8 * i) * 16 + r16, e, a.H, a.W, a.f_wp, a.f_hwp, a.f_rcp);
     else xp = xpix[i];
     const bool ok = xp >= 0 && (c0 + xk < a.Cin);
     const unsigned off = ((unsigned)xp * (unsigned)ctot + (unsigned)(cb + xk)) * 2u;
@@ -543,34 +516,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   auto issueW = [&](const half_t* wb, int slot) {
     if (wreal) glds16_off(wb, woff, wdst + slot * WSTAGE);
     else glds16(zp, sink_a);
-  };
-  // ---- the same two transfers, branch-free (K loop): `on` is wave-uniform
-  const uint64_t zp64 = uniform64((uint64_t)zp);
-  const uint64_t wbase = uniform64((uint64_t)(a.w + (int64_t)cout0 * BK));  // rows cout0.. of packed block 0
-  const unsigned tstride = (unsigned)cs64 * (unsigned)a.Cout_pad * BK * 2u;    // bytes from one tap's packed blocks to the next's
-  const unsigned sink_u = __builtin_amdgcn_readfirstlane(sink_a), wdst_u = __builtin_amdgcn_readfirstlane(wdst);
-  const unsigned ldsX_u = __builtin_amdgcn_readfirstlane(ldsX_a + wave * 1024);
-  auto issueW2 = [&](int tap, int c, int slot, auto ONC, bool more_) {  // weights of K-step (tap, c) into ring slot `slot`
-    const unsigned off = (unsigned)tap * tstride + ((unsigned)(c >> 1) * (unsigned)a.Cout_pad * BK + (unsigned)(c & 1) * H32_BK) * 2u;
-    if constexpr (false) {
-      dma16s(wbase + off, woff, wdst_u + slot * WSTAGE);  // every wave carries a piece and the step exists: nothing to select
-    } else {
-      const bool on = (decltype(ONC)::value || more_) && wreal;
-      dma16s(on ? wbase + off : zp64, on ? woff : 0u, on ? wdst_u + slot * WSTAGE : sink_u);
-    }
-  };
-  auto issueX2 = [&](int c, int i, int buf, bool on) {   // halo piece i of chunk c into halo buffer `buf`
-    const int c0 = c * H32_BK;
-    const bool s0 = c0 < a.split;  // wave-uniform
-    const int ctot = s0 ? a.x0_ctot : a.x1_ctot;
-    const int cb = (s0 ? a.x0_coff : a.x1_coff - a.split) + c0;
-    int xp;
-    if constexpr (FLAT) xp = flat_pixel(q0 - pitch - 1 + (wave + 8 * i) * 16 + r16, e, a.H, a.W, a.f_wp, a.f_hwp, a.f_magic);
-    else xp = xpix[i];
-    const bool ok = on && xp >= 0 && (c0 + xk < a.Cin);
-    const unsigned off = ((unsigned)xp * (unsigned)ctot + (unsigned)(cb + xk)) * 2u;
-    const uint64_t base = (uint64_t)(s0 ? a.x0 : a.x1);
-    dma16v(ok ? base + off : zp64, on ? ldsX_u + buf * xbytes + i * 8192 : sink_u);
   };
 
   float16v acc[M16 ? 1 : TM][M16 ? 1 : TN];
@@ -652,22 +597,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
   };
 
-  // the same step in two halves (16x16x32 form): all eight fragment reads of a tap, then its sixteen matrix instructions -
-  // the 3x3 K loop puts the tap's LDS-DMA issue between them, in the shadow of the reads' latency
-  auto load_frags = [&](const unsigned char* bw, const unsigned char* bx, int Rl, int dy, int dx, half8 (&wf)[MI], half8 (&xf)[NJ]) {
-    const int xa0 = swz32<true>(Rl + (dy + 1) * pitch + (dx + 1), lk);
-#pragma unroll
-    for (int i = 0; i < MI; ++i) wf[i] = *reinterpret_cast<const half8*>(bw + (wa0 + i * 1024));
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) xf[j] = *reinterpret_cast<const half8*>(bx + (xa0 + j * 1024));
-  };
-  auto mma_frags = [&](const half8 (&wf)[MI], const half8 (&xf)[NJ]) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int i = 0; i < MI; ++i) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc16[i][j], 0, 0, 0);
-  };
-
   // ---- prologue: halo chunk 0, weights of steps 0 and 1
 #pragma unroll
   for (int i = 0; i < H32_XP; ++i)
@@ -691,19 +620,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       auto tap_step = [&](auto TAPC) {
         constexpr int TAP = decltype(TAPC)::value;
         constexpr int T2 = TAP + 2;
-        if constexpr (M16) {
-          half8 wf[MI], xf[NJ];
-          load_frags(ldsW + (TAP % 3) * WSTAGE, bx, Rl, TAP / 3 - 1, TAP % 3 - 1, wf, xf);
-          if constexpr (T2 < 9) issueW2(T2, c, T2 % 3, std::true_type{}, true);
-          else issueW2(T2 - 9, c + 1, T2 % 3, std::false_type{}, more);
-          if constexpr (TAP < H32_XP) issueX2(c + 1, TAP, (c + 1) & 1, more && piece_used(TAP));
-          mma_frags(wf, xf);
+        if constexpr (T2 < 9) {
+          issueW(wsrc(T2, c), T2 % 3);
         } else {
-          if constexpr (T2 < 9) issueW2(T2, c, T2 % 3, std::true_type{}, true);
-          else issueW2(T2 - 9, c + 1, T2 % 3, std::false_type{}, more);
-          if constexpr (TAP < H32_XP) issueX2(c + 1, TAP, (c + 1) & 1, more && piece_used(TAP));
-          mma_step(ldsW + (TAP % 3) * WSTAGE, bx, Rl, TAP / 3 - 1, TAP % 3 - 1);
+          if (more) issueW(wsrc(T2 - 9, c + 1), T2 % 3);
+          else glds16(zp, sink_a);
         }
+        if constexpr (TAP < H32_XP) {
+          if (more && piece_used(TAP)) issueX(c + 1, TAP, (c + 1) & 1);
+          else glds16(zp, sink_a);
+        }
+        mma_step(ldsW + (TAP % 3) * WSTAGE, bx, Rl, TAP / 3 - 1, TAP % 3 - 1);
         if constexpr (TAP == 0 || TAP == 4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else if constexpr (TAP < 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
@@ -956,7 +883,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int pitch = FLAT ? a.f_wp : HALO_PITCH, xbytes = FLAT ? a.f_xbytes : H32_XBYTES;
   const int npieces = FLAT ? a.f_pieces : H32_PIECES;
   auto pix_of = [&](int pl) -> int64_t {
-    if constexpr (FLAT) return flat_pixel(q0 + pl, e, a.H, a.W, a.f_wp, a.f_hwp, a.f_magic);
+    if constexpr (FLAT) return flat_pixel(q0 + pl, e, a.H, a.W, a.f_wp, a.f_hwp, a.f_rcp);
     else return ((int64_t)(e * a.H + y0 + (pl >> 6))) * a.W + x0 + (pl & 63);
   };
   const int cs32 = a.Cin_pad / H32_BK, cs64 = a.Cin_pad / 64;
@@ -973,7 +900,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int pce = wave + 8 * i;
     const int r = pce * 16 + r16;
     if constexpr (FLAT) {
-      xpix[i] = pce < npieces ? flat_pixel(q0 - pitch - 1 + r, e, a.H, a.W, a.f_wp, a.f_hwp, a.f_magic) : -1;
+      xpix[i] = pce < npieces ? flat_pixel(q0 - pitch - 1 + r, e, a.H, a.W, a.f_wp, a.f_hwp, a.f_rcp) : -1;
     } else {
       const int hy = r / HALO_PITCH, hx = r % HALO_PITCH;
       const int y = y0 + hy - 1, x = x0 + hx - 1;
@@ -1165,7 +1092,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int y0 = (trem / xsegs) * HALO_TH, x0 = (trem % xsegs) * HALO_TW;
   const int q0 = trem * (HALO_TH * HALO_TW), pitch = FLAT ? a.f_wp : C7_PW;
   auto pix_of = [&](int pl) -> int64_t {
-    if constexpr (FLAT) return flat_pixel(q0 + pl, e, a.H, a.W, a.f_wp, a.f_hwp, a.f_magic);
+    if constexpr (FLAT) return flat_pixel(q0 + pl, e, a.H, a.W, a.f_wp, a.f_hwp, a.f_rcp);
     else return ((int64_t)(e * a.H + y0 + (pl >> 6))) * a.W + x0 + (pl & 63);
   };
   const int l16 = lane & 15, lk = lane >> 4;
@@ -1187,7 +1114,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   if constexpr (FLAT) {
     const int nh = HALO_TH * HALO_TW + 6 * pitch + 6;
     for (int i = tid; i < nh; i += 512) {
-      const int m = flat_pixel(q0 - 3 * pitch - 3 + i, e, a.H, a.W, a.f_wp, a.f_hwp, a.f_magic);
+      const int m = flat_pixel(q0 - 3 * pitch - 3 + i, e, a.H, a.W, a.f_wp, a.f_hwp, a.f_rcp);
       uint2 v = make_uint2(0u, 0u);
       if (m >= 0) v = *reinterpret_cast<const uint2*>(a.x0 + (int64_t)m * a.x0_ctot + a.x0_coff);
       *reinterpret_cast<uint2*>(ldsX + i * 8) = v;
@@ -1337,14 +1264,14 @@ bool flat_geometry(ConvArgs& a, int pad, bool is1x1) {
   a.f_wp = a.W + pad;
   a.f_hwp = a.H * a.f_wp;
   a.f_tiles = (a.f_hwp + 255) / 256;
-  a.f_magic = (unsigned)(((1ull << 32) + (unsigned)a.f_wp - 1) / (unsigned)a.f_wp);
+  a.f_rcp = 1.0f / (float)a.f_wp;
   const int rows = 256 + 2 * a.f_wp + 2;
   a.f_pieces = (rows + 15) / 16;
   a.f_xbytes = a.f_pieces * 1024;
   a.f_p1lo = (a.f_wp + 1) / 16;
   a.f_p1hi = (a.f_wp + 256) / 16;
   (void)is1x1;
-  return a.f_wp >= 2 && a.f_pieces <= 8 * H32_XP && a.f_hwp < (1 << 23);
+  return a.f_pieces <= 8 * H32_XP && a.f_hwp < (1 << 23);
 }
 
 template <int BMC, int KS, int VAR, bool FLAT>
@@ -1441,7 +1368,7 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
     }
     flat_geometry(a, 3, false);
     const size_t need = C7_WBYTES + (size_t)(256 + 6 * a.f_wp + 6) * 8;
-    if (need <= MAX_LDS && a.f_hwp < (1 << 23) && a.f_wp >= 2) {
+    if (need <= MAX_LDS && a.f_hwp < (1 << 23)) {
       static std::atomic<uint64_t> seen{0};
       allow_lds(conv7x7_c4_kernel<true>, seen, MAX_LDS);
       const size_t lds = need > (size_t)(256 * 136 * 2) ? need : (size_t)(256 * 136 * 2);

@@ -694,10 +694,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if constexpr (M16) {
           half8 wf[MI], xf[NJ];
           load_frags(ldsW + (TAP % 3) * WSTAGE, bx, Rl, TAP / 3 - 1, TAP % 3 - 1, wf, xf);
+#pragma unroll
+          for (int i = 0; i < MI; ++i) acc16[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[0], acc16[i][0], 0, 0, 0);
           if constexpr (T2 < 9) issueW2(T2, c, T2 % 3, std::true_type{}, true);
           else issueW2(T2 - 9, c + 1, T2 % 3, std::false_type{}, more);
           if constexpr (TAP < H32_XP) issueX2(c + 1, TAP, (c + 1) & 1, more && piece_used(TAP));
-          mma_frags(wf, xf);
+#pragma unroll
+          for (int j = 1; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc16[i][j], 0, 0, 0);
         } else {
           if constexpr (T2 < 9) issueW2(T2, c, T2 % 3, std::true_type{}, true);
           else issueW2(T2 - 9, c + 1, T2 % 3, std::false_type{}, more);

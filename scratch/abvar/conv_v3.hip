@@ -400,19 +400,15 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
 __device__ __forceinline__ void dma16s(uint64_t sbase, unsigned voff_bytes, unsigned lds_addr) {  // sbase, lds_addr wave-uniform
 #if defined(__HIP_DEVICE_COMPILE__)
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff_bytes), "s"(sbase), "s"(lds_addr)
-               : "memory");
+  (void)keep;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff_bytes), "s"(sbase), "s"(lds_addr) : "memory", "m0");
 #endif
 }
 __device__ __forceinline__ void dma16v(uint64_t lane_ptr, unsigned lds_addr) {  // per-lane source, lds_addr wave-uniform
 #if defined(__HIP_DEVICE_COMPILE__)
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(lane_ptr), "s"(lds_addr)
-               : "memory");
+  (void)keep;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(lane_ptr), "s"(lds_addr) : "memory", "m0");
 #endif
 }
 

@@ -663,9 +663,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   };
   auto mma_frags = [&](const half8 (&wf)[MI], const half8 (&xf)[NJ]) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int i = 0; i < MI; ++i) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc16[i][j], 0, 0, 0);
+      for (int j = 0; j < NJ; ++j) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc16[i][j], 0, 0, 0);
   };
 
   // ---- prologue: halo chunk 0, weights of steps 0 and 1

@@ -693,10 +693,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         constexpr int T2 = TAP + 2;
         if constexpr (M16) {
           half8 wf[MI], xf[NJ];
-          load_frags(ldsW + (TAP % 3) * WSTAGE, bx, Rl, TAP / 3 - 1, TAP % 3 - 1, wf, xf);
           if constexpr (T2 < 9) issueW2(T2, c, T2 % 3, std::true_type{}, true);
           else issueW2(T2 - 9, c + 1, T2 % 3, std::false_type{}, more);
           if constexpr (TAP < H32_XP) issueX2(c + 1, TAP, (c + 1) & 1, more && piece_used(TAP));
+          load_frags(ldsW + (TAP % 3) * WSTAGE, bx, Rl, TAP / 3 - 1, TAP % 3 - 1, wf, xf);
           mma_frags(wf, xf);
         } else {
           if constexpr (T2 < 9) issueW2(T2, c, T2 % 3, std::true_type{}, true);

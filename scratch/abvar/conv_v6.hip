@@ -697,7 +697,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           if constexpr (T2 < 9) issueW2(T2, c, T2 % 3, std::true_type{}, true);
           else issueW2(T2 - 9, c + 1, T2 % 3, std::false_type{}, more);
           if constexpr (TAP < H32_XP) issueX2(c + 1, TAP, (c + 1) & 1, more && piece_used(TAP));
+          __builtin_amdgcn_s_setprio(2);
           mma_frags(wf, xf);
+          __builtin_amdgcn_s_setprio(0);
         } else {
           if constexpr (T2 < 9) issueW2(T2, c, T2 % 3, std::true_type{}, true);
           else issueW2(T2 - 9, c + 1, T2 % 3, std::false_type{}, more);
