@@ -20,6 +20,6 @@ def run(cin, cout, k, reps=10, tag=''):
     fl = 2.0 * E * H * W * cin * cout * k * k
     print(f'{tag} cin={cin} cout={cout} k={k}: {ms:.3f} ms  {fl/ms/1e9:.0f} TFLOP/s', flush=True)
 for cfg in [(448, 256, 3), (448, 128, 3), (128, 128, 3), (128, 384, 3), (200, 128, 1), (128, 128, 1)]:
-    run(*cfg, tag=os.environ.get('VIPE_AMD_CONV_REGSTAGE', 'glds'))
+    run(*cfg, tag='halo')
 for cfg in [(128, 64, 3), (256, 4, 3)]:
     run(*cfg, tag='small')
