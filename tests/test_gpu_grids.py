@@ -621,3 +621,26 @@ def test_slam_system_on_16_9_frames():
     assert (g.ht, g.wd) == (41, 73) and g.corr.blocked and g.pgate is not None and g.corr.pool[0].dim() == 7
     assert tuple(sysm.buffer.fmaps.shape[-2:]) == (41, 73)
     assert out.slam_map is not None and len(out.slam_map.dense_disp_frame_inds) > 0
+
+
+def test_tile_convolution_beyond_4_gib_of_input():
+    """The halo source offsets are formed in 64 bits: a 384-channel input of more than 4 GiB (the heads' input of a
+    1900-edge backend chunk at 48 x 64) still takes the tile kernel and is right at both ends of the tensor."""
+    import torch.nn.functional as F
+    from vipe_amd._lib import check, lib, ptr, stream_ptr
+    from vipe_amd.slam.update_engine import _Packed
+    B, H, W, cin_tot, cin, cout = 1900, 48, 64, 384, 256, 4
+    assert B * H * W * cin_tot * 2 > 2**32
+    x = torch.zeros(B, H, W, cin_tot, dtype=torch.float16, device=dev())
+    g = torch.Generator().manual_seed(1)
+    for b in (0, B // 2, B - 1):
+        x[b] = (torch.randn(H, W, cin_tot, generator=g) * 0.5).half().to(dev())
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).half()
+    pk = _Packed(w, torch.zeros(cout), dev())
+    y = torch.zeros(B, H, W, 4, dtype=torch.float16, device=dev())
+    check(lib().vipe_conv2d_nhwc_f16(ptr(x), ptr(pk.packed), ptr(pk.bias), None, ptr(y), B, H, W, cin, cin_tot, 0, cout, 4, 0,
+                                     3, 3, 0, stream_ptr(x)), "conv")
+    for b in (0, B // 2, B - 1):
+        ref = F.conv2d(x[b, :, :, :cin].float().cpu().permute(2, 0, 1)[None], w.float(), None, padding=1)[0]
+        assert (y[b].float().cpu().permute(2, 0, 1) - ref).abs().max().item() < 4e-3, b
+    assert not y[1].any()

@@ -532,7 +532,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if constexpr (FLAT) xp = flat_pixel(q0 - pitch - 1 + (wave + 8 * i) * 16 + r16, e, a.H, a.W, a.f_wp, a.f_hwp, a.f_magic);
     else xp = xpix[i];
     const bool ok = xp >= 0 && (c0 + xk < a.Cin);
-    const unsigned off = ((unsigned)xp * (unsigned)ctot + (unsigned)(cb + xk)) * 2u;
+    const uint64_t off = ((uint64_t)(unsigned)xp * (unsigned)ctot + (unsigned)(cb + xk)) * 2u;  // one v_mad_u64_u32: no 4 GiB limit
     const char* src = reinterpret_cast<const char*>(s0 ? a.x0 : a.x1) + off;
     glds16(ok ? (const void*)src : (const void*)zp, ldsX_a + buf * xbytes + (wave + 8 * i) * 1024);
   };
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if constexpr (FLAT) xp = flat_pixel(q0 - pitch - 1 + (wave + 8 * i) * 16 + r16, e, a.H, a.W, a.f_wp, a.f_hwp, a.f_magic);
     else xp = xpix[i];
     const bool ok = on && xp >= 0 && (c0 + xk < a.Cin);
-    const unsigned off = ((unsigned)xp * (unsigned)ctot + (unsigned)(cb + xk)) * 2u;
+    const uint64_t off = ((uint64_t)(unsigned)xp * (unsigned)ctot + (unsigned)(cb + xk)) * 2u;  // one v_mad_u64_u32: no 4 GiB limit
     const uint64_t base = (uint64_t)(s0 ? a.x0 : a.x1);
     dma16v(ok ? base + off : zp64, on ? ldsX_u + buf * xbytes + i * 8192 : sink_u);
   };
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int i = 0; i < H32_XP; ++i) {
       if (wave + 8 * i < npieces) {
         const bool ok = xpix[i] >= 0 && (c0 + xk < a.Cin);
-        const unsigned off = ((unsigned)xpix[i] * (unsigned)ctot + (unsigned)(cb + xk)) * 2u;
+        const uint64_t off = ((uint64_t)(unsigned)xpix[i] * (unsigned)ctot + (unsigned)(cb + xk)) * 2u;
         const char* src = reinterpret_cast<const char*>(s0 ? a.x0 : a.x1) + off;
         glds16(ok ? (const void*)src : (const void*)zp, ldsX_a + buf * xbytes + (wave + 8 * i) * 1024);
       }
@@ -1410,7 +1410,7 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
   // such tiles, the FLAT tiling (256 consecutive positions of the row-padded image) for every other shape up to
   // W = 126; wider ragged images take the per-tap gather kernel.
   const bool sq13 = !small && a.KH == a.KW && (a.KH == 1 || a.KH == 3);
-  const bool off32 = (int64_t)a.B * a.H * a.W * (a.x0_ctot > a.x1_ctot ? a.x0_ctot : a.x1_ctot) * 2 < (1ll << 32);
+  const bool off32 = (int64_t)a.B * a.H * a.W < (1ll << 31);  // pixel indices are ints; byte offsets are formed in 64 bits
   const bool aligned = a.W % HALO_TW == 0 && a.H % HALO_TH == 0;
   const bool halo = sq13 && aligned && off32;
   const bool flat = sq13 && !aligned && off32 && flat_geometry(a, a.KH == 3 ? 1 : 0, a.KH == 1);
@@ -1431,7 +1431,7 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
     if (rc != VIPE_EUNSUPPORTED || a.accinit || a.epi == EPI_PARTIAL || a.ai_f32) return rc;
   }
   if (small && a.KH == 7 && a.KW == 7 && cp % 128 == 0 && kp == 256 && a.epi == EPI_PLAIN && a.extra == nullptr &&
-      (int64_t)a.B * a.H * a.W * a.x0_ctot * 2 < (1ll << 32)) {
+      (int64_t)a.B * a.H * a.W < (1ll << 31)) {
     const int gy = cp / 128;
     if (aligned) {
       static std::atomic<uint64_t> seen{0};

@@ -557,16 +557,17 @@ class FactorGraph:
         # The reference walks the source keyframes in groups of 8 (factor_graph.py:337-343) to bound memory.  The
         # operator couples edges only through GraphAgg's per-source-frame mean, so ANY partition that keeps every
         # source frame's edges together gives the same result: with 288 GB of HBM the groups are merged until a
-        # chunk holds up to VIPE_AMD_BACKEND_CHUNK_EDGES edges (default 1792, ~48 GB of pyramids) - normally one chunk.
+        # chunk holds up to VIPE_AMD_BACKEND_CHUNK_EDGES edges (default 4096, ~110 GB of pyramids at 48 x 64) - normally one chunk.
         # Edge indices come from the host mirror; chunks are selected with index vectors, not masks.
         h_ = self.host_edges()
         ii_np, jj_np = h_["ii"], h_["jj"]
         assert jj_np.max() >= ii_np.max()
         E_all = ii_np.shape[0]
-        # (the tile convolutions address their operands with 32-bit byte offsets: a chunk's widest tensor, the heads' 384-channel
-        # input, must stay below 4 GiB - 1820 edges at 48 x 64, 682 at 64 x 128)
-        max_edges = min(int(os.environ.get("VIPE_AMD_BACKEND_CHUNK_EDGES", "1792")),
-                        max(8, (2**32 - 1) // (self.ht * self.wd * 384 * 2)))
+        # a chunk's pyramids must fit the volume budget (VIPE_AMD_BACKEND_VOLUME_GB) whatever the grid: 33 MB per edge at
+        # 48 x 64, 238 MB at 64 x 128
+        per_edge = vol_bytes / max(1, self.ii.shape[0] * V)
+        max_edges = max(8, min(int(os.environ.get("VIPE_AMD_BACKEND_CHUNK_EDGES", "4096")),
+                               int(float(os.environ.get("VIPE_AMD_BACKEND_VOLUME_GB", "160")) * 2**30 / per_edge)))
         cnt = np.bincount(ii_np)
         groups, cur, cur_n = [], [], 0
         for g0 in range(0, len(cnt), 8):  # the reference's groups of 8 source frames are the merge unit
