@@ -266,9 +266,11 @@ class GraphBuffer:
         # expand poses into (n v) space: R_v^-1 * G_n   (geom.py:338)
         exp = (rig.inv().view((1, -1)) * poses.view((-1, 1))).view((-1,)).data.contiguous()
         intr = self._pinhole_intrinsics_8()
-        d = slam_ext.frame_distance(exp, self.flattened_disps, intr, pi * V + qi, pj * V + qj, qi, qj, di, beta)
+        # one view: frame index = pose index (no index arithmetic on the device: six launches per call otherwise)
+        fi, fj = (pi, pj) if V == 1 else (pi * V + qi, pj * V + qj)
+        d = slam_ext.frame_distance(exp, self.flattened_disps, intr, fi, fj, qi, qj, di, beta)
         if bidirectional:
-            d2 = slam_ext.frame_distance(exp, self.flattened_disps, intr, pj * V + qj, pi * V + qi, qj, qi, dj, beta)
+            d2 = slam_ext.frame_distance(exp, self.flattened_disps, intr, fj, fi, qj, qi, dj, beta)
             d = 0.5 * (d + d2)
         return d.view(-1, V)
 

@@ -168,7 +168,8 @@ class FactorGraph:
                 self.corr = CorrPool(capacity=max(64, self.max_factors + 16))
             V = self.buffer.n_views
             lo, hi = int(min(ii_h.min(), jj_h.min())), int(max(ii_h.max(), jj_h.max()))
-            self.corr.add_edges(self.buffer.flattened_fmaps, pi * V + qi, pj * V + qj, frame_range=(lo * V, (hi + 1) * V))
+            f1, f2 = (pi, pj) if V == 1 else (pi * V + qi, pj * V + qj)  # one view: frame index = pose index
+            self.corr.add_edges(self.buffer.flattened_fmaps, f1, f2, frame_range=(lo * V, (hi + 1) * V))
             WORK["pyramids_built"] += int(pi.shape[0])
             xb = torch.zeros((ii.shape[0] * self.buffer.n_views, self.ht, self.wd, 320), dtype=torch.half,
                              device=self.device)
@@ -488,7 +489,7 @@ class FactorGraph:
                 ii = torch.cat([self.ii_inac[sel], self.ii], 0)
                 jj = torch.cat([self.jj_inac[sel], self.jj], 0)
                 V = buf.n_views
-                sel_exp = (sel.view(-1, 1) * V + torch.arange(V, device=self.device).view(1, -1)).view(-1)
+                sel_exp = sel if V == 1 else (sel.view(-1, 1) * V + torch.arange(V, device=self.device).view(1, -1)).view(-1)
                 base = int(min(h["ii"].min(), h["jj"].min(), *(h[k][sel_h].min() for k in ("ii_inac", "jj_inac") if sel_h.size)))
                 P[key] = (ii, jj, sel_exp, self._shift_plan(buf.expand_edge_multiview(ii, jj)[:5], base))
             ii, jj, sel_exp, plan = P[key]

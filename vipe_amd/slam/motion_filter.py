@@ -66,8 +66,12 @@ class MotionFilter:
         self._xbuf = torch.empty((V, ht, wd, 320), dtype=torch.float16, device=net.device)
         self._xbuf[..., :128] = inp.permute(0, 2, 3, 1)
         self._pgate = eng.gate_context(self._xbuf) if eng.supports_gate_split(ht, wd) else None
-        self._motn0 = torch.zeros((V, ht, wd, 4), dtype=torch.float16, device=net.device)
-        self._coords0 = self.coords_grid(ht, wd, device=net.device)[None].repeat(V, 1, 1, 1).contiguous()
+        m0 = getattr(self, "_motn0", None)  # zero motion features (read only): built once per map size
+        if m0 is None or tuple(m0.shape) != (V, ht, wd, 4) or m0.device != net.device:
+            self._motn0 = torch.zeros((V, ht, wd, 4), dtype=torch.float16, device=net.device)
+        c0 = getattr(self, "_coords0", None)  # the identity grid only depends on the map size: built once
+        if c0 is None or tuple(c0.shape) != (V, ht, wd, 2) or c0.device != net.device:
+            self._coords0 = self.coords_grid(ht, wd, device=net.device)[None].repeat(V, 1, 1, 1).contiguous()
 
     @torch.no_grad()
     def check(self, images, buffer_masks=None):
