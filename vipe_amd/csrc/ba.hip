@@ -2117,6 +2117,7 @@ __global__ __launch_bounds__(2 * BAND_T) void ba_solve_band_kernel(BAArgs a, int
 // (look-ahead), barrier.  Back substitution by wave 0 alone, column oriented, wave barriers only.
 // Sets info[5] = 2 when it solved the system.
 constexpr int DN_T = 512;
+typedef double double4c __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_doubles) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -2129,36 +2130,68 @@ __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_
   const int NP = (n + 1) * (n + 2) / 2;  // packed size incl. the rhs row
   // info[5] == 1: the band solver (which resets the flag whenever it runs) solved THIS iteration.  A 2 can only be this
   // kernel's own mark from the previous Gauss-Newton iteration of the call (ba_sens_kernel clears the flag per call).
-  if (n == 0 || w.info[5] == 1 || a.mv || NP + 64 + n > lds_doubles || F > 2 || n > 192) return;
+  if (n == 0 || w.info[5] == 1 || a.mv || NP + 64 + n + 6 * (n + 6) > lds_doubles || F > 2 || n > 192) return;
   double* const blk = L + NP;   // 6x7: the current diagonal factor block
   double* const rd = blk + 42;  // its reciprocal pivots
   int* const failp = reinterpret_cast<int*>(rd + 6);
   double* const rdall = rd + 8; // [n] reciprocal pivots of every column (back substitution)
+  double* const Linv = rdall + n + 8;  // [blocks][6][6] inverses of the diagonal factor blocks, zero above the diagonal
   auto off = [](int r) { return r * (r + 1) / 2; };
   const double* S = w.S;
   const int ld = w.ld;
   if (t == 0) *failp = 0;
-  // ---- load with LM damping on the diagonal (matrix.py:179-186): one row per wave and pass, lanes over the columns;
-  //      unrolled so that eight rows (x up to 4 column passes) are in flight per wave - the loop is otherwise one L2
-  //      round trip per row
-  {
-    const int wv = t >> 6, ln = t & 63;
-    const int passes = (n + 63) >> 6;
-    for (int cp = 0; cp < passes; ++cp) {
-      const int c = cp * 64 + ln;
-#pragma unroll 8
-      for (int r = wv; r <= n; r += DN_T / 64) {
-        if (c <= r && c < n) {
-          double v = S[(int64_t)r * ld + c];
-          if (c == r) {
-            const bool pose = r < npr;
-            v += (pose ? (double)prm.pose_ep : 1e-6) + (pose ? (double)prm.pose_damping : 1e-6) * (a.droid ? v : w.Hd[r]);
+  // ---- the matrix (rows 0..n, row n = rhs; LM damping on the diagonal, matrix.py:179-186) goes into REGISTERS: 16 x 16
+  //      tiles of the lower triangle in the accumulator layout of v_mfma_f64_16x16x4_f64 (lane (l16, kq), element r4 =
+  //      row kq + 4 r4, column l16), tile tau = I (I + 1) / 2 + J owned by wave tau % 8 as its slot tau / 8.  The
+  //      trailing update of a block step is then two matrix instructions per live tile with NO read-modify-write of
+  //      the matrix through LDS (the scalar update walked the packed triangle: 8 LDS accesses per entry and step, 5.6 us
+  //      per step at n = 150); LDS holds only what has left the registers: the factor's columns (packed rows, read by
+  //      the panel, the update's operand fragments and the back substitution).
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l16 = lane & 15, kq = lane >> 4;
+  const int NTR = (n + 16) >> 4, NTL = NTR * (NTR + 1) / 2;  // tile rows covering rows 0..n; tiles of the triangle
+  constexpr int DN_SLOTS = 12;                               // 8 waves x 12 >= 91 tiles (n <= 192)
+  int tI[DN_SLOTS], tJ[DN_SLOTS];
+  double4c T[DN_SLOTS];
+#pragma unroll
+  for (int sl = 0; sl < DN_SLOTS; ++sl) {
+    const int tau = wave + 8 * sl;
+    int ti = (int)((sqrtf(8.0f * (float)tau + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= tau) ++ti;
+    while (ti * (ti + 1) / 2 > tau) --ti;
+    tI[sl] = tau < NTL ? ti : -1;
+    tJ[sl] = tau - ti * (ti + 1) / 2;
+    T[sl] = double4c{0.0, 0.0, 0.0, 0.0};
+    if (tI[sl] >= 0) {
+      const int col = 16 * tJ[sl] + l16;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int row = 16 * tI[sl] + kq + 4 * r4;
+        double v = 0.0;
+        if (row <= n && col < n && col <= row) {
+          v = S[(int64_t)row * ld + col];
+          if (col == row) {
+            const bool pose = row < npr;
+            v += (pose ? (double)prm.pose_ep : 1e-6) + (pose ? (double)prm.pose_damping : 1e-6) * (a.droid ? v : w.Hd[row]);
           }
-          L[off(r) + c] = v;
         }
+        T[sl][r4] = v;
       }
     }
   }
+  // columns j0 .. R0 - 1 of the trailing matrix (rows >= the column) leave the registers for their packed rows
+  auto extract = [&](int j0, int R0) {
+#pragma unroll
+    for (int sl = 0; sl < DN_SLOTS; ++sl) {
+      if (tI[sl] < 0 || 16 * tJ[sl] >= R0 || 16 * tJ[sl] + 16 <= j0 || 16 * tI[sl] + 15 < j0) continue;  // wave-uniform
+      const int col = 16 * tJ[sl] + l16;
+      if (col < j0 || col >= R0) continue;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int row = 16 * tI[sl] + kq + 4 * r4;
+        if (row >= col && row <= n) L[off(row) + col] = T[sl][r4];
+      }
+    }
+  };
   const int nblk = n_free + (F > 0 ? 1 : 0);
   // factor the diagonal block of step kb (bw columns); publish L, blk, rd.  Executed by the whole of wave 0: lane i < 6
   // holds row i of the block, the pivot and the column entries other rows need travel by v_readlane (compile-time
@@ -2206,11 +2239,18 @@ __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_
       }
     }
   };
-  __syncthreads();
-  if (t < 64) factor_diag(0);
-  __syncthreads();
+  // @stamp 1
   for (int kb = 0; kb < nblk; ++kb) {
     const int j0 = 6 * kb, bw = min(6, n - j0), R0 = j0 + bw;
+    // @stampk 0
+    extract(j0, R0);
+    // @stampk 1
+    __syncthreads();
+    // @stampk 2
+    if (t < 64) factor_diag(kb);
+    // @stampk 3
+    __syncthreads();
+    // @stampk 4
     // panel: rows R0..n (row n = rhs)
     {
       const int r = R0 + t;
@@ -2229,130 +2269,142 @@ __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_
           if (j < bw) row[j] = x[j];
       }
     }
+    // @stampk 5
     __syncthreads();
-    const int nbw = min(6, n - R0);  // width of the next diagonal block
-    if (t < 64) {
-      // wave 0: the next diagonal block's entries (i, j), j <= i < nbw, then its factorisation by lane 0
-      if (t < 21) {
-        const int i = SYM_R[t], j = SYM_C[t];
-        if (i < nbw) {
-          const double* pa = L + off(R0 + i) + j0;
-          const double* pb = L + off(R0 + j) + j0;
-          double sacc = 0.0;
+    // @stampk 6
+    // trailing update T -= P P^T on the matrix cores: operand fragments are rows of the solved panel (6 columns, padded
+    // to 8 with zeros); tiles whose columns all lie left of R0 are finished and skipped
 #pragma unroll
-          for (int m = 0; m < 6; ++m)
-            if (m < bw) sacc = __builtin_fma(pa[m], pb[m], sacc);
-          L[off(R0 + i) + R0 + j] -= sacc;
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (kb + 1 < nblk) factor_diag(kb + 1);
-    } else {
-      // waves 1..7: rows r >= R0 + nbw (the rows of the next diagonal block belong to wave 0), columns R0 <= c <= min(r, n - 1).
-      // Four columns per pass: their operands are fetched together and the four dot products are independent chains
-      // (a dependent fp64 op costs ~40 cycles on this part; LDS stores would otherwise order the loads of the next column)
-      const int u = t - 64, rr = u >> 4, cc = u & 15;  // 28 x 16
-      for (int r = R0 + nbw + rr; r <= n; r += 28) {
-        const double* pa = L + off(r) + j0;
-        double xr[6];
-#pragma unroll
-        for (int m = 0; m < 6; ++m) xr[m] = m < bw ? pa[m] : 0.0;
-        double* drow = L + off(r);
-        const int cmax = min(r, n - 1);
-        for (int c0 = R0 + cc; c0 <= cmax; c0 += 64) {
-          double pb[4][6], dv[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int c = min(c0 + 16 * q, cmax);
-            const double* pbq = L + off(c) + j0;
-#pragma unroll
-            for (int m = 0; m < 6; ++m) pb[q][m] = m < bw ? pbq[m] : 0.0;
-            dv[q] = drow[c];
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            double sacc = dv[q];
-#pragma unroll
-            for (int m = 0; m < 6; ++m) sacc = __builtin_fma(-xr[m], pb[q][m], sacc);
-            dv[q] = sacc;
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (c0 + 16 * q <= cmax) drow[c0 + 16 * q] = dv[q];
-        }
-      }
+    for (int sl = 0; sl < DN_SLOTS; ++sl) {
+      if (tI[sl] < 0 || 16 * tJ[sl] + 15 < R0) continue;  // wave-uniform
+      const int ar = 16 * tI[sl] + l16, bc = 16 * tJ[sl] + l16;
+      const bool aok = ar >= R0 && ar <= n, bok = bc >= R0 && bc < n;
+      const double* pa = L + off(aok ? ar : 0) + j0;
+      const double* pb = L + off(bok ? bc : 0) + j0;
+      const double a0 = (aok && kq < bw) ? pa[kq] : 0.0, b0 = (bok && kq < bw) ? pb[kq] : 0.0;
+      const double a1 = (aok && kq + 4 < bw) ? pa[kq + 4] : 0.0, b1 = (bok && kq + 4 < bw) ? pb[kq + 4] : 0.0;
+      T[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, T[sl], 0, 0, 0);
+      T[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, T[sl], 0, 0, 0);
     }
-    __syncthreads();
+    // no barrier here: the next step's extract writes columns >= R0 of rows >= R0, which nobody reads before the barrier
+    // that follows it; the panel columns read above are not written again
+    // @stampk 7
   }
-  // ---- back substitution L^T x = y (y = row n), wave 0, column oriented: once x of block kb is known every lane
-  //      subtracts its columns' contributions from y
-  double* y = L + off(n);
-  if (t < 64) {
-    // operands that do not depend on the running y - the block factor, its reciprocal pivots and this lane's columns of
-    // the six block rows - are fetched one block AHEAD, so that only y sits on the dependent chain
-    double Lk[6][6], rp[6], lc[3][6];
-    auto fetch_block = [&](int kb) {
+  // @stamp 2
+  // ---- back substitution L^T x = y (y = row n).  First every diagonal block is replaced by its INVERSE (thread = one
+  //      column of one block; all blocks at once), so that a block's six unknowns are six independent dot products
+  //      instead of a twelve-step substitution chain.  Then wave 0 alone, y in REGISTERS (lane c holds y[c], y[c + 64],
+  //      y[c + 128]): per block the six y entries come by v_readlane, every lane forms all six x (uniform values, the
+  //      inverse block by broadcast reads) and subtracts its columns' contributions; the next block's operands are
+  //      fetched while the current one is on the chain.  The version that kept y in LDS spent 2 570 cycles per block
+  //      (LDS round trip of y behind the 39 in-order prefetch reads) where the dependent chain is ~500.
+  const double* y = L + off(n);
+  __syncthreads();
+  {
+    const int kb = t / 6, q = t - 6 * kb;
+    if (kb < nblk) {
       const int j0 = 6 * kb, bw = min(6, n - j0);
+      double z[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        rp[i] = i < bw ? rdall[j0 + i] : 0.0;
+        // column q of the inverse: z_q = 1 / L_qq, z_i = -(sum_{q <= m < i} L_im z_m) / L_ii; zero rows beyond the matrix
+        double sacc = 0.0;
 #pragma unroll
-        for (int j = 0; j < i; ++j) Lk[i][j] = i < bw ? L[off(j0 + i) + j0 + j] : 0.0;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          const int c = t + 64 * q;
-          lc[q][i] = (i < bw && c < j0) ? L[off(j0 + i) + c] : 0.0;
-        }
+        for (int m = 0; m < i; ++m) sacc = __builtin_fma((i < bw) ? L[off(j0 + i) + j0 + m] : 0.0, (m >= q) ? z[m] : 0.0, sacc);
+        const double ri = (i < bw) ? rdall[j0 + i] : 0.0;
+        z[i] = (q < bw) ? ((i == q) ? ri : ((i > q) ? -sacc * ri : 0.0)) : 0.0;
+        Linv[kb * 36 + 6 * i + q] = z[i];
       }
-    };
-    fetch_block(nblk - 1);
-    for (int kb = nblk - 1; kb >= 0; --kb) {
-      const int j0 = 6 * kb, bw = min(6, n - j0);
-      double x[6];
-#pragma unroll
-      for (int j = 5; j >= 0; --j) {
-        double sacc = j < bw ? y[j0 + j] : 0.0;
-#pragma unroll
-        for (int m = 5; m > j; --m) sacc = __builtin_fma(-Lk[m][j], x[m], sacc);
-        x[j] = sacc * rp[j];
-      }
-      double dy[3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        dy[q] = lc[q][0] * x[0];
-#pragma unroll
-        for (int j = 1; j < 6; ++j) dy[q] = __builtin_fma(lc[q][j], x[j], dy[q]);
-      }
-      if (t < bw) {
-        double xo = x[0];
-#pragma unroll
-        for (int j = 1; j < 6; ++j) xo = t == j ? x[j] : xo;
-        y[j0 + t] = xo;
-      }
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int c = t + 64 * q;
-        if (c < j0) y[c] -= dy[q];
-      }
-      if (kb > 0) fetch_block(kb - 1);  // independent of y: overlaps the y round trip above
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
     }
   }
   __syncthreads();
+  // @stamp 3
   const bool bad = *failp != 0;
-  if (t == 0) {
-    if (bad) w.info[2] += 1;
-    w.info[5] = 2;
+  if (t < 64) {
+    // y in registers: column c = 48 q + lane (lanes 0..47; 48 = 8 blocks, so a block never straddles two registers).
+    // Per block: its six y entries by v_readlane, x_q in the block's own lanes (lane 6 kbl + q holds column q of the
+    // inverse), x back to every lane by v_readlane, then each lane subtracts its columns' contributions.  Operands are
+    // fetched a block ahead with UNCONDITIONAL loads (what lies right of the block in a packed row is discarded by a
+    // select on the result): a predicated load costs a branch, and a spilled operand a scratch round trip.
+    constexpr int YR = 4;
+    double yv[YR];
+#pragma unroll
+    for (int q = 0; q < YR; ++q) yv[q] = (t < 48 && 48 * q + t < n) ? y[48 * q + t] : 0.0;
+    const int qmax = (nblk - 1) >> 3;
+    auto run_reg = [&](auto QC, int kb_hi) {  // blocks kb_hi .. 8 Q, register Q
+      constexpr int Q = decltype(QC)::value;
+      double col[2][6], lc[2][Q + 1][6];
+      auto fetch = [&](int kb, double (&cv)[6], double (&lv)[Q + 1][6]) {
+        const int j0 = 6 * kb;
+        const double* ci = Linv + kb * 36 + (t - 6 * (kb - 8 * Q));  // column (lane - first lane of the block)
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+          cv[m] = ci[6 * m];
+          const double* row = L + off(j0 + m) + t;
+#pragma unroll
+          for (int q = 0; q <= Q; ++q) lv[q][m] = row[48 * q];
+        }
+      };
+      auto solve = [&](int kb, const double (&cv)[6], const double (&lv)[Q + 1][6]) {
+        const int kbl = kb - 8 * Q, j0 = 6 * kb, l0 = 6 * kbl;
+        double v[6], x[6];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) v[m] = readlane_f64(yv[Q], l0 + m);
+        double s0 = cv[0] * v[0], s1 = cv[1] * v[1];
+        s0 = __builtin_fma(cv[2], v[2], s0);
+        s1 = __builtin_fma(cv[3], v[3], s1);
+        s0 = __builtin_fma(cv[4], v[4], s0);
+        s1 = __builtin_fma(cv[5], v[5], s1);
+        const double xq = s0 + s1;  // x of column (lane - l0) in the block's lanes
+#pragma unroll
+        for (int m = 0; m < 6; ++m) x[m] = readlane_f64(xq, l0 + m);
+#pragma unroll
+        for (int q = 0; q <= Q; ++q) {
+          double d0 = lv[q][0] * x[0], d1 = lv[q][1] * x[1];
+          d0 = __builtin_fma(lv[q][2], x[2], d0);
+          d1 = __builtin_fma(lv[q][3], x[3], d1);
+          d0 = __builtin_fma(lv[q][4], x[4], d0);
+          d1 = __builtin_fma(lv[q][5], x[5], d1);
+          const double nv = yv[q] - (d0 + d1);
+          yv[q] = (t < 48 && 48 * q + t < j0) ? nv : yv[q];  // columns left of the block
+        }
+        yv[Q] = (t >= l0 && t < l0 + 6) ? xq : yv[Q];  // the block's own entries become x
+      };
+      int kb = kb_hi;
+      fetch(kb, col[0], lc[0]);
+      while (true) {  // two blocks per trip: the operand buffers are named at compile time
+        if (kb > 8 * Q) fetch(kb - 1, col[1], lc[1]);
+        solve(kb, col[0], lc[0]);
+        if (--kb < 8 * Q) break;
+        if (kb > 8 * Q) fetch(kb - 1, col[0], lc[0]);
+        solve(kb, col[1], lc[1]);
+        if (--kb < 8 * Q) break;
+      }
+    };
+    if (qmax >= 3) run_reg(std::integral_constant<int, 3>{}, nblk - 1);
+    if (qmax >= 2) run_reg(std::integral_constant<int, 2>{}, qmax == 2 ? nblk - 1 : 23);
+    if (qmax >= 1) run_reg(std::integral_constant<int, 1>{}, qmax == 1 ? nblk - 1 : 15);
+    run_reg(std::integral_constant<int, 0>{}, qmax == 0 ? nblk - 1 : 7);
+    if (t < 48) {
+#pragma unroll
+      for (int q = 0; q < YR; ++q) {
+        const int dd = 48 * q + t;
+        if (dd < n) {
+          double x = yv[q];
+          if (bad || !(x == x)) x = 0.0;
+          w.dx[dd] = (float)x;
+        }
+      }
+    }
+    if (t == 0) {
+      if (bad) w.info[2] += 1;
+      w.info[5] = 2;
+    }
   }
-  for (int dd = t; dd < n; dd += DN_T) {
-    double x = y[dd];
-    if (bad || !(x == x)) x = 0.0;
-    w.dx[dd] = (float)x;
-  }
+  // @stamp 4
   __syncthreads();
   apply_retraction(a, t, DN_T, n_free);
+  // @stamp 5
 }
 
 // ------------------------------------------------------------------------------------------------ solve
@@ -2638,7 +2690,6 @@ __global__ __launch_bounds__(SOLVE_T) void ba_solve_kernel(BAArgs a, int panel_c
 // so the order is immaterial).  A dependent fp64 operation costs ~40 cycles on this part: the pivot chain alone is
 // ~0.15 us per column - the floor of any Cholesky here - which is why the diagonal tile stays in one wave's registers.
 constexpr int CT = 64;
-typedef double double4c __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double rsqrt_seeded(double x) {
   // branch free (the callers are long fully unrolled blocks): pivots of a damped normal matrix are far inside the float
