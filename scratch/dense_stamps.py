@@ -16,11 +16,15 @@ for N in (16, 26):
         poses, disps = T(g.poses).clone(), T(g.disps).clone()
         slam_ext.dense_ba(poses, disps, *args, 1, N, 2, 1e-3, 0.1)
     torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * 1024)()
+    buf = (ctypes.c_ulonglong * 4096)()
     dll.vipe_dbg_dn_stamps(buf)
     s = np.array(buf[:], dtype=np.int64)
     nb = N - 1
     print(f"N={N} n={6*nb}: load {s[1]-s[0]}  loop {s[2]-s[1]}  blockinv {s[3]-s[2]}  backsub {s[4]-s[3]}  retract {s[5]-s[4]}  total {s[5]-s[0]} (ticks of s_memtime = 100 MHz? see ratio)")
-    ph = np.array([[s[8 + 8*k + i + 1] - s[8 + 8*k + i] for i in range(7)] for k in range(nb)])
-    print("  per-step mean [extract, bar, factor, bar, panel, bar, update]:", ph.mean(0).round(0), " sum", ph.sum())
+    ph = np.array([[s[8 + 8*k + i + 1] - s[8 + 8*k + i] for i in range(5)] for k in range(nb)])
+    print("  per-step mean wave 0: [own panel rows, barrier, next block + factor, -, barrier]:", ph.mean(0).round(0), " sum", ph.sum())
     print("  first step", ph[0], " last", ph[-1])
+    for tw in range(6):
+        b = 512 + 256 * tw
+        wp = np.array([[s[b + 8*k + i + 1] - s[b + 8*k + i] for i in range(5)] for k in range(nb - 1)])
+        print(f"  tile wave {tw} per-step mean [panel, barrier, update, extract, barrier]:", wp.mean(0).round(0), " first", wp[0], " mid", wp[nb // 2])

@@ -1561,24 +1561,36 @@ __device__ __forceinline__ void band_solve_body(const BAArgs& a, int lds_doubles
   {
     // one band row (WB <= 64 doubles, contiguous in S) per wave and iteration; unrolled so that a dozen row loads are
     // in flight per wave (the loop is otherwise one L2 round trip per row)
-    const int wv = t >> 6, ln = t & 63;
-    auto load_entry = [&](int r, int l2) {
-      const int c = 6 * (r / 6) - PB + l2;
-      double v = 0.0;
-      if (l2 < WB && c >= 0 && c <= r) {
-        v = S[(int64_t)r * ld + c];
-        if (c == r) v += (double)prm.pose_ep + (double)prm.pose_damping * (a.droid ? v : w.Hd[r]);  // DROID: geom_kernels.cu:1176
+    // Sixteen rows per pass with every load of the pass - matrix entries AND the damping diagonal - issued from clamped
+    // addresses before the first use: as `load; if (diagonal) load Hd; store` the loop was one memory round trip per row
+    // (the second load depends on a branch on the first; stamps: 34.7k cycles to load the headline's two images).
+    // The row is wave-uniform: its block arithmetic runs on the scalar unit (as per-entry divisions it was the loop's bulk).
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6), ln = t & 63;
+    constexpr int CH = 16, NC = TWO ? 2 : 1;
+    const bool dr = a.droid;
+    const double dep = (double)prm.pose_ep, ddm = (double)prm.pose_damping;
+    for (int r0 = wv; r0 < npr; r0 += CH * (BAND_T / 64)) {
+      double sv[CH][NC], hv[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int r = min(r0 + i * (BAND_T / 64), npr - 1), rb6 = 6 * (r / 6);
+        hv[i] = dr ? 0.0 : w.Hd[r];
+#pragma unroll
+        for (int h = 0; h < NC; ++h) sv[i][h] = S[(int64_t)r * ld + min(max(rb6 - PB + ln + 64 * h, 0), r)];
       }
-      if (l2 < WBP) L[r * WBP + l2] = v;
-    };
-    if constexpr (!TWO) {  // neighbourhood graphs: one lane per band column, a dozen row loads in flight per wave
-#pragma unroll 12
-      for (int r = wv; r < npr; r += BAND_T / 64) load_entry(r, ln);
-    } else {  // dense windows: two band columns per lane
-#pragma unroll 6
-      for (int r = wv; r < npr; r += BAND_T / 64) {
-        load_entry(r, ln);
-        load_entry(r, ln + 64);
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int r = r0 + i * (BAND_T / 64);
+        if (r < npr) {
+          const int rb6 = 6 * (r / 6), rm = r - rb6;
+#pragma unroll
+          for (int h = 0; h < NC; ++h) {
+            const int l2 = ln + 64 * h;
+            double v = (l2 < WB && rb6 + l2 >= PB && l2 <= rm + PB) ? sv[i][h] : 0.0;
+            if (l2 == rm + PB) v += dep + ddm * (dr ? v : hv[i]);  // DROID: geom_kernels.cu:1176
+            if (l2 < WBP) L[r * WBP + l2] = v;
+          }
+        }
       }
     }
   }
@@ -1853,33 +1865,86 @@ __device__ __forceinline__ bool band2_solve_body(const BAArgs& a, int lds_double
   double* const LB = LA + IMG;
   const double* S = w.S;
   auto gblk = [&](int l) { return g ? nb - 1 - l : l; };  // local block -> global block
+  // @bstamp 0
+  // @bwave 100
   if (t == 0) { *failp = 0; w.info[5] = 0; }
 
   // ---- load both images (LM damping on the diagonal, matrix.py:179-186).  Image B: mirrored; its separator square and
   // separator right-hand side start from zero (they only collect chain B's contributions)
   {
-    const int wv = tl >> 6, ln = tl & 63;
-#pragma unroll 6
-    for (int r = wv; r < npr; r += B2_T / 64) {
-      const int lr = r / 6, c = 6 * lr - PB + ln;
-      double v = 0.0;
-      if (ln < WB && c >= 0 && c <= r) {
-        const int lc = c / 6;
-        const int R = 6 * gblk(lr) + r % 6, C = 6 * gblk(lc) + c % 6;
-        const bool sepsq = g && lr >= chain && lc >= chain;
-        if (!sepsq) {
-          v = R >= C ? S[(int64_t)R * ld + C] : S[(int64_t)C * ld + R];
-          if (c == r) v += (double)prm.pose_ep + (double)prm.pose_damping * (a.droid ? v : w.Hd[R]);
+    // Sixteen rows per pass, every load of the pass in flight before the first use (see band_solve_body), and NO per-entry
+    // index arithmetic: the row is wave-uniform (scalar unit), what depends on the lane is a constant of the lane.  The
+    // first form of this loop spent its time issuing integer divisions - four waves per SIMD, 14k .. 38k cycles by wave
+    // (stamps).  Image A reads its band rows as they lie in S.  Image B is the MIRRORED matrix (its band row is a column
+    // of S): it walks the rows of S as well and scatters every entry to its mirrored position (zero-filled first).
+    const int wv = __builtin_amdgcn_readfirstlane(tl >> 6), ln = tl & 63;
+    const int lq = ln / 6, lm = ln - 6 * lq;
+    constexpr int CH = 20;  // the headline's images: 19 rows per wave, one pass = one memory round trip
+    const bool dr = a.droid;
+    const double dep = (double)prm.pose_ep, ddm = (double)prm.pose_damping;
+    if (g)
+      for (int idx = tl; idx < npr * WBP; idx += B2_T) L[idx] = 0.0;
+    __syncthreads();
+    if (!g) {
+      for (int r0 = wv; r0 < npr; r0 += CH * (B2_T / 64)) {
+        double sv[CH], hv[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int r = min(r0 + i * (B2_T / 64), npr - 1), rb6 = 6 * (r / 6);
+          sv[i] = S[(int64_t)r * ld + min(max(rb6 - PB + ln, 0), r)];
+          hv[i] = dr ? 0.0 : w.Hd[r];
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int r = r0 + i * (B2_T / 64);
+          if (r < npr) {
+            const int rb6 = 6 * (r / 6), rm = r - rb6;
+            double v = (ln < WB && rb6 + ln >= PB && ln <= rm + PB) ? sv[i] : 0.0;
+            if (ln == rm + PB) v += dep + ddm * (dr ? v : hv[i]);
+            if (ln < WBP) L[r * WBP + ln] = v;
+          }
         }
       }
-      if (ln < WBP) L[r * WBP + ln] = v;
+    } else {
+      const int G0 = 6 * (nb - nf);  // first global row of image B's blocks
+      // target offset of lane ln's entry of global row Cg (block bcl = nb - 1 - Cg / 6 locally, cm = Cg % 6):
+      //   own block (ln >= PB): (6 bcl + cm) WBP + lm + PB - inside a diagonal block the mirrored matrix keeps the row /
+      //   column order, so the entry goes to the transposed position; left of it: local row block bcl + bandblk - lq
+      const bool own = ln >= PB;
+      const int K1 = 6 * (bandblk - lq);
+      const int lconst = own ? lm : (K1 + lm) * WBP - K1;
+      for (int r0 = wv; r0 < npr; r0 += CH * (B2_T / 64)) {
+        double sv[CH], hv[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int Cg = G0 + min(r0 + i * (B2_T / 64), npr - 1), cb6 = 6 * (Cg / 6);
+          sv[i] = S[(int64_t)Cg * ld + min(max(cb6 - PB + ln, G0), Cg)];
+          hv[i] = dr ? 0.0 : w.Hd[Cg];
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int rr = r0 + i * (B2_T / 64);
+          const int Cg = G0 + rr, cq = Cg / 6, cb6 = 6 * cq, cm = Cg - cb6, bcl = nb - 1 - cq;
+          // rows of the separator: their own square starts from zero (the zero fill), their chain columns are loaded
+          if (rr < npr && ln < WB && cb6 - PB + ln >= G0 && ln <= cm + PB) {
+            const bool sepsq = bcl >= chain && (own || bcl + bandblk - lq >= chain);
+            const int A1 = 6 * bcl * WBP + PB;
+            double v = sepsq ? 0.0 : sv[i];
+            if (ln == cm + PB && !sepsq) v += dep + ddm * (dr ? v : hv[i]);
+            L[(own ? A1 + cm * WBP : A1 + cm) + lconst] = v;
+          }
+        }
+      }
     }
+    // @bwave 120
+    // @bstamp 8
     for (int c = tl; c <= npr; c += B2_T) {
       double v = 0.0;
       if (c < npr && !(g && c / 6 >= chain)) v = S[(int64_t)n * ld + 6 * gblk(c / 6) + c % 6];
       y[c] = v;
     }
   }
+  // @bstamp 9
   // ---- per-thread operand descriptors (as in band_solve_body, one tail row = the right-hand side)
   int prow_off = 0, prow_str = 0, prow_ia = -1;
   const bool has_prow = tl < PB + 1;
@@ -1914,6 +1979,8 @@ __device__ __forceinline__ bool band2_solve_body(const BAArgs& a, int lds_double
       uD[sl] = nprmax * WBP + 6 + ib; sD[sl] = 6;
     }
   }
+  // @bstamp 10
+  // @bwave 140
   auto bofs = [&](int r, int c) { return r * WBP + c - 6 * (r / 6) + PB; };
   auto factor_diag = [&](int kb) {
     const int j0 = 6 * kb;
@@ -1983,8 +2050,10 @@ __device__ __forceinline__ bool band2_solve_body(const BAArgs& a, int lds_double
     }
   };
   __syncthreads();
+  // @bstamp 1
   if (tl == 0) factor_diag(0);
   __syncthreads();
+  // @bstamp 2
   // ---- both chains, one block per step
   for (int kb = 0; kb < cb; ++kb) {
     const bool mine = kb < chain;
@@ -1993,6 +2062,7 @@ __device__ __forceinline__ bool band2_solve_body(const BAArgs& a, int lds_double
     if (mine) trailing(kb, chain);  // the look-ahead stops at the chain's end: the separator is not final yet
     __syncthreads();
   }
+  // @bstamp 3
   // ---- chain B's contributions to the separator square and right-hand side go to image A (mirrored back)
   for (int idx = t; idx < PB * PB + PB; idx += 2 * B2_T) {
     if (idx < PB * PB) {
@@ -2019,6 +2089,7 @@ __device__ __forceinline__ bool band2_solve_body(const BAArgs& a, int lds_double
     if (g == 0) trailing(kb, ca + bandblk);
     __syncthreads();
   }
+  // @bstamp 4
   // ---- back substitution, column oriented as in band_solve_body (one wave per image): separator first (image A) ...
   auto backsub_block = [&](int kb, bool known, int colmax) {
     // x of block kb (solved here, or `known`: already in y), then y[band columns < colmax] -= L[block rows][column] x
@@ -2065,6 +2136,7 @@ __device__ __forceinline__ bool band2_solve_body(const BAArgs& a, int lds_double
   if (g == 0 && tl < 64)
     for (int kb = ca + bandblk - 1; kb >= ca; --kb) backsub_block(kb, false, npr);
   __syncthreads();
+  // @bstamp 5
   if (t < PB) LB[nprmax * WBP + 6 * (cb + bandblk - 1 - t / 6) + t % 6] = LA[nprmax * WBP + 6 * ca + t];  // x of the separator, mirrored
   __syncthreads();
   // ... then both chains at once; in image B the separator rows only hand their (known) x down to the chain's columns
@@ -2074,6 +2146,7 @@ __device__ __forceinline__ bool band2_solve_body(const BAArgs& a, int lds_double
     for (int kb = chain - 1; kb >= 0; --kb) backsub_block(kb, false, npr);
   }
   __syncthreads();
+  // @bstamp 6
   const bool bad = *failp != 0;
   if (t == 0) {
     if (bad) w.info[2] += 1;
@@ -2086,6 +2159,7 @@ __device__ __forceinline__ bool band2_solve_body(const BAArgs& a, int lds_double
   }
   __syncthreads();
   apply_retraction(a, t, 2 * B2_T, nb);
+  // @bstamp 7
   return true;
 }
 
@@ -2108,15 +2182,28 @@ __global__ __launch_bounds__(2 * BAND_T) void ba_solve_band_kernel(BAArgs a, int
 // ------------------------------------------------------------------------------------------------ solve (LDS dense)
 //
 // Dense windows that the band solver cannot hold (the keyframe frontend: up to ~25 free poses, every pair coupled through
-// proximity and inactive edges) but whose PACKED lower triangle still fits LDS (n + 1 <= ~190 rows: 145 KB of fp64): the
-// whole factorisation runs out of LDS like the band solver's, instead of three L2 round trips per block step in the
-// global-memory kernel (99 us at n = 150).  Row r (columns 0..r) lives at r (r + 1) / 2; row n is the rhs, so the forward
-// substitution falls out of the factorisation.  Per 6-column block step: panel (one row per thread, forward
-// substitution against the 6 x 6 factor block), barrier, trailing update (waves 1..7: a 28 x 16 thread grid walks the
-// remaining triangle) while wave 0 updates the 21 entries of the NEXT diagonal block and its lane 0 factors it
-// (look-ahead), barrier.  Back substitution by wave 0 alone, column oriented, wave barriers only.
+// proximity and inactive edges), n + 1 <= 160 rows (26 free poses).  One workgroup of 8 waves, fp64, 6-column block steps; row n of the
+// matrix is the right-hand side, so the forward substitution falls out of the factorisation.
+//   * The trailing matrix lives in REGISTERS of waves 1..7: 16 x 16 tiles of the lower triangle in the accumulator
+//     layout of v_mfma_f64_16x16x4_f64 (negated, so that the update is a plain multiply-accumulate); the update of a
+//     block step is two matrix instructions per live tile whose operand fragments come from a panel buffer at addresses
+//     that never change (no index arithmetic in the loop).
+//   * Wave 0 is the CHAIN wave: it owns the dependent chain and nothing else - factor the 6 x 6 diagonal block in
+//     registers (row per lane, pivots by v_readlane), solve the six panel rows of the NEXT diagonal block itself,
+//     subtract their product from a preview of that block which the tile waves extracted one step earlier, factor it.
+//     The tile waves' panel / update / extract run beside it; two workgroup barriers per step.  The wave that shares
+//     the chain wave's SIMD (read from HW_ID) stays idle: fp64 matrix instructions and the chain's fp64 arithmetic use
+//     the same pipe, and with a tile wave next to it the chain ran 2.5 times slower (stamps).
+//   * LDS holds what has left the registers: the factor (packed rows, for the back substitution), the panel buffer
+//     (two parities, rows of 8 doubles: 6 panel columns + 2 zeros = the K = 8 of two matrix instructions), previews.
+// A single wave issues at most one instruction every ~4 cycles and a dependent fp64 operation takes ~35: the phases were
+// sized by in-kernel cycle stamps (scratch/make_ba_stamps.py) - before this form the chain (2 850 cycles per block) ran
+// in sequence with the panel, the update and the extraction (7 700 per step).
 // Sets info[5] = 2 when it solved the system.
 constexpr int DN_T = 512;
+constexpr int DN_PP = 20;     // panel buffer: doubles per row = 2 parities x 8 + 4 (20 l16 mod 32 takes 8 values 4 apart: with kq the 64
+                              // lanes of an operand-fragment read cover the 32 8-byte slots of the bank window twice - a pitch of 16 is 8-way conflicted)
+constexpr int DN_SLOTS = 10;  // 6 tile waves x 10 >= 55 tiles (n + 1 <= 160 rows: 10 tile rows; 11 slots spill)
 typedef double double4c __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_doubles) {
@@ -2127,168 +2214,344 @@ __global__ __launch_bounds__(DN_T) void ba_solve_dense_kernel(BAArgs a, int lds_
   const int t = threadIdx.x;
   const int n = w.info[3], n_free = w.info[0];
   const int npr = 6 * n_free, F = n - npr;
-  const int NP = (n + 1) * (n + 2) / 2;  // packed size incl. the rhs row
+  const int NP = ((n + 1) * (n + 2) / 2 + 1) & ~1;  // packed size incl. the rhs row (even: what follows is 16-byte aligned)
+  const int NTR = (n + 16) >> 4, NTL = NTR * (NTR + 1) / 2;  // tile rows covering rows 0..n; tiles of the triangle
+  const int LDS_NEED = NP + 64 + 2 * 36 + 36 + (n + 8) + 6 * (n + 6) + DN_PP * 16 * NTR;
   // info[5] == 1: the band solver (which resets the flag whenever it runs) solved THIS iteration.  A 2 can only be this
   // kernel's own mark from the previous Gauss-Newton iteration of the call (ba_sens_kernel clears the flag per call).
-  if (n == 0 || w.info[5] == 1 || a.mv || NP + 64 + n + 6 * (n + 6) > lds_doubles || F > 2 || n > 192) return;
-  double* const blk = L + NP;   // 6x7: the current diagonal factor block
-  double* const rd = blk + 42;  // its reciprocal pivots
+  if (n == 0 || w.info[5] == 1 || a.mv || LDS_NEED > lds_doubles || F > 2 || NTL > 6 * DN_SLOTS) return;
+  double* const blk = L + NP;      // 6x7: the current diagonal factor block
+  double* const rd = blk + 42;     // its reciprocal pivots
   int* const failp = reinterpret_cast<int*>(rd + 6);
-  double* const rdall = rd + 8; // [n] reciprocal pivots of every column (back substitution)
-  double* const Linv = rdall + n + 8;  // [blocks][6][6] inverses of the diagonal factor blocks, zero above the diagonal
+  double* const dnext = rd + 8;    // [2][36] previews of the next diagonal block (entries (i, j), j <= i)
+  double* const xbuf = dnext + 72; // [6][6] the chain wave's own panel rows
+  double* const rdall = xbuf + 36; // [n] reciprocal pivots of every column (back substitution)
+  double* const Linv = rdall + ((n + 8) & ~1);  // [blocks][6][6] inverses of the diagonal factor blocks, zero above the diagonal
+  double* const Pbuf = Linv + 6 * (n + 6);      // [16 NTR rows][DN_PP]: panel rows (raw, then solved), parity p at column 8 p
   auto off = [](int r) { return r * (r + 1) / 2; };
   const double* S = w.S;
   const int ld = w.ld;
-  if (t == 0) *failp = 0;
-  // ---- the matrix (rows 0..n, row n = rhs; LM damping on the diagonal, matrix.py:179-186) goes into REGISTERS: 16 x 16
-  //      tiles of the lower triangle in the accumulator layout of v_mfma_f64_16x16x4_f64 (lane (l16, kq), element r4 =
-  //      row kq + 4 r4, column l16), tile tau = I (I + 1) / 2 + J owned by wave tau % 8 as its slot tau / 8.  The
-  //      trailing update of a block step is then two matrix instructions per live tile with NO read-modify-write of
-  //      the matrix through LDS (the scalar update walked the packed triangle: 8 LDS accesses per entry and step, 5.6 us
-  //      per step at n = 150); LDS holds only what has left the registers: the factor's columns (packed rows, read by
-  //      the panel, the update's operand fragments and the back substitution).
   const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l16 = lane & 15, kq = lane >> 4;
-  const int NTR = (n + 16) >> 4, NTL = NTR * (NTR + 1) / 2;  // tile rows covering rows 0..n; tiles of the triangle
-  constexpr int DN_SLOTS = 12;                               // 8 waves x 12 >= 91 tiles (n <= 192)
-  int tI[DN_SLOTS], tJ[DN_SLOTS];
+  const int nblk = n_free + (F > 0 ? 1 : 0);
+  // @stamp 0
+  if (t == 0) *failp = 0;
+  // roles: wave 0 = chain; waves on its SIMD = idle (barriers only); the others = tile waves, ranked.  Should the
+  // hardware place fewer than six waves on the other SIMDs, the idle ones become tile waves after all (slower, correct).
+  int* const simd_of = reinterpret_cast<int*>(xbuf);  // 8 ints, before xbuf's first use
+  if (lane == 0) simd_of[wave] = (int)(__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3);  // HW_ID.SIMD_ID
+  __syncthreads();
+  int twave = -1, ntw = 0;  // this wave's rank among the tile waves; their number
+  {
+    int others = 0;
+    for (int v = 1; v < DN_T / 64; ++v) others += simd_of[v] != simd_of[0];
+    const bool use_partners = others < 6;
+    for (int v = 1; v < DN_T / 64; ++v) {
+      const bool tw = use_partners || simd_of[v] != simd_of[0];
+      if (v == wave && tw) twave = ntw;
+      ntw += tw;
+    }
+    if (twave >= 6) twave = -1;  // six tile waves carry all the slots
+  }
+  twave = __builtin_amdgcn_readfirstlane(twave);
+  __syncthreads();
+  for (int i = t; i < DN_PP * 16 * NTR; i += DN_T) Pbuf[i] = 0.0;  // columns 6, 7 stay zero; rows beyond n too
+  auto damped = [&](int r, double v) {  // LM damping on the diagonal (matrix.py:179-186)
+    const bool pose = r < npr;
+    return v + (pose ? (double)prm.pose_ep : 1e-6) + (pose ? (double)prm.pose_damping : 1e-6) * (a.droid ? v : w.Hd[r]);
+  };
+
+  // ---- tile waves: tile tau = I (I + 1) / 2 + J of the lower triangle -> tile wave tau % 6, slot tau / 6.  Per slot and
+  //      lane: T (four entries: rows 16 I + kq + 4 r4, column 16 J + l16, NEGATED), the row / column this lane extracts
+  //      and the LDS byte addresses of its two operand fragments in the panel buffer
   double4c T[DN_SLOTS];
+  int colv[DN_SLOTS], rowv[DN_SLOTS];
 #pragma unroll
   for (int sl = 0; sl < DN_SLOTS; ++sl) {
-    const int tau = wave + 8 * sl;
-    int ti = (int)((sqrtf(8.0f * (float)tau + 1.0f) - 1.0f) * 0.5f);
-    while ((ti + 1) * (ti + 2) / 2 <= tau) ++ti;
-    while (ti * (ti + 1) / 2 > tau) --ti;
-    tI[sl] = tau < NTL ? ti : -1;
-    tJ[sl] = tau - ti * (ti + 1) / 2;
     T[sl] = double4c{0.0, 0.0, 0.0, 0.0};
-    if (tI[sl] >= 0) {
-      const int col = 16 * tJ[sl] + l16;
+    colv[sl] = rowv[sl] = -(1 << 20);
+  }
+  if (twave >= 0) {
+#pragma unroll
+    for (int sl = 0; sl < DN_SLOTS; ++sl) {
+      const int tau = twave + 6 * sl;
+      int ti = (int)((sqrtf(8.0f * (float)tau + 1.0f) - 1.0f) * 0.5f);
+      while ((ti + 1) * (ti + 2) / 2 <= tau) ++ti;
+      while (ti * (ti + 1) / 2 > tau) --ti;
+      const int tj = tau - ti * (ti + 1) / 2;
+      const bool ok = tau < NTL;
+      colv[sl] = ok ? 16 * tj + l16 : -(1 << 20);  // an absent tile is never live and never intersects a column block
+      rowv[sl] = ok ? 16 * ti + kq : -(1 << 20);
+      // unconditional loads from clamped positions (all of a lane's loads in flight at once: a load under a branch
+      // whose condition needs the previous load costs a memory round trip each), selected afterwards
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        const int row = 16 * tI[sl] + kq + 4 * r4;
-        double v = 0.0;
-        if (row <= n && col < n && col <= row) {
-          v = S[(int64_t)row * ld + col];
-          if (col == row) {
-            const bool pose = row < npr;
-            v += (pose ? (double)prm.pose_ep : 1e-6) + (pose ? (double)prm.pose_damping : 1e-6) * (a.droid ? v : w.Hd[row]);
-          }
+        const int row = 16 * ti + kq + 4 * r4, col = 16 * tj + l16;
+        const int rr = min(row, n), cc = min(col, min(rr, n - 1));
+        T[sl][r4] = S[(int64_t)rr * ld + cc];
+      }
+    }
+    const bool dr = a.droid;
+#pragma unroll
+    for (int sl = 0; sl < DN_SLOTS; ++sl) {
+      double hd[4];
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) hd[r4] = dr ? 0.0 : w.Hd[min(max(rowv[sl] + 4 * r4, 0), n - 1)];
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int row = rowv[sl] + 4 * r4, col = colv[sl];
+        double v = T[sl][r4];
+        if (col == row) {
+          const bool pose = row < npr;
+          v += (pose ? (double)prm.pose_ep : 1e-6) + (pose ? (double)prm.pose_damping : 1e-6) * (dr ? v : hd[r4]);
         }
-        T[sl][r4] = v;
+        T[sl][r4] = (row <= n && col < n && col <= row && col >= 0) ? -v : 0.0;
       }
     }
   }
-  // columns j0 .. R0 - 1 of the trailing matrix (rows >= the column) leave the registers for their packed rows
-  auto extract = [&](int j0, int R0) {
+  // which of this wave's slots hold tile column J / tile row I: bit masks, lane J < 16 holds the column mask of J and
+  // lane 16 + I the row mask of I (a block step finds the two or three slots that meet its columns with two v_readlane
+  // instead of testing every slot); nsl = slots in use (the unrolled slot loops leave at the first unused one)
+  int maskv = 0, nsl = 0;
 #pragma unroll
-    for (int sl = 0; sl < DN_SLOTS; ++sl) {
-      if (tI[sl] < 0 || 16 * tJ[sl] >= R0 || 16 * tJ[sl] + 16 <= j0 || 16 * tI[sl] + 15 < j0) continue;  // wave-uniform
-      const int col = 16 * tJ[sl] + l16;
-      if (col < j0 || col >= R0) continue;
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int row = 16 * tI[sl] + kq + 4 * r4;
-        if (row >= col && row <= n) L[off(row) + col] = T[sl][r4];
-      }
+  for (int sl = 0; sl < DN_SLOTS; ++sl) {
+    const int tj = __builtin_amdgcn_readfirstlane(colv[sl]) >> 4, ti = __builtin_amdgcn_readfirstlane(rowv[sl]) >> 4;
+    if (tj >= 0) {
+      maskv |= ((lane == tj) || (lane == 16 + ti)) ? (1 << sl) : 0;
+      nsl = sl + 1;
     }
-  };
-  const int nblk = n_free + (F > 0 ? 1 : 0);
-  // factor the diagonal block of step kb (bw columns); publish L, blk, rd.  Executed by the whole of wave 0: lane i < 6
-  // holds row i of the block, the pivot and the column entries other rows need travel by v_readlane (compile-time
-  // lanes) - per pivot the dependent chain is rsqrt -> multiply -> readlane -> fused multiply-add -> readlane instead
-  // of one lane walking all 21 entries: 71 -> 67 us per solve on the frontend's windows (a v_readlane round trip
-  // through the scalar file costs ~85 cycles, so the chain is hardly shorter: in the band solver the same change
-  // measured no gain and was not kept).  Same fused multiply-adds in the same order: bit-identical factors.
+  }
+  // the chain wave's diagonal block: lane i = row i (lanes >= 6 run along on row 5 and store nothing)
+  const int ic = lane < 6 ? lane : 5;
+  double A[6];
+  if (wave == 0) {
+    const int bw0 = min(6, n);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      double v = (c == ic) ? 1.0 : 0.0;
+      if (ic < bw0 && c <= ic) {
+        v = S[(int64_t)ic * ld + c];
+        if (c == ic) v = damped(ic, v);
+      }
+      A[c] = v;
+    }
+  }
+  // factor the block held in A (bw columns; identity beyond); publish L, blk, rd, rdall.
+  // DIVISION-FREE elimination: a pivot step multiplies the remaining rows by the pivot p instead of dividing the pivot
+  // column by it, a_im <- (a_im p - a_ic a_mc) 2^-e with 2^e the binade of p (an exact rescale that keeps the running
+  // scale s in (2^-6, 1]): the dependent chain per pivot is v_readlane -> fused multiply-add -> ldexp instead of
+  // reciprocal square root + two Newton steps + multiply + fused multiply-add (9 dependent fp64 operations of ~35 cycles
+  // each: 2 850 cycles per block by the stamps).  The factor follows at the end, all six columns at once:
+  // L_ic = a_ic / sqrt(p_c s_c), 1 / L_cc = s_c / sqrt(p_c s_c), one reciprocal square root per LANE.  Same stability as
+  // the Cholesky recurrence (it is the LDL^T elimination with exactly rescaled rows).
   auto factor_diag = [&](int kb) {
     const int j0 = 6 * kb, bw = min(6, n - j0);
-    const int i = t;  // lane = row of the block (lanes >= 6 run along and store nothing)
-    const int ic = i < 6 ? i : 5;
-    double A[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) A[c] = (ic < bw && c <= ic) ? L[off(j0 + ic) + j0 + c] : (c == ic ? 1.0 : 0.0);
-    double d = readlane_f64(A[0], 0);
+    double sc = 1.0, p_own = 1.0, s_own = 1.0;
     bool bad = false;
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-      const bool okp = d > 0.0;
-      bad |= (c < bw) & !okp;
-      d = okp ? d : 1.0;
-      const double rl = rsqrt_nr(d);
-      const double lj = ic == c ? d * rl : (ic > c ? A[c] * rl : 0.0);
-      A[c] = lj;
-      if (i == 0) {
-        rd[c] = rl;
-        if (c < bw) rdall[j0 + c] = rl;
-      }
+      // a non-positive pivot marks the solve as failed (its step is then zero) and the arithmetic just runs on
+      const double pv = readlane_f64(A[c], c);
+      bad |= (c < bw) & !(pv > 0.0);
+      p_own = (ic == c) ? pv : p_own;
+      s_own = (ic == c) ? sc : s_own;
       if (c + 1 < 6) {
-        // the next pivot first (lane c + 1's own diagonal entry), then the rest of the rank-1 update
-        A[c + 1] = __builtin_fma(-lj, readlane_f64(lj, c + 1), A[c + 1]);
-        d = readlane_f64(A[c + 1], c + 1);
+        // pv = ps 2^e with ps in [0.5, 1): rows are multiplied by ps and the pivot column is scaled by 2^-e ONCE, so that
+        // an entry's update is one multiply and one fused multiply-add
+        const unsigned long long pb = __builtin_bit_cast(unsigned long long, pv);
+        const int e = (int)((pb >> 52) & 0x7ff) - 1022;
+        const double ps = __builtin_bit_cast(double, (pb & 0x800fffffffffffffull) | (1022ull << 52));
+        const double own_sq = A[c] * A[c];              // ready before the pivot arrives
+        const double colc = __builtin_ldexp(A[c], -e);  // this lane's entry of the pivot column, scaled
 #pragma unroll
-        for (int m = c + 2; m < 6; ++m) A[m] = __builtin_fma(-lj, readlane_f64(lj, m), A[m]);
+        for (int m = c + 1; m < 6; ++m) {
+          // lane c + 1 forms its next pivot from its own entry: no lane hand-off on the dependent chain
+          const double prod = (m == c + 1 && ic == c + 1) ? __builtin_ldexp(own_sq, -e) : A[c] * readlane_f64(colc, m);
+          A[m] = __builtin_fma(A[m], ps, -prod);
+        }
+        sc = sc * ps;
       }
     }
-    if (i == 0 && bad) *failp = 1;
-    if (i < 6) {
+    const double rho = rsqrt_nr(p_own * s_own);  // lane c: 1 / sqrt(p_c s_c)
+    const double rdv = s_own * rho;              // 1 / L_cc
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const double rc = readlane_f64(rho, c);
+      A[c] = ic == c ? p_own * rho : (ic > c ? A[c] * rc : 0.0);
+    }
+    if (lane == 0 && bad) *failp = 1;
+    if (lane < 6) {
+      rd[lane] = rdv;
+      if (lane < bw) rdall[j0 + lane] = rdv;
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
-        if (c <= i) {
-          if (i < bw) L[off(j0 + i) + j0 + c] = A[c];
-          blk[i * 7 + c] = A[c];
+        if (c <= lane) {
+          if (lane < bw) L[off(j0 + lane) + j0 + c] = A[c];
+          blk[lane * 7 + c] = A[c];
         }
       }
     }
   };
-  // @stamp 1
-  for (int kb = 0; kb < nblk; ++kb) {
-    const int j0 = 6 * kb, bw = min(6, n - j0), R0 = j0 + bw;
-    // @stampk 0
-    extract(j0, R0);
-    // @stampk 1
-    __syncthreads();
-    // @stampk 2
-    if (t < 64) factor_diag(kb);
-    // @stampk 3
-    __syncthreads();
-    // @stampk 4
-    // panel: rows R0..n (row n = rhs)
-    {
-      const int r = R0 + t;
-      if (r <= n) {
-        double* row = L + off(r) + j0;
-        double x[6];
+  // forward substitution of one panel row against the published factor block
+  auto solve_row = [&](const double (&raw)[6], int bw, double (&x)[6]) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          double sacc = j < bw ? row[j] : 0.0;
+    for (int j = 0; j < 6; ++j) {
+      double sacc = j < bw ? raw[j] : 0.0;
 #pragma unroll
-          for (int m = 0; m < j; ++m) sacc = __builtin_fma(-x[m], blk[j * 7 + m], sacc);
-          x[j] = sacc * rd[j];
-        }
-#pragma unroll
-        for (int j = 0; j < 6; ++j)
-          if (j < bw) row[j] = x[j];
-      }
+      for (int m = 0; m < j; ++m) sacc = __builtin_fma(-x[m], blk[j * 7 + m], sacc);
+      x[j] = sacc * rd[j];
     }
-    // @stampk 5
-    __syncthreads();
-    // @stampk 6
-    // trailing update T -= P P^T on the matrix cores: operand fragments are rows of the solved panel (6 columns, padded
-    // to 8 with zeros); tiles whose columns all lie left of R0 are finished and skipped
+  };
+  // tile waves: columns [c0, c0 + cw) of the trailing matrix -> panel buffer Pb (= Pbuf + 8 parity; every row of the
+  // tiles that hold them: rows that are not panel rows any more only ever meet finished entries); the block
+  // [p0, p0 + pw)^2 that follows -> preview buffer pv
+  auto extract = [&](double* Pb, int c0, int cw, int p0, int pw, double* pv) {
+    const int cm = __builtin_amdgcn_readlane(maskv, c0 >> 4) | __builtin_amdgcn_readlane(maskv, (c0 + cw - 1) >> 4);
+    int pm = 0;
+    if (pw > 0) {
+      const int ja = p0 >> 4, jb = (p0 + pw - 1) >> 4;
+      pm = (__builtin_amdgcn_readlane(maskv, ja) | __builtin_amdgcn_readlane(maskv, jb)) &
+           (__builtin_amdgcn_readlane(maskv, 16 + ja) | __builtin_amdgcn_readlane(maskv, 16 + jb));
+    }
+    if ((cm | pm) == 0) return;
 #pragma unroll
     for (int sl = 0; sl < DN_SLOTS; ++sl) {
-      if (tI[sl] < 0 || 16 * tJ[sl] + 15 < R0) continue;  // wave-uniform
-      const int ar = 16 * tI[sl] + l16, bc = 16 * tJ[sl] + l16;
-      const bool aok = ar >= R0 && ar <= n, bok = bc >= R0 && bc < n;
-      const double* pa = L + off(aok ? ar : 0) + j0;
-      const double* pb = L + off(bok ? bc : 0) + j0;
-      const double a0 = (aok && kq < bw) ? pa[kq] : 0.0, b0 = (bok && kq < bw) ? pb[kq] : 0.0;
-      const double a1 = (aok && kq + 4 < bw) ? pa[kq + 4] : 0.0, b1 = (bok && kq + 4 < bw) ? pb[kq + 4] : 0.0;
-      T[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, T[sl], 0, 0, 0);
-      T[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, T[sl], 0, 0, 0);
+      if ((cm >> sl) & 1) {
+        if ((unsigned)(colv[sl] - c0) < (unsigned)cw) {
+          double* dst = Pb + rowv[sl] * DN_PP + (colv[sl] - c0);
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) dst[r4 * 4 * DN_PP] = -T[sl][r4];
+        }
+      }
+      if ((pm >> sl) & 1) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int pr = rowv[sl] + 4 * r4 - p0, pc = colv[sl] - p0;
+          if ((unsigned)pr < (unsigned)pw && pc >= 0 && pc <= pr) pv[pr * 6 + pc] = -T[sl][r4];
+        }
+      }
     }
-    // no barrier here: the next step's extract writes columns >= R0 of rows >= R0, which nobody reads before the barrier
-    // that follows it; the panel columns read above are not written again
-    // @stampk 7
+  };
+
+  if (twave >= 0) extract(Pbuf, 0, min(6, n), min(6, n), min(6, n - min(6, n)), dnext + 36);
+  if (wave == 0) factor_diag(0);
+  __syncthreads();
+  // @stamp 1
+  // one block step of each role; the panel buffer's parity is kb & 1.  Two workgroup barriers per step in BOTH loops (the
+  // hardware barrier counts arrivals, whatever the code address): separate loops keep the tile registers out of the
+  // chain wave's code and the chain's out of the tile waves'
+  if (wave == 0) {
+    for (int kb = 0; kb < nblk; ++kb) {
+      double* const Pb = Pbuf + 8 * (kb & 1);
+      const int j0 = 6 * kb, bw = min(6, n - j0), R0 = j0 + bw, nbw = min(6, n - R0);
+      double x[6];
+      // @stampk 0
+      // the rows of the next diagonal block: solved here, kept in registers, published for the update
+      if (nbw > 0) {
+        const int r = min(R0 + ic, n);
+        const double* src = Pb + r * DN_PP;
+        double raw[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) raw[j] = src[j];
+        solve_row(raw, bw, x);
+        if (lane < nbw) {
+          double* dst = Pb + r * DN_PP;
+          double* lrow = L + off(r) + j0;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            dst[j] = j < bw ? x[j] : 0.0;
+            if (j < bw) lrow[j] = x[j];
+            xbuf[lane * 6 + j] = j < bw ? x[j] : 0.0;
+          }
+        }
+      }
+      // @stampk 1
+      __syncthreads();
+      // @stampk 2
+      if (nbw > 0) {
+        // next diagonal block = its preview (state before this step) - P P^T of its six panel rows, then its factor
+        const double* pv = dnext + ((kb + 1) & 1) * 36;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          double v = (c == ic) ? 1.0 : 0.0;
+          if (ic < nbw && c <= ic) {
+            double s0 = pv[ic * 6 + c], s1 = 0.0;
+#pragma unroll
+            for (int m = 0; m < 6; m += 2) {
+              s0 = __builtin_fma(-x[m], xbuf[c * 6 + m], s0);
+              s1 = __builtin_fma(-x[m + 1], xbuf[c * 6 + m + 1], s1);
+            }
+            v = s0 + s1;
+          }
+          A[c] = v;
+        }
+        // @stampk 3
+        factor_diag(kb + 1);
+      }
+      // @stampk 4
+      __syncthreads();
+      // @stampk 5
+    }
+  } else {
+    for (int kb = 0; kb < nblk; ++kb) {
+      double* const Pb = Pbuf + 8 * (kb & 1);
+      const int j0 = 6 * kb, bw = min(6, n - j0), R0 = j0 + bw, nbw = min(6, n - R0), R1 = R0 + nbw;
+      // @wstampk 0
+      if (twave >= 0) {
+        const int r = R1 + 64 * twave + lane;
+        if (r <= n) {
+          double* row = Pb + r * DN_PP;
+          double raw[6], x[6];
+#pragma unroll
+          for (int j = 0; j < 6; ++j) raw[j] = row[j];
+          solve_row(raw, bw, x);
+          double* lrow = L + off(r) + j0;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            row[j] = j < bw ? x[j] : 0.0;
+            if (j < bw) lrow[j] = x[j];
+          }
+        }
+      }
+      // @wstampk 1
+      __syncthreads();
+      // @wstampk 2
+      // trailing update T' += P P^T (live tiles: some column >= R0), then the next column block and the preview after it.
+      // One inline-asm block per slot - skip test, the four operand reads, both matrix instructions - so that the
+      // compiler sees T[sl] modified IN PLACE on every path: through the builtin under a branch it kept the skipped and
+      // the updated accumulator in two register sets (four 64-bit moves per slot and step, twice the registers).
+      const unsigned pb_u = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(Pb + kq);
+      const bool upd = twave >= 0 && R0 < n;
+#pragma unroll
+      for (int sl = 0; sl < DN_SLOTS; ++sl) {
+        const int live = __builtin_amdgcn_readfirstlane((int)(upd && sl < nsl && (colv[sl] | 15) >= R0));
+        const unsigned aa = pb_u + (unsigned)(((rowv[sl] & ~15) + l16) * (DN_PP * 8));
+        const unsigned ba = pb_u + (unsigned)(((colv[sl] & ~15) + l16) * (DN_PP * 8));
+        double fa0, fa1, fb0, fb1;
+        asm volatile(
+            "s_cmp_eq_u32 %7, 0\n\t"
+            "s_cbranch_scc1 1f\n\t"
+            "ds_read_b64 %1, %5\n\t"
+            "ds_read_b64 %3, %6\n\t"
+            "ds_read_b64 %2, %5 offset:32\n\t"
+            "ds_read_b64 %4, %6 offset:32\n\t"
+            "s_waitcnt lgkmcnt(2)\n\t"
+            "v_mfma_f64_16x16x4_f64 %0, %1, %3, %0\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_mfma_f64_16x16x4_f64 %0, %2, %4, %0\n"
+            "1:"
+            : "+v"(T[sl]), "=&v"(fa0), "=&v"(fa1), "=&v"(fb0), "=&v"(fb1)
+            : "v"(aa), "v"(ba), "s"(live)
+            : "scc", "memory");
+      }
+      // the compiler does not see matrix instructions inside inline asm: cover the result hazard of the last one (the
+      // extraction below reads T with vector instructions) by hand
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+      // @wstampk 3
+      if (upd) extract(Pbuf + 8 * ((kb + 1) & 1), R0, nbw, R1, min(6, n - R1), dnext + (kb & 1) * 36);
+      // @wstampk 4
+      __syncthreads();
+      // @wstampk 5
+    }
   }
   // @stamp 2
   // ---- back substitution L^T x = y (y = row n).  First every diagonal block is replaced by its INVERSE (thread = one
