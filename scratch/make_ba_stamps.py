@@ -5,11 +5,12 @@ def rep(old, new):
     global s
     assert s.count(old) == 1, (s.count(old), old[:60])
     s = s.replace(old, new)
-rep("constexpr int BAND_T = 512;\n", "__device__ unsigned long long g_dn_stamps[4096];\nconstexpr int BAND_T = 512;\n")
+rep("constexpr int AM_ROWS = 48;", "__device__ unsigned long long g_dn_stamps[4096];\nconstexpr int AM_ROWS = 48;")
 rep("constexpr int DN_T = 512;\n", "constexpr int DN_T = 512;\n#define STAMP(i) do { if (t == 0 && (i) < 1024) g_dn_stamps[(i)] = __builtin_amdgcn_s_memtime(); } while (0)\n")
 import re, sys
 # generic markers placed in the source as comments: // @stamp N  or  // @stampk N  (8 + 8 * kb + N)
 s = re.sub(r"// @wstampk (\d+)", lambda m: f"if (twave >= 0 && lane == 0 && 8 * kb + {m.group(1)} < 256) g_dn_stamps[512 + 256 * twave + 8 * kb + {m.group(1)}] = __builtin_amdgcn_s_memtime();", s)
+s = re.sub(r"// @astamp (\d+)", lambda m: f"if (threadIdx.x == 0 && blockIdx.x == 3 && (blockIdx.y == 24 || blockIdx.y == 2)) g_dn_stamps[3300 + 16 * (blockIdx.y == 24) + {m.group(1)}] = __builtin_amdgcn_s_memtime();", s)
 s = re.sub(r"// @bwave (\d+)", lambda m: f"if ((threadIdx.x & 63) == 0) g_dn_stamps[3000 + {m.group(1)} + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime();", s)
 s = re.sub(r"// @bstamp (\d+)", lambda m: f"if (threadIdx.x == 0) g_dn_stamps[3000 + {m.group(1)}] = __builtin_amdgcn_s_memtime();", s)
 s = re.sub(r"// @stampk (\d+)", lambda m: f"STAMP(8 + 8 * kb + {m.group(1)});", s)

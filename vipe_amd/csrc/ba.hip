@@ -416,6 +416,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
   const int n_free = w.info[0], nrow = w.info[3];
   const int foff = 6 * n_free;
 
+  // @astamp 0
   extern __shared__ __align__(16) float am_smem[];
   float* wbuf = am_smem + wave * AM_WBUF;       // wave-private
   float* accS = am_smem + NWAVE * AM_WBUF;      // [48][49] Schur Gram accumulators
@@ -439,6 +440,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     tg[tid] = m;
   }
   __syncthreads();
+  // @astamp 1
 
   const cam::Intr Ii = cam::load_scaled(a.intr + qi * (4 + a.D), a.D, 1.0f / prm.intr_factor);
   const float u = (float)(p % prm.wd), v = (float)(p / prm.wd);
@@ -562,6 +564,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     __builtin_amdgcn_wave_barrier();
   }
 
+  // @astamp 2
   // ---- finish the disparity block of this pixel: sensor prior, damping (terms.py:258-268, buffer.py:482-489)
   float sq = 0.0f;
   const int NR = 6 * (deg + 1) + F + 1;  // R2 rows: pose i, targets, intrinsics, w
@@ -648,7 +651,9 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         }
       }
   }
+  // @astamp 3
   __syncthreads();
+  // @astamp 4
 
   // ---- per-term blocks from the Gram sums (one wave per term)
   for (int t = wave; t < deg; t += NWAVE) {
@@ -710,6 +715,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
+  // @astamp 5
 
   // ---- frame level: H_ii, v_i, H_if, H_ff, v_f
   {
@@ -737,6 +743,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
       atomicAdd(&w.S[(int64_t)nrow * w.ld + foff + (tid - 42 - 6 * F - F * F)], (double)accI[tid]);
     }
   }
+  // @astamp 6
   // ---- Schur complement of frame k: S -= E Q E^T, g -= E Q w   (solver.py:176-178)
   if (dfree) {
     auto gmap = [&](int row) -> int {
@@ -759,6 +766,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
       }
     }
   }
+  // @astamp 7
 }
 
 // ---- general accumulate (any number of terms per source frame): the same walk with matrix-core Gram reductions, the
