@@ -10,6 +10,8 @@ rep("constexpr int DN_T = 512;\n", "constexpr int DN_T = 512;\n#define STAMP(i) 
 import re, sys
 # generic markers placed in the source as comments: // @stamp N  or  // @stampk N  (8 + 8 * kb + N)
 s = re.sub(r"// @wstampk (\d+)", lambda m: f"if (twave >= 0 && lane == 0 && 8 * kb + {m.group(1)} < 256) g_dn_stamps[512 + 256 * twave + 8 * kb + {m.group(1)}] = __builtin_amdgcn_s_memtime();", s)
+s = re.sub(r"// @kstampc (\d+)", lambda m: f"if (threadIdx.x == 0 && blockIdx.x == 3) {{ g_dn_stamps[3400 + 32 * (blockIdx.y & 15) + 6 * (cb / WK_CH1) + {m.group(1)}] = __builtin_amdgcn_s_memtime(); g_dn_stamps[3400 + 32 * (blockIdx.y & 15) + 31] = deg_all; }}", s)
+s = re.sub(r"// @kstamp (\d+)", lambda m: f"if (threadIdx.x == 0 && blockIdx.x == 3) g_dn_stamps[3400 + 32 * (blockIdx.y & 15) + {m.group(1)}] = __builtin_amdgcn_s_memtime();", s)
 s = re.sub(r"// @astamp (\d+)", lambda m: f"if (threadIdx.x == 0 && blockIdx.x == 3 && (blockIdx.y == 24 || blockIdx.y == 2)) g_dn_stamps[3300 + 16 * (blockIdx.y == 24) + {m.group(1)}] = __builtin_amdgcn_s_memtime();", s)
 s = re.sub(r"// @bwave (\d+)", lambda m: f"if ((threadIdx.x & 63) == 0) g_dn_stamps[3000 + {m.group(1)} + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime();", s)
 s = re.sub(r"// @bstamp (\d+)", lambda m: f"if (threadIdx.x == 0) g_dn_stamps[3000 + {m.group(1)}] = __builtin_amdgcn_s_memtime();", s)

@@ -772,9 +772,11 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
 // ---- general accumulate (any number of terms per source frame): the same walk with matrix-core Gram reductions, the
 // terms staged 8 at a time, WITHOUT the Schur complement - that is formed afterwards by ba_schur_kernel from the E rows
 // this kernel leaves in the workspace (E_kk, E_j, E_f, w, C).  LDS per workgroup is independent of the degree (42 KB).
-constexpr int WK_CH = 8;
+constexpr int WK_CH = 8;    // rig walk: terms per chunk
+constexpr int WK_CH1 = 12;  // mono walk: the keyframe frontend's source frames have 6-12 terms - with 8 per chunk a 9-term
+                            // frame paid a second chunk's set-up (10k cycles of dependent loads, stamps) for one term: 17k of 66k
 constexpr size_t walk_lds() {
-  return sizeof(float) * (NWAVE * 16 * AM_P1 + WK_CH * 256 + 64) + WK_CH * sizeof(TermGeomM);
+  return sizeof(float) * (NWAVE * 16 * AM_P1 + WK_CH1 * 256 + 64) + WK_CH1 * sizeof(TermGeomM);
 }
 
 template <int CAM, int F>
@@ -804,9 +806,10 @@ __global__ __launch_bounds__(TILE) void ba_walk_kernel(BAArgs a) {
 
   extern __shared__ __align__(16) float am_smem[];
   float* wbuf = am_smem + wave * WBUF;        // wave-private R1 tile
-  float* acc1 = am_smem + NWAVE * WBUF;       // [WK_CH][16][16] per-term Gram accumulators of the current chunk
-  float* accI = acc1 + WK_CH * 256;           // [64] frame level: H_ii 36, v_i 6, H_if 6F, H_ff 3, v_f F
+  float* acc1 = am_smem + NWAVE * WBUF;       // [WK_CH1][16][16] per-term Gram accumulators of the current chunk
+  float* accI = acc1 + WK_CH1 * 256;          // [64] frame level: H_ii 36, v_i 6, H_if 6F, H_ff 3, v_f F
   TermGeomM* tg = reinterpret_cast<TermGeomM*>(accI + 64);
+  // @kstamp 0
   if (tid < 64) accI[tid] = 0.0f;
 
   const cam::Intr Ii = cam::load_scaled(a.intr + qi * (4 + a.D), a.D, 1.0f / prm.intr_factor);
@@ -817,10 +820,11 @@ __global__ __launch_bounds__(TILE) void ba_walk_kernel(BAArgs a) {
   float C = 0.f, wz = 0.f, Ei[6] = {0, 0, 0, 0, 0, 0}, Efr[FF] = {};
   const int l16 = lane & 15, kq = lane >> 4;
 
-  for (int cb = 0; cb < deg_all; cb += WK_CH) {
-    const int deg = min(WK_CH, deg_all - cb);  // terms of this chunk
+  for (int cb = 0; cb < deg_all; cb += WK_CH1) {
+    const int deg = min(WK_CH1, deg_all - cb);  // terms of this chunk
+    // @kstampc 1
     __syncthreads();                            // the previous chunk's flush is done with acc1 / tg
-    for (int i = tid; i < WK_CH * 256; i += TILE) acc1[i] = 0.0f;
+    for (int i = tid; i < WK_CH1 * 256; i += TILE) acc1[i] = 0.0f;
     if (tid < deg) {
       TermGeomM m;
       TermGeom& g = m.g;
@@ -836,6 +840,7 @@ __global__ __launch_bounds__(TILE) void ba_walk_kernel(BAArgs a) {
       tg[tid] = m;
     }
     __syncthreads();
+    // @kstampc 2
 
     // target / weight of the next tile's terms are fetched while the current tile is computed (the walk is otherwise
     // a chain of dependent global-load latencies: measured 5 us per tile)
@@ -950,8 +955,10 @@ __global__ __launch_bounds__(TILE) void ba_walk_kernel(BAArgs a) {
       }
       __builtin_amdgcn_wave_barrier();
     }
+    // @kstampc 3
 
     __syncthreads();
+    // @kstampc 4
     // ---- per-term blocks from the Gram sums (one wave per term)
     for (int t = wave; t < deg; t += NWAVE) {
       const TermGeomM& TG = tg[t];
@@ -1011,9 +1018,11 @@ __global__ __launch_bounds__(TILE) void ba_walk_kernel(BAArgs a) {
       }
       __builtin_amdgcn_wave_barrier();
     }
+    // @kstampc 5
 
   }
   __syncthreads();
+  // @kstamp 20
 
   // ---- frame level: H_ii, v_i, H_if, H_ff, v_f
   {
@@ -1056,6 +1065,7 @@ __global__ __launch_bounds__(TILE) void ba_walk_kernel(BAArgs a) {
       }
     }
   }
+  // @kstamp 21
 }
 
 // ---- multi-view rigs (n_views > 1, optionally the rig-rotation group): the general walk with per-term LOCAL variable
