@@ -1682,6 +1682,31 @@ def test_extract_slam_map_and_project_map():
     assert float((err[hit] / ref_depth[hit]).median()) < 1e-3
 
 
+@pytest.mark.parametrize("n_poses,intr,expect_lds_dense", [(4, False, None), (9, True, None), (17, False, True), (17, True, True),
+                                                          (24, False, True), (27, False, True), (27, True, True), (28, False, False)])
+def test_dense_window_solver_sizes(n_poses, intr, expect_lds_dense):
+    """Sizes of the register-tile dense solver (`ba_solve_dense_kernel`: chain wave + fp64 matrix-core tiles, 6-column
+    block steps, 16 x 16 tiles): windows with every pair coupled from one tile row to the kernel's limit of 160 rows
+    (26 free poses; with the focal length n + 1 = 158), tile-row boundaries (n + 1 = 97: seven tile rows), the partial
+    last block of the intrinsics column - and the first size beyond the limit, which another solver must take.
+    HIP vs the fp64 oracle."""
+    g = make_graph(n=n_poses, height=96, width=128, radius=n_poses - 1, seed=17 + n_poses)
+    bk = dict(t0=1, t1=n_poses, n_iters=2, pose_damping=1e-3, pose_ep=0.1, motion_only=False, limited_disp=False,
+              optimize_intrinsics=intr)
+    p, d, k, info = run_hip_ba(g, g.intrinsics, "pinhole", bk)
+    E = len(g.ii)
+    op, od, ok_, _ = oba.bundle_adjustment(g.poses, g.disps[:, None], g.disps_sens[:, None], g.intrinsics,
+                                           ose3.se3_identity(1), g.target.reshape(E, -1, 2), g.weight.reshape(E, -1, 2),
+                                           g.eta[:, None], g.ii, g.jj, **bk)
+    assert info[0] == n_poses - 1 and info[3] == 6 * (n_poses - 1) + int(intr) and info[2] == 0
+    if expect_lds_dense is not None:
+        assert (info[5] == 2) == expect_lds_dense
+    assert np.abs(p - op).max() <= 1e-4 * max(1.0, np.abs(op).max())
+    assert np.abs(d - od[:, 0]).max() <= 1e-4 * np.abs(od).max()
+    if intr:
+        assert np.abs(k - ok_).max() <= 1e-4 * np.abs(ok_).max()
+
+
 @pytest.mark.parametrize("intr", [False, True])
 def test_dense_ba_dense_window_of_twelve_poses(intr):
     """The frontend's steady state (12 free poses, every pair coupled, source degree 12): the reduced system is a dense
