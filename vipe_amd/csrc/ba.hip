@@ -1858,7 +1858,10 @@ constexpr int B2_T = BAND_T;  // threads per chain: the kernel is launched with 
 __device__ __forceinline__ bool band2_solve_body(const BAArgs& a, int lds_doubles, unsigned char* smem_raw) {
   const vipe_ba_params& prm = a.p;
   const BAWs& w = a.w;
-  const int t = threadIdx.x, g = t >= B2_T ? 1 : 0, tl = t - g * B2_T;
+  // image B's threads are rotated by one wave: its critical wave (tl < 64: diagonal pairs, look-ahead factor, back
+  // substitution) is then hardware wave 9 - another SIMD than image A's wave 0 (waves go to SIMDs round robin); with both
+  // chains' critical waves on one SIMD each ran at the pace of two
+  const int t = threadIdx.x, g = t >= B2_T ? 1 : 0, tl = g ? ((t - 64) & (B2_T - 1)) : t;
   const int n = w.info[3], nb = w.info[0], bandblk = w.info[4];
   const int ld = w.ld;
   if (n != 6 * nb || bandblk < 1 || nb < 4 * bandblk + 4) return false;
