@@ -1546,10 +1546,10 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // pipelined load pass); the frontend's dense windows the <BAND_UPT, true> one.
 template <int UPT_, bool TWO>
 __device__ __forceinline__ void band_solve_body(const BAArgs& a, int lds_doubles, unsigned char* smem_raw) {
+  const int t = threadIdx.x;
   double* const L = reinterpret_cast<double*>(smem_raw);
   const vipe_ba_params& prm = a.p;
   const BAWs& w = a.w;
-  const int t = threadIdx.x;
   const int n = w.info[3], n_free = w.info[0], bandblk = w.info[4];
   const int ld = w.ld;
   const int npr = 6 * n_free, ntail = n - npr + 1;  // tail rows: intrinsics rows, then the rhs row
