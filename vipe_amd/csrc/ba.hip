@@ -18,6 +18,10 @@
 //                     rhs carried as an extra matrix row (forward substitution for free), blocked backward
 //                     substitution, pose / intrinsics retraction.
 //   ba_retract_kernel per pixel dz = (w - sum_a E_ak^T dx_a)/C, d += dz (dz > 10 rejected).
+//
+// Comments of the form `// @stamp N`, `// @stampk N`, `// @wstampk N`, `// @bstamp N`, `// @bwave N`, `// @astamp N`,
+// `// @kstamp N` / `// @kstampc N` mark phase boundaries: scratch/make_ba_stamps.py turns them into s_memtime stores of
+// a VARIANT source for cycle measurements from inside the kernels.  This file compiles none of it.
 #include <stdlib.h>
 
 #include "term_geom.cuh"
