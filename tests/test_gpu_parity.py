@@ -1707,6 +1707,25 @@ def test_dense_window_solver_sizes(n_poses, intr, expect_lds_dense):
         assert np.abs(k - ok_).max() <= 1e-4 * np.abs(ok_).max()
 
 
+def test_dense_window_solver_with_two_intrinsics_columns():
+    """The register-tile dense solver with the unified (MEI) camera: focal length + distortion = TWO tail columns, i.e. a
+    last block step of width 2 (and a 2-wide preview of it one step earlier).  17 poses with every pair coupled
+    (n = 98: the tail starts a new 16 x 16 tile row).  HIP vs the fp64 oracle."""
+    g = make_graph(n=17, height=96, width=128, radius=16, seed=53)
+    intr = np.concatenate([g.intrinsics, np.array([[0.4]], np.float32)], 1)
+    bk = dict(t0=1, t1=17, n_iters=2, pose_damping=1e-3, pose_ep=0.1, motion_only=False, limited_disp=False,
+              optimize_intrinsics=True)
+    p, d, k, info = run_hip_ba(g, intr, "mei", bk)
+    E = len(g.ii)
+    op, od, ok_, _ = oba.bundle_adjustment(g.poses, g.disps[:, None], g.disps_sens[:, None], intr, ose3.se3_identity(1),
+                                           g.target.reshape(E, -1, 2), g.weight.reshape(E, -1, 2), g.eta[:, None], g.ii, g.jj,
+                                           model="mei", **bk)
+    assert info[0] == 16 and info[3] == 98 and info[2] == 0 and info[5] == 2
+    assert np.abs(p - op).max() <= 1e-4 * max(1.0, np.abs(op).max())
+    assert np.abs(d - od[:, 0]).max() <= 1e-4 * np.abs(od).max()
+    assert np.abs(k - ok_).max() <= 1e-4 * np.abs(ok_).max()
+
+
 @pytest.mark.parametrize("intr", [False, True])
 def test_dense_ba_dense_window_of_twelve_poses(intr):
     """The frontend's steady state (12 free poses, every pair coupled, source degree 12): the reduced system is a dense
