@@ -11,7 +11,7 @@ import os
 import numpy as np
 import torch
 
-from .._lib import upload
+from .._lib import upload, upload_many
 from ..ext import slam_ext
 from .networks import AltCorrBlock, CorrBlock, CorrPool
 
@@ -160,8 +160,7 @@ class FactorGraph:
             # leaves the order of equal ages unspecified - the stable order is used here)
             ix = np.argsort(self.host_edges()["age"], kind="stable")
             self.rm_factors(ix >= self.max_factors - ii_h.shape[0], store=True)
-        ii = upload(ii_h, self.device)
-        jj = upload(jj_h, self.device)
+        ii, jj = upload_many([ii_h, jj_h], self.device)
         pi, qi, _, pj, qj, _ = self.buffer.expand_edge_multiview(ii, jj)
         if self.incremental:
             if self.corr is None:
@@ -207,8 +206,7 @@ class FactorGraph:
             self._have.difference_update(zip(h["ii"][m].tolist(), h["jj"][m].tolist()))
         h["ii"], h["jj"], h["age"] = h["ii"][~m], h["jj"][~m], h["age"][~m]
         V = self.buffer.n_views
-        keep = upload(np.flatnonzero(~m), self.device)
-        drop = upload(np.flatnonzero(m), self.device)
+        keep, drop = upload_many([np.flatnonzero(~m), np.flatnonzero(m)], self.device)
         views = torch.arange(V, device=self.device)
         keep_x = (keep[:, None] * V + views).view(-1) if V > 1 else keep
         drop_x = (drop[:, None] * V + views).view(-1) if V > 1 else drop
@@ -258,7 +256,7 @@ class FactorGraph:
             d = np.array(dist, dtype=np.float32).reshape(-1)
             assert d.shape[0] == iin.shape[0]
         else:
-            ii, jj = upload(iin, self.device), upload(jjn, self.device)
+            ii, jj = upload_many([iin, jjn], self.device)
             d = self.buffer.frame_distance_dense_disp(ii, jj, beta=beta).mean(-1).cpu().numpy().astype(np.float32)
         nj = t - t1
 
@@ -373,8 +371,7 @@ class FactorGraph:
                 n_src = int(du.numel())
             else:
                 du_h, dix_h = np.unique(di_h, return_inverse=True)
-                du = upload(du_h, self.device)
-                dix = upload(dix_h.astype(np.int64), self.device)
+                du, dix = upload_many([du_h, dix_h], self.device)
                 n_src = int(du_h.shape[0])
             from .update_engine import segment_csr
             self._plan_serial = getattr(self, "_plan_serial", 0) + 1
@@ -383,7 +380,7 @@ class FactorGraph:
             else:  # the same CSR from the host mirror (torch.bincount reads its maximum back: a stream drain)
                 order_h = np.argsort(dix_h, kind="stable").astype(np.int32)
                 rowptr_h = np.concatenate([[0], np.cumsum(np.bincount(dix_h, minlength=n_src))]).astype(np.int32)
-                csr = (upload(order_h, self.device, torch.int32), upload(rowptr_h, self.device, torch.int32))
+                csr = tuple(upload_many([order_h, rowptr_h], self.device, torch.int32))
             self._plan = dict(pi=pi, qi=qi, di=di, pj=pj, qj=qj, du=du, dix=dix, n_src=n_src,
                               csr=csr,
                               t0=int(max(1, h["ii"].min() + 1)),
@@ -603,12 +600,12 @@ class FactorGraph:
             pis, qis, dis, pjs, qjs, djs = buf.expand_edge_multiview(iis, jjs)
             dis_np = (ii_np[sel][:, None] * V + np.arange(V)).reshape(-1)
             du_np, dixs_np = np.unique(dis_np, return_inverse=True)
+            du_d, dixs_d = upload_many([du_np, dixs_np], self.device)
             c.update(pis=pis, qis=qis, dis=dis, pjs=pjs, qjs=qjs, djs=djs, n=sel.shape[0] * V, n_src=int(du_np.shape[0]),
-                     du=upload(du_np, self.device), dixs=upload(dixs_np.astype(np.int64), self.device),
-                     mask=buf.masks[pis, qis].contiguous())
+                     du=du_d, dixs=dixs_d, mask=buf.masks[pis, qis].contiguous())
             order_h = np.argsort(dixs_np, kind="stable").astype(np.int32)
             rowptr_h = np.concatenate([[0], np.cumsum(np.bincount(dixs_np, minlength=c["n_src"]))]).astype(np.int32)
-            c["csr"] = (upload(order_h, self.device, torch.int32), upload(rowptr_h, self.device, torch.int32))
+            c["csr"] = tuple(upload_many([order_h, rowptr_h], self.device, torch.int32))
             xb = torch.empty((c["n"], self.ht, self.wd, 320), dtype=torch.half, device=self.device)
             xb[..., 0:128] = buf.inps[pis, qis].permute(0, 2, 3, 1)
             c["xb"] = xb

@@ -8,7 +8,7 @@ from dataclasses import dataclass
 
 import torch
 
-from .._lib import upload
+from .._lib import upload, upload_many
 from ..ext.lietorch import SE3
 from .factor_graph import FactorGraph
 
@@ -70,7 +70,8 @@ class SLAMFrontend:
         import numpy as np
         iin, jjn = np.meshgrid(np.arange(t0, t, dtype=np.int64), np.arange(t1, t, dtype=np.int64), indexing="ij")
         dev = self.video.device
-        d = self.video.frame_distance_dense_disp(upload(iin.reshape(-1), dev), upload(jjn.reshape(-1), dev), beta=a.beta,
+        ii_d, jj_d = upload_many([iin.reshape(-1), jjn.reshape(-1)], dev)
+        d = self.video.frame_distance_dense_disp(ii_d, jj_d, beta=a.beta,
                                                  n_frames=t).mean(-1)
         host = torch.empty(d.shape, dtype=d.dtype, pin_memory=True)
         host.copy_(d, non_blocking=True)
@@ -97,7 +98,8 @@ class SLAMFrontend:
                                          beta=a.beta, remove=True, dist=self._prefetched_distances(t0p, t1p, a.beta))
         self._iterate(self.iters1)
         dev = self.video.device
-        d = self.video.frame_distance_dense_disp(upload([self.t1 - 3], dev), upload([self.t1 - 2], dev), beta=a.beta,
+        ii_d, jj_d = upload_many([[self.t1 - 3], [self.t1 - 2]], dev)
+        d = self.video.frame_distance_dense_disp(ii_d, jj_d, beta=a.beta,
                                                  bidirectional=True)
         if d.max().item() < a.keyframe_thresh:
             self.graph.rm_second_newest_keyframe(self.t1 - 2)
