@@ -54,7 +54,7 @@ extern "C" {
 
 /* library / build identification ("gfx950", ABI version) */
 const char* vipe_amd_version(void);
-int vipe_amd_abi_version(void); /* 3 since round 3 (vipe_ba_params.solver_options; rounds 1-2: 1, 2) */
+int vipe_amd_abi_version(void); /* 4 since round 4 (vipe_corr_pyramid_build_prepared.n_prepared, slot-indexed operator state); 3: vipe_ba_params.solver_options; rounds 1-2: 1, 2 */
 
 /* ---------------------------------------------------------------------------------------------
  * droid_net_ext  (csrc/droid_net_ext/droid.cpp:57-63)
@@ -112,13 +112,14 @@ int vipe_corr_pyramid_build_indexed(const void* d_fmaps, const int64_t* d_idx1, 
  * operand images the MFMA kernel loads with aligned 16-byte accesses (an h x w map with an odd pixel count has no
  * aligned rows):  vipe_corr_prep(d_fmaps [n,C,h,w] f16 -> d_prep [n][vipe_corr_prep_halves(C,h,w)] f16), then
  * vipe_corr_pyramid_build_prepared with frame indices d_idx1 / d_idx2 counted from `frame_base` (d_prep holds frames
- * frame_base .. frame_base + n - 1 of the keyframe buffer).  Output: VIPE_PYRAMID_BLOCKED on the padded grid.
+ * frame_base .. frame_base + n_prepared - 1 of the keyframe buffer; an edge one of whose frames lies outside that range
+ * is SKIPPED - its slot keeps its old contents - instead of reading outside d_prep).  Output: VIPE_PYRAMID_BLOCKED on the padded grid.
  * vipe_corr_blocked_dims: dims6 = {G, S, R, level-2 row pitch, level-3 row pitch, 1 if vipe_corr_pyramid_build_indexed
  * tiles this grid directly (no preparation needed) else 0}. */
 int vipe_corr_blocked_dims(int h, int w, int* dims6);
 int64_t vipe_corr_prep_halves(int C, int h, int w);
 int vipe_corr_prep(const void* d_fmaps, void* d_prep, int n, int C, int h, int w, void* stream);
-int vipe_corr_pyramid_build_prepared(const void* d_prep, int64_t frame_base, const int64_t* d_idx1, const int64_t* d_idx2,
+int vipe_corr_pyramid_build_prepared(const void* d_prep, int64_t frame_base, int64_t n_prepared, const int64_t* d_idx1, const int64_t* d_idx2,
                                      const int* d_slots, void* const* h_levels, int B, int C, int h, int w, int num_levels,
                                      void* stream);
 

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     L = _lib.lib()
     assert b"gfx950" in L.vipe_amd_version()
-    assert L.vipe_amd_abi_version() == 3
+    assert L.vipe_amd_abi_version() == 4
 
 
 def test_header_cites_reference_interfaces():
@@ -95,6 +95,9 @@ def test_scatter_host_path_and_autograd():
     import pytest
     with pytest.raises(_lib.VipeError):
         scatter.scatter_sum(src.detach(), idx + 100, 1, None, 6)  # out-of-range index is an error, not a stray write
+    # an index with fewer dims than `dim` (scatter.cpp:19-26 appends trailing dims and broadcasts): index [1,1], dim 2
+    s3 = torch.arange(5.0, dtype=torch.float64).view(1, 1, 5)
+    assert torch.equal(scatter.scatter_sum(s3, torch.zeros(1, 1, dtype=torch.long), 2), torch.full((1, 1, 1), 10.0, dtype=torch.float64))
 
 
 def test_corr_ext_host_path_against_torch_autograd():
@@ -203,3 +206,32 @@ def test_motion_filter_sparse_track_score():
     assert s3 != s3 and not (s3 > 4.8) and mf.last_n_sparse_tracks == 0
     tr.enabled = False
     assert mf._sparse_motion_score(1) == 0.0
+
+
+def test_vipe_ext_module_binds_like_the_reference_loader():
+    """vipe/ext/__init__.py:24-46 of the reference: `import vipe_ext as _C`, then seven attribute reads.  With this
+    repository on the path the unmodified loader finds the package; the calls below go through the C ABI (host loop)."""
+    import vipe_ext as _C
+    droid_net_ext = _C.droid_net_ext
+    grounding_dino_ext = _C.grounding_dino_ext
+    utils_ext = _C.utils_ext
+    slam_ext = _C.slam_ext
+    scatter_ext = _C.scatter_ext
+    lietorch_ext = _C.lietorch_ext
+    corr_ext = _C.corr_ext
+    for mod, names in ((droid_net_ext, ("corr_index_forward", "corr_index_backward", "altcorr_forward", "altcorr_backward")),
+                       (slam_ext, ("ba", "frame_distance", "projmap", "depth_filter", "iproj")),
+                       (lietorch_ext, ("expm", "logm", "inv", "mul", "adj", "adjT", "act", "act4", "as_matrix", "projector",
+                                       "Jinv", "expm_backward", "mul_backward", "act4_backward")),
+                       (scatter_ext, ("scatter_sum", "scatter_mean", "scatter_mul", "scatter_min", "scatter_max")),
+                       (corr_ext, ("forward", "backward")), (utils_ext, ("nearest_neighbours",)),
+                       (grounding_dino_ext, ("ms_deform_attn_forward", "ms_deform_attn_backward"))):
+        for n in names:
+            assert callable(getattr(mod, n)), (mod, n)
+    xi = torch.tensor([[0.1, -0.2, 0.3, 0.02, 0.01, -0.03]], dtype=torch.float64)
+    X = _C.lietorch_ext.expm(3, xi)  # SE3 group id 3, as the reference's group classes call it (group_ops.py)
+    assert np.abs(X.numpy() - ose3.se3_exp(xi.numpy())).max() < 1e-12
+    assert np.abs(_C.lietorch_ext.logm(3, X).numpy() - xi.numpy()).max() < 1e-12
+    import pytest
+    with pytest.raises(NotImplementedError):
+        _C.grounding_dino_ext.ms_deform_attn_forward()

@@ -644,3 +644,53 @@ def test_tile_convolution_beyond_4_gib_of_input():
         ref = F.conv2d(x[b, :, :, :cin].float().cpu().permute(2, 0, 1)[None], w.float(), None, padding=1)[0]
         assert (y[b].float().cpu().permute(2, 0, 1) - ref).abs().max().item() < 4e-3, b
     assert not y[1].any()
+
+
+@pytest.mark.gpu
+def test_cross_view_self_edges_outside_the_edge_window_on_a_ragged_grid():
+    """A two-camera rig on a grid that needs prepared operand images (9 x 18), with `cross_view_idx` re-targeted the way
+    `GraphBuffer.build_adaptive_cross_view_idx` leaves it: the cross-view self edge (i, i) of the NEWEST keyframes
+    correlates with keyframe 0, far outside the window [lo, hi] of the host (ii, jj) the edges are added with.  The
+    pyramid of every such edge must be the one of (frame i*V+v) x (frame 0*V+v'): the prepared range has to cover it
+    (round-3 advisor finding: it covered frames [lo*V, (hi+1)*V) only and the kernel read outside the store).  Also:
+    the library skips - does not read for - an edge whose frame is outside the prepared range."""
+    from oracle import corr as ocorr
+    from vipe_amd.ext import droid_net_ext
+    from vipe_amd.slam.buffer import GraphBuffer
+    from vipe_amd.slam.factor_graph import FactorGraph
+    from vipe_amd.slam.networks import UpdateModule
+    h, w, V, n = 9, 18, 2, 6
+    buf = GraphBuffer(h * 8, w * 8, n_views=V, buffer_size=8, device=dev())
+    buf.n_frames = n
+    gen = torch.Generator().manual_seed(11)
+    buf.fmaps[:n] = torch.randn(n, V, 128, h, w, generator=gen).half().to(dev())
+    buf.nets[:n] = torch.randn(n, V, 128, h, w, generator=gen).tanh().half().to(dev())
+    buf.inps[:n] = torch.randn(n, V, 128, h, w, generator=gen).relu().half().to(dev())
+    buf.intrinsics[:] = torch.tensor([60.0, 60.0, w * 4.0, h * 4.0], device=dev())
+    buf.cross_view_idx[4:6, :, 0] = 0          # keyframes 4, 5: cross-view partner = keyframe 0, other view
+    torch.manual_seed(0)
+    graph = FactorGraph(UpdateModule().eval(), buf, dev(), max_factors=-1, cross_view=True)
+    ii = np.array([4, 5, 4, 5], dtype=np.int64)
+    jj = np.array([4, 5, 5, 4], dtype=np.int64)    # host window [4, 5]; the self edges point at keyframe 0
+    graph.add_factors(torch.from_numpy(ii), torch.from_numpy(jj))
+    P_ = graph._edge_plan()
+    pi, qi, pj, qj = (P_[k].cpu().numpy() for k in ("pi", "qi", "pj", "qj"))
+    assert (pj[:4] == 0).all() and (pj[4:] >= 4).all()
+    lv = graph.corr.corr_pyramid  # reference layout, edge order
+    fm = buf.flattened_fmaps.cpu().numpy()
+    for e in range(len(pi)):
+        f1, f2 = fm[pi[e] * V + qi[e]].astype(np.float32), fm[pj[e] * V + qj[e]].astype(np.float32)
+        want = (f1.reshape(128, -1).T @ f2.reshape(128, -1) / 16.0).reshape(h, w, h, w)
+        got = lv[0][e].float().cpu().numpy()
+        assert np.abs(got - want).max() < 2e-2 * max(1.0, np.abs(want).max()), e
+    # direct library call with a frame outside the prepared range: the edge is skipped, the slot keeps its contents
+    fmaps = buf.flattened_fmaps[:n * V].contiguous()
+    idx1 = torch.tensor([8, 9], device=dev())
+    idx2 = torch.tensor([9, 0], device=dev())   # frame 0 is outside [8, 12)
+    levels = [torch.full(s, 7.0, dtype=torch.float16, device=dev())
+              for s in droid_net_ext.pyramid_level_shapes(2, h, w, 4, droid_net_ext.BLOCKED)]
+    droid_net_ext.corr_pyramid_build_indexed(fmaps, idx1, idx2, levels=levels, frame_range=(8, 12))
+    torch.cuda.synchronize()
+    ref = droid_net_ext.pyramid_to_reference(levels, h, w)
+    assert bool((ref[0][1] == 7.0).all()), "edge with a frame outside the prepared store must be left untouched"
+    assert not bool((ref[0][0] == 7.0).all())

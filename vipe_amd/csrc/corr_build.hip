@@ -70,6 +70,7 @@ struct BuildArgs {
   half_t* lv[4];
   int B, h, w, nlev;
   int64_t base;          // GEN: f1 is the prepared store of frames [base, base + n): edge e reads frames idx1[e] - base, ..
+  int64_t n_prep;        // GEN: n; an edge with a frame outside the store is skipped (its slot is left as it was)
 };
 
 // geometry of the padded blocked layout (shared with corr_lookup.hip through include/vipe_amd.h's description)
@@ -142,6 +143,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int tiles = P / PB_M;
   const int L = xcd_remap(blockIdx.x, gridDim.x);
   const int e = L / tiles, p1_0 = (L % tiles) * PB_M;
+  if (GEN) {  // whole workgroups leave (e is uniform): a frame index outside the prepared store would be a wild read
+    const int64_t r1 = (a.idx1 ? a.idx1[e] : (int64_t)e) - a.base, r2 = (a.idx2 ? a.idx2[e] : (int64_t)e) - a.base;
+    if (r1 < 0 || r1 >= a.n_prep || r2 < 0 || r2 >= a.n_prep) return;
+  }
   // operand images: rows of the [C][h*w] maps, or (GEN) of the prepared A / B images of the two frames
   const int pitch1 = P, pitch2 = GEN ? gd.nch * 128 : P;
   const half_t* f1 = GEN ? a.f1 + ((a.idx1 ? a.idx1[e] : (int64_t)e) - a.base) * gd.fstride
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(256) void avg_pool2x2_kernel(const T* __restrict__ 
 
 static int build_impl(const void* d_f1, const void* d_f2, const int64_t* d_idx1, const int64_t* d_idx2, const int* d_slots,
                       void* const* h_levels, int B, int C, int h, int w, int num_levels, int layout, bool prepared,
-                      int64_t base, void* stream) {
+                      int64_t base, int64_t n_prep, void* stream) {
   VIPE_CHECK_ARG(h_levels && num_levels >= 1 && num_levels <= 4 && B >= 0 && C > 0 && h > 0 && w > 0);
   VIPE_CHECK_ARG(layout == VIPE_PYRAMID_REFERENCE || layout == VIPE_PYRAMID_BLOCKED);
   if (B == 0) return VIPE_OK;
@@ -415,7 +420,7 @@ static int build_impl(const void* d_f1, const void* d_f2, const int64_t* d_idx1,
   a.f2 = (const half_t*)d_f2;
   a.idx1 = d_idx1; a.idx2 = d_idx2; a.slots = d_slots;
   for (int i = 0; i < 4; ++i) a.lv[i] = i < num_levels ? (half_t*)h_levels[i] : nullptr;
-  a.B = B; a.h = h; a.w = w; a.nlev = num_levels; a.base = base;
+  a.B = B; a.h = h; a.w = w; a.nlev = num_levels; a.base = base; a.n_prep = n_prep;
   static std::atomic<uint64_t> attr{0};  // bit d: set on device d
   vipe_once_per_device(attr, [] {
     (void)hipFuncSetAttribute((const void*)corr_pyramid_build_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS);
@@ -434,14 +439,14 @@ extern "C" {
 VIPE_EXPORT int vipe_corr_pyramid_build(const void* d_fmap1, const void* d_fmap2, void* const* h_levels, int B, int C,
                                         int h, int w, int num_levels, void* stream) {
   return build_impl(d_fmap1, d_fmap2, nullptr, nullptr, nullptr, h_levels, B, C, h, w, num_levels, VIPE_PYRAMID_REFERENCE,
-                    false, 0, stream);
+                    false, 0, 0, stream);
 }
 
 VIPE_EXPORT int vipe_corr_pyramid_build_indexed(const void* d_fmaps, const int64_t* d_idx1, const int64_t* d_idx2,
                                                 const int* d_slots, void* const* h_levels, int B, int C, int h, int w,
                                                 int num_levels, int layout, void* stream) {
   VIPE_CHECK_ARG(B == 0 || (d_idx1 && d_idx2));
-  return build_impl(d_fmaps, d_fmaps, d_idx1, d_idx2, d_slots, h_levels, B, C, h, w, num_levels, layout, false, 0, stream);
+  return build_impl(d_fmaps, d_fmaps, d_idx1, d_idx2, d_slots, h_levels, B, C, h, w, num_levels, layout, false, 0, 0, stream);
 }
 
 VIPE_EXPORT int vipe_corr_blocked_dims(int h, int w, int* dims6) {
@@ -468,12 +473,12 @@ VIPE_EXPORT int vipe_corr_prep(const void* d_fmaps, void* d_prep, int n, int C, 
   return vipe_launch_status();
 }
 
-VIPE_EXPORT int vipe_corr_pyramid_build_prepared(const void* d_prep, int64_t frame_base, const int64_t* d_idx1,
+VIPE_EXPORT int vipe_corr_pyramid_build_prepared(const void* d_prep, int64_t frame_base, int64_t n_prepared, const int64_t* d_idx1,
                                                  const int64_t* d_idx2, const int* d_slots, void* const* h_levels, int B,
                                                  int C, int h, int w, int num_levels, void* stream) {
-  VIPE_CHECK_ARG(B == 0 || (d_idx1 && d_idx2));
+  VIPE_CHECK_ARG((B == 0 || (d_idx1 && d_idx2)) && n_prepared >= 0);
   return build_impl(d_prep, d_prep, d_idx1, d_idx2, d_slots, h_levels, B, C, h, w, num_levels, VIPE_PYRAMID_BLOCKED, true,
-                    frame_base, stream);
+                    frame_base, n_prepared, stream);
 }
 
 VIPE_EXPORT int vipe_corr_volume(const void* d_fmap1, const void* d_fmap2, void* d_volume, int B, int C, int P, int dtype,

@@ -238,8 +238,10 @@ def corr_pyramid_build_indexed(fmaps, idx1, idx2, levels=None, slots=None, layou
         both = torch.cat([idx1, idx2])
         frame_range = (int(both.min().item()), int(both.max().item()) + 1)
     lo, hi = max(0, int(frame_range[0])), min(n, int(frame_range[1]))
+    require(hi > lo, "corr_pyramid_build_indexed: empty frame range")
     prep = corr_prep(fmaps[lo:hi])
-    check(lib().vipe_corr_pyramid_build_prepared(ptr(prep), lo, ptr(idx1), ptr(idx2), sl, _level_ptrs(levels), E, C, h, w,
+    # an index outside [lo, hi) cannot be detected here without a read-back: the kernel skips such an edge (bounded read)
+    check(lib().vipe_corr_pyramid_build_prepared(ptr(prep), lo, hi - lo, ptr(idx1), ptr(idx2), sl, _level_ptrs(levels), E, C, h, w,
                                                  num_levels, stream_ptr(fmaps)), "corr_pyramid_build_prepared")
     return levels
 

@@ -33,6 +33,8 @@ def _row_index(index, src, dim):
     whose other dimensions are 1 (what scatter_mean / scatter_add callers pass: droid_net.py:420-421) - else None"""
     if index.dim() == 1:
         return index.contiguous() if index.shape[0] == src.shape[dim] else None
+    if dim >= index.dim():  # scatter.cpp:19-26 appends trailing dims: the index does not run along `dim` at all
+        return None
     if index.dim() <= src.dim() and all(int(s) == 1 for i, s in enumerate(index.shape) if i != dim) and index.shape[dim] == src.shape[dim]:
         return index.reshape(-1).contiguous()
     return None

@@ -168,7 +168,10 @@ class FactorGraph:
             V = self.buffer.n_views
             lo, hi = int(min(ii_h.min(), jj_h.min())), int(max(ii_h.max(), jj_h.max()))
             f1, f2 = (pi, pj) if V == 1 else (pi * V + qi, pj * V + qj)  # one view: frame index = pose index
-            self.corr.add_edges(self.buffer.flattened_fmaps, f1, f2, frame_range=(lo * V, (hi + 1) * V))
+            # a cross-view self edge (i, i) is re-targeted to cross_view_idx[i, v] by expand_edge_multiview - after an
+            # adaptive cross-view pass that may be ANY keyframe of the buffer: the host (ii, jj) do not bound the frames
+            rng = (0, self.buffer.n_frames * V) if (self.cross_view and V > 1) else (lo * V, (hi + 1) * V)
+            self.corr.add_edges(self.buffer.flattened_fmaps, f1, f2, frame_range=rng)
             WORK["pyramids_built"] += int(pi.shape[0])
             xb = torch.zeros((ii.shape[0] * self.buffer.n_views, self.ht, self.wd, 320), dtype=torch.half,
                              device=self.device)
@@ -627,8 +630,9 @@ class FactorGraph:
                     vol = vols.get(gi)
                     if vol is None:
                         vol = CorrBlock.from_buffer(buf.flattened_fmaps, c["pis"] * V + c["qis"], c["pjs"] * V + c["qjs"],
-                                                    frame_range=(int(min(ii_np.min(), jj_np.min())) * V,
-                                                                 (int(max(ii_np.max(), jj_np.max())) + 1) * V))
+                                                    frame_range=(0, t * V) if (self.cross_view and V > 1) else
+                                                    (int(min(ii_np.min(), jj_np.min())) * V,
+                                                     (int(max(ii_np.max(), jj_np.max())) + 1) * V))
                         WORK["pyramids_built"] += n
                         if keep_vols:
                             vols[gi] = vol
