@@ -508,9 +508,46 @@ def gen_splat(R):
     print("splat: weight sum", float(wgt.sum()))
 
 
+def gen_headline(R):
+    """Headline-size fixtures from the reference itself (BASELINE configs[2]: 512 x 384, 48 keyframes, E = 276, depth
+    prior on - the graph `bench.py` times):
+      (a) the reference `Solver` on `make_graph(n=48, 384 x 512, radius 3, seed 1234, depth_prior=True)` with the
+          frontend's BA parameters, 3 Gauss-Newton iterations -> poses [48,7], disps [48,48,64] (inputs are re-created from
+          the seed by the tests);
+      (b) the reference `UpdateModule` (seed-0 default-init weights) on [1,4,.,48,64] inputs with `ix` - SURVEY 8(c)
+          golden #1 at the full grid; hidden state kept 1:8 in channels."""
+    g = make_graph(n=48, height=384, width=512, radius=3, seed=1234, depth_prior=True)
+    p, d, k, en = reference_ba(R, g.poses, g.disps, g.disps_sens, g.intrinsics, g.target, g.weight, g.eta, g.ii, g.jj,
+                               t0=1, t1=48, n_iters=3, pose_damping=1e-3, pose_ep=0.1, motion_only=False,
+                               limited_disp=False, optimize_intrinsics=False)
+    print("headline BA: E =", len(g.ii), "energy", en)
+    np.savez_compressed(os.path.join(HERE, "ba_headline_reference.npz"), poses=p, disps=d, intrinsics=k, energy=en,
+                        n_edges=np.array([len(g.ii)]))
+    torch.manual_seed(0)
+    um = R.droid_net.UpdateModule().eval()
+    E, ht, wd = 4, 48, 64
+    gen = torch.Generator().manual_seed(21)
+    net = torch.randn(1, E, 128, ht, wd, generator=gen).tanh()
+    inp = torch.randn(1, E, 128, ht, wd, generator=gen).relu()
+    corr = torch.randn(1, E, 196, ht, wd, generator=gen)
+    flow = torch.randn(1, E, 4, ht, wd, generator=gen) * 4
+    ix = torch.tensor([0, 0, 1, 2])
+    with torch.no_grad():
+        net2, delta, weight, eta, upmask = um(net, inp, corr, flow, ix)
+    insum = np.array([float(t.double().sum()) for t in (net, inp, corr, flow)])
+    sd = {"sdsum/" + kk: np.array([float(v.double().sum()), float(v.double().abs().sum())]) for kk, v in um.state_dict().items()}
+    np.savez_compressed(os.path.join(HERE, "update_module_headline_reference.npz"), input_sums=insum, ix=_np(ix),
+                        out_net_sub=_np(net2[:, :, ::8]).astype(np.float16), out_delta=_np(delta), out_weight=_np(weight),
+                        out_eta=_np(eta), **sd)
+    print("headline UpdateModule:", tuple(net2.shape), "delta range", float(delta.min()), float(delta.max()))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     R = load_reference()
+    if os.environ.get("GOLDEN_ONLY") == "headline":
+        gen_headline(R)
+        sys.exit(0)
     if os.environ.get("GOLDEN_ONLY") == "edges":
         gen_edge_selection(R)
         sys.exit(0)
@@ -536,4 +573,5 @@ if __name__ == "__main__":
     gen_update_module(R)
     gen_corr(R)
     gen_encoder(R)
+    gen_headline(R)
     print("golden fixtures written to", HERE)

@@ -233,6 +233,64 @@ def test_dense_ba_matches_reference_solver(name):
     assert np.abs(rp - g.poses).max() + np.abs(rd - g.disps).max() > 1e-3
 
 
+def test_dense_ba_matches_reference_solver_at_the_headline_size():
+    """BASELINE configs[2] without the oracle in between: the HIP BA on the very graph `bench.py` times (48 keyframes,
+    48 x 64, E = 276, depth prior on, 3 Gauss-Newton iterations) against the reference `Solver`'s own output
+    (`ba_headline_reference.npz`, make_golden.gen_headline), 1e-4 relative; the default kernel selection (fused
+    matrix-core accumulate, two-chain band solve) and the general forms."""
+    from vipe_amd.ext import slam_ext
+    G = np.load(os.path.join(GOLD, "ba_headline_reference.npz"))
+    g = make_graph(n=48, height=384, width=512, radius=3, seed=1234, depth_prior=True)
+    assert len(g.ii) == int(G["n_edges"][0]) == 276
+    rp, rd = G["poses"], G["disps"]
+    for opts in (0, slam_ext.BA_OPT_ONE_CHAIN | slam_ext.BA_OPT_GENERAL_ACCUMULATE):
+        p, d, k, info = run_hip_ba(g, g.intrinsics, "pinhole",
+                                   dict(t0=1, t1=48, n_iters=3, pose_damping=1e-3, pose_ep=0.1, solver_options=opts))
+        assert info[2] == 0, "Cholesky must not fail"
+        assert np.abs(p - rp).max() <= 1e-4 * max(1.0, np.abs(rp).max()), opts
+        assert np.abs(d - rd).max() <= 1e-4 * np.abs(rd).max(), opts
+    assert np.abs(rp - g.poses).max() + np.abs(rd - g.disps).max() > 1e-3
+
+
+def test_bench_operator_path_matches_reference_update_module_at_the_headline_grid():
+    """SURVEY 8(c) golden #1 at [1,4,.,48,64] against the operator exactly as the bench's step drives it: natively
+    sequenced (`vipe_update_operator`), gate context hoisted (`gate_context`), the hidden-state part of the z|r gates
+    and the global-context terms staged beforehand (`hidden_gate_state`, for HALF the edges as `FactorGraph.update`
+    does), two streams inside the call - vs the reference class's own fp32 outputs.  Tolerance as
+    test_update_module_matches_reference_fixture (fp16 activations through ~8 layers)."""
+    from vipe_amd.synth import headline_update_module_inputs
+    from vipe_amd.slam.update_engine import CORR_CH, UpdateEngine, segment_csr
+    G = np.load(os.path.join(GOLD, "update_module_headline_reference.npz"))
+    um, net, inp, cor, flow = headline_update_module_inputs()
+    eng = UpdateEngine(um, dev())
+    eng.op_side_min_edges = 1  # the bench's E = 276 is above the default threshold; here 4 edges must take the same path
+    E, ht, wd = 4, 48, 64
+    f16 = torch.float16
+    net_n = net[0].permute(0, 2, 3, 1).contiguous().to(dev(), f16)
+    xbuf = torch.zeros(E, ht, wd, 320, dtype=f16, device=dev())
+    xbuf[..., :128] = inp[0].permute(0, 2, 3, 1).to(dev(), f16)
+    corr_n = torch.zeros(E, ht, wd, CORR_CH, dtype=f16, device=dev())
+    corr_n[..., :196] = cor[0].permute(0, 2, 3, 1).to(dev(), f16)
+    motn = flow[0].permute(0, 2, 3, 1).contiguous().to(dev(), f16)
+    ix = torch.from_numpy(G["ix"]).to(dev())
+    csr = segment_csr(ix, 3)
+    pg = eng.gate_context(xbuf)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # staged on a second stream, as under the BA
+        gs = eng.hidden_gate_state(net_n, pg, n_staged=2)
+    torch.cuda.current_stream().wait_stream(side)
+    assert eng.gate_state_matches(gs, net_n, pg)
+    n2, dw, eta, _ = eng.forward_nhwc(net_n, xbuf, corr_n, motn, ix=ix, n_src=3, csr=csr, pgate=pg, gate_state=gs, native=True)
+    torch.cuda.synchronize()
+    assert eng._op_side is not None
+    n2 = n2.permute(0, 3, 1, 2)[None].float().cpu().numpy()
+    assert np.abs(n2[:, :, ::8] - G["out_net_sub"].astype(np.float32)).max() < 2e-2
+    assert np.abs(dw[..., 0:2].cpu().numpy()[None] - G["out_delta"]).max() < 2e-2
+    assert np.abs(dw[..., 2:4].cpu().numpy()[None] - G["out_weight"]).max() < 1e-2
+    assert np.abs(eta.cpu().numpy()[None] - G["out_eta"]).max() < 2e-4
+
+
 def _ba_rig_cases():
     src = open(os.path.join(GOLD, "make_golden.py")).read()
     ns = {}
@@ -1366,24 +1424,41 @@ def test_frontend_mirror_runs_and_keeps_graph_state_consistent():
 
 def test_clip_pipeline_at_bench_resolution_from_rgb():
     """BASELINE configs[1]-shaped run at the bench resolution (512 x 384, 48 x 64 grid - the shapes every fast kernel
-    is specialised for): RGB frames -> motion filter (feature / context encoders, one operator application) on the side
-    stream -> keyframe frontend (proximity edges, pyramids into the pooled store, 4 + 2 update iterations with inactive
-    edges in the BA) -> the two global-BA passes, exactly as `bench.py --mode video --with-backend` runs it; pipelined
-    and serial forms of the driver must agree on the bookkeeping and produce close trajectories (the atomically pooled
-    global-context sums make them differ in the last bits)."""
+    is specialised for) through the product's entry point, exactly as `bench.py --mode video` runs it: ONE
+    `SLAMSystem.run(frames)` - RGB + sensor-depth frames -> motion filter (feature / context encoders, one operator
+    application; `SLAMConfig.pipeline_filter`: prefetched on the side stream under the previous keyframe's frontend
+    step) -> keyframe frontend (proximity edges, pyramids into the pooled store, 4 + 2 update iterations with inactive
+    edges in the BA) -> the two global-BA passes -> pass 2.  The pipelined and the serial schedule must agree on the
+    bookkeeping and produce close trajectories (the atomically pooled global-context sums make them differ in the last
+    bits); the pipelined run must really have collected prefetched filter work."""
     import bench
-    res = {}
+    from vipe_amd.slam.motion_filter import MotionFilter
+    res, collected = {}, {True: 0, False: 0}
+    real_finish = MotionFilter.finish
     for pipelined in (True, False):
-        run_clip = bench.make_clip_runner(dev(), pipelined=pipelined)
-        res[pipelined] = run_clip(seed=3, n_frames=14, with_backend=True, with_infill=True)
+        def finish(self, h, _p=pipelined):
+            collected[_p] += int(h["stream"] is not None)
+            return real_finish(self, h)
+        MotionFilter.finish = finish
+        try:
+            run_clip = bench.make_clip_runner(dev(), pipelined=pipelined)
+            res[pipelined] = run_clip(seed=3, n_frames=14)
+        finally:
+            MotionFilter.finish = real_finish
+    assert collected[True] == 13 and collected[False] == 0  # every frame but the first came through the side stream
     for r in res.values():
         assert r["finite"] and r["keyframes"] == 14 and r["update_iterations"] == 8 + 6 * 6
-        assert r["infill_frames"] == 14  # pass 2: every frame got a pose (here all of them are keyframes)
+        assert tuple(r["poses"].shape) == (14, 7)  # pass 2: every frame got a pose (here all of them are keyframes)
         assert 0 < r["edges_final"] <= 48 + 2 * 3 and r["backend_edges"] > r["edges_final"]
         q = r["poses"][:, 3:]
         assert (q.norm(dim=-1) - 1.0).abs().max().item() < 1e-4  # unit quaternions after every retraction
+        assert r["pass1_seconds"] < r["seconds_to_global_ba_done"] < r["seconds_to_pass2_done"] <= r["seconds"]
     assert res[True]["edges_final"] == res[False]["edges_final"] and res[True]["backend_edges"] == res[False]["backend_edges"]
     assert (res[True]["poses"] - res[False]["poses"]).abs().max().item() < 5e-2
+    # a scripted keep rate: about one frame in four becomes a keyframe, the others get their pose in pass 2
+    thr = bench.keep_rate_threshold(res[True]["filter_scores"], 0.25)
+    r4 = bench.make_clip_runner(dev())(seed=4, n_frames=40, filter_thresh=thr)
+    assert r4["finite"] and tuple(r4["poses"].shape) == (40, 7) and 2 <= r4["keyframes"] < 30
 
 
 def test_backend_depth_prior_branch_with_a_pluggable_depth_model():

@@ -104,6 +104,22 @@ def test_ba_matches_reference_solver(name, dtype):
     assert np.abs(rp - g.poses).max() + np.abs(rd - g.disps).max() > 1e-3
 
 
+def test_ba_matches_reference_solver_at_the_headline_size():
+    """BASELINE configs[2] itself - 48 keyframes, 48 x 64 grid, E = 276, depth prior on, 3 Gauss-Newton iterations, the
+    graph `bench.py` times - through the reference `Solver` (`ba_headline_reference.npz`, make_golden.gen_headline)."""
+    G = np.load(os.path.join(GOLD, "ba_headline_reference.npz"))
+    g = make_graph(n=48, height=384, width=512, radius=3, seed=1234, depth_prior=True)
+    E = len(g.ii)
+    assert E == int(G["n_edges"][0]) == 276
+    p, d, _, _ = ba.bundle_adjustment(g.poses, g.disps[:, None], g.disps_sens[:, None], g.intrinsics, se3.se3_identity(1),
+                                      g.target.reshape(E, -1, 2), g.weight.reshape(E, -1, 2), g.eta[:, None], g.ii, g.jj,
+                                      t0=1, t1=48, n_iters=3, pose_damping=1e-3, pose_ep=0.1)
+    rp, rd = G["poses"], G["disps"]
+    assert np.abs(p - rp).max() <= 2e-5 * max(1.0, np.abs(rp).max())
+    assert np.abs(d[:, 0] - rd).max() <= 2e-5 * np.abs(rd).max()
+    assert np.abs(rp - g.poses).max() + np.abs(rd - g.disps).max() > 1e-3 and G["energy"][-1] < G["energy"][0]
+
+
 def test_ba_energy_decreases():
     G = np.load(os.path.join(GOLD, "ba_reference.npz"))
     for name in BA_CASES:
@@ -256,6 +272,25 @@ def test_update_module_matches_reference():
     assert np.allclose(weight.numpy(), G["out_weight"], atol=2e-5)
     assert np.allclose(eta.numpy(), G["out_eta"], atol=2e-6)
     assert np.allclose(upmask[:, :, ::16].numpy(), G["out_upmask_sub"], atol=2e-5)
+
+
+def test_update_module_matches_reference_at_the_headline_grid():
+    """SURVEY 8(c) golden #1 at [1,4,.,48,64]: the reference class's own outputs (`update_module_headline_reference.npz`)."""
+    G = np.load(os.path.join(GOLD, "update_module_headline_reference.npz"))
+    from vipe_amd.synth import headline_update_module_inputs
+    um, net, inp, cor, flow = headline_update_module_inputs()
+    sd = um.state_dict()
+    for k, v in sd.items():
+        ref = G["sdsum/" + k]
+        assert abs(float(v.double().sum()) - ref[0]) < 1e-6 * max(1, ref[1]), k
+    for t, s in zip((net, inp, cor, flow), G["input_sums"]):
+        assert abs(float(t.double().sum()) - s) < 1e-6 * t.numel()
+    with torch.no_grad():
+        n2, delta, weight, eta, _ = update_module.update_forward(sd, net, inp, cor, flow, torch.from_numpy(G["ix"]))
+    assert np.allclose(n2[:, :, ::8].numpy(), G["out_net_sub"].astype(np.float32), atol=1e-3)  # stored as fp16
+    assert np.allclose(delta.numpy(), G["out_delta"], atol=2e-5)
+    assert np.allclose(weight.numpy(), G["out_weight"], atol=2e-5)
+    assert np.allclose(eta.numpy(), G["out_eta"], atol=2e-6)
 
 
 @pytest.mark.parametrize("case", ["frontend", "backend", "backend_dense"])

@@ -49,6 +49,8 @@ class MotionFilter:
         self.sparse_tracks = sparse_tracks
         self.initialized = False
         self.last_score = None
+        self._pending = None  # handle of a prefetched `begin` (see prefetch)
+        self.scores = []      # the dense score of every frame checked after the first (host floats; diagnostics)
 
     @staticmethod
     def coords_grid(ht, wd, **kwargs):
@@ -77,7 +79,33 @@ class MotionFilter:
     def check(self, images, buffer_masks=None):
         """images [V,3,H,W] fp32 RGB in [0,1] on the device; buffer_masks [V,h,w] bool (True = invalid) or None.
         Returns True when the frame is to become a keyframe (its features are then in f_fmap / f_net / f_inp)."""
-        return self.finish(self.begin(images, buffer_masks))
+        h, self._pending = getattr(self, "_pending", None), None
+        if h is None or h["images"] is not images:  # nothing (or another frame) was prefetched: the whole check now
+            return self.finish(self.begin(images, buffer_masks))
+        kept = self.finish(h)
+        side = h["stream"]
+        if kept and side is not None:
+            # the keyframe's features / context were produced on the filter's stream: the caller's stream reads them next
+            main = torch.cuda.current_stream(self.f_fmap.device)
+            main.wait_stream(side)
+            for x in (self.f_fmap, self.f_net, self.f_inp):
+                x.record_stream(main)
+        return kept
+
+    @torch.no_grad()
+    def prefetch(self, images, buffer_masks=None, stream=None):
+        """Two-stage pipeline of a streaming system: ENQUEUE the first half of `check(images, buffer_masks)` now - on
+        `stream`, a side stream that first joins the current one - and let the next `check` of these very tensors only
+        collect the score.  The filter of frame f+1 depends on nothing but the last keyframe's features, which `check(f)`
+        has already installed, so a caller that prefetches frame f+1 BEFORE it optimises keyframe f (`SLAMFrontend.run`)
+        has the filter fill the chip the frontend's single-workgroup solves and small grids leave idle.  A `check` of
+        other tensors drops the prefetched work and starts over (same result, no overlap)."""
+        if stream is not None:
+            stream.wait_stream(torch.cuda.current_stream(images.device))
+            images.record_stream(stream)
+            if buffer_masks is not None:
+                buffer_masks.record_stream(stream)
+        self._pending = self.begin(images, buffer_masks, stream=stream)
 
     @torch.no_grad()
     def begin(self, images, buffer_masks=None, stream=None):
@@ -124,6 +152,7 @@ class MotionFilter:
             self.current_frame_idx += 1
             h["event"].synchronize()
             self.last_score = float(h["score"])
+            self.scores.append(self.last_score)
             sparse = self._sparse_motion_score(h["images"].shape[0])
             # the track score is a sum over keypoints' mean displacement, not a pixel average: twice the threshold
             if self.last_score > self.thresh or sparse > self.thresh * 2:

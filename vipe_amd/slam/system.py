@@ -5,7 +5,12 @@ the rerun visualisation are outside the path):
     pass 1  every frame through the motion filter; accepted frames (and the last one) become keyframes - features and
             context into the buffer, sensor disparities from the frame's metric depth or a caller-supplied depth model,
             poses from the frame when given - then `SLAMFrontend.run()`; `SLAMBackend.run_if_necessary(5)` at
-            `frontend_backend_iters` keyframes (system.py:236-273)
+            `frontend_backend_iters` keyframes (system.py:236-273).  Scheduled as a two-stage pipeline
+            (`SLAMConfig.pipeline_filter`): the filter of frame f+1 - feature encoder + one application of the update
+            operator against the last keyframe, which depend on nothing the frontend changes - is enqueued on a side stream
+            BEFORE keyframe f is optimised on the main stream and its score is collected afterwards
+            (`MotionFilter.prefetch` / `check`); same decisions, same results, the filter fills the chip the frontend's
+            single-workgroup solves leave idle
             `SLAMBackend.run(7)`, `SLAMBackend.run(backend_iters)` (system.py:279-282)
     pass 2  every frame appended again behind the keyframes, `InnerFiller` in chunks (system.py:284-294)
             `extract_slam_map`, `SLAMOutput(trajectory = filled poses inverted, intrinsics, rig, map)` (system.py:303-316)
@@ -35,6 +40,9 @@ class SLAMConfig:
     frontend: FrontendArgs = field(default_factory=FrontendArgs)
     backend: BackendArgs = field(default_factory=BackendArgs)
     infill: InfillArgs = field(default_factory=InfillArgs)
+    # not in the reference's configuration - how THIS build schedules pass 1 (results do not depend on either):
+    pipeline_filter: bool = True   # motion filter of frame f+1 on a side stream under keyframe f's frontend step
+    pause_gc: bool = True          # keep the cyclic collector off during run() (its gen-2 sweeps cost up to 0.4 s per clip)
 
 
 @dataclass
@@ -113,6 +121,62 @@ class SLAMSystem:
             b.update_disps_sens(self.metric_depth, frame_idx=k)
         b.n_frames += 1
 
+    def _run_passes(self, frames, total):
+        import time
+        b, mf = self.buffer, self.motion_filter
+        on_gpu = torch.device(self.device).type == "cuda"
+        main = torch.cuda.current_stream(self.device) if on_gpu else None
+        side = None
+        if on_gpu and self.config.pipeline_filter:
+            side = getattr(self, "_filter_stream", None)
+            if side is None or side.device != main.device:
+                side = self._filter_stream = torch.cuda.Stream(device=self.device)
+
+        def mark(name):  # phase boundaries: three stream drains per clip
+            if on_gpu:
+                torch.cuda.synchronize(self.device)
+            self.timings[name] = time.perf_counter() - t_start
+
+        from . import factor_graph as _fg
+        work0 = dict(_fg.WORK)
+        self.timings, self.work = {}, {}
+        t_start = time.perf_counter()
+        nxt = self._precompute_features(frames[0])
+        for frame_idx, fl in enumerate(frames):  # SLAM pass 1/2 (system.py:236-273)
+            images, masks = nxt
+            if self.sparse_tracks is not None:
+                self.sparse_tracks.track_image(fl)
+            kept = mf.check(images, masks)  # collects the prefetched first half when there is one
+            is_keyframe = kept or frame_idx == total - 1
+            if is_keyframe:  # a frame the filter kept has its features and context there already
+                self._add_keyframe(frame_idx, images, masks, fl, phase=1,
+                                   reuse=(mf.f_fmap, mf.f_net, mf.f_inp) if kept else None)
+            if frame_idx + 1 < total:
+                nxt = self._precompute_features(frames[frame_idx + 1])
+                if side is not None:  # frame f+1's filter runs beside keyframe f's optimisation
+                    mf.prefetch(nxt[0], nxt[1], stream=side)
+            self.frontend.run()
+            # the backend in between corrects intrinsics / extrinsics early (system.py:269-272)
+            if is_keyframe and b.n_frames in self.config.frontend_backend_iters:
+                self.backend.run_if_necessary(5)
+        if side is not None:
+            main.wait_stream(side)
+        mark("pass1_seconds")
+        self.work["pass1"] = {k: _fg.WORK[k] - work0[k] for k in work0}
+        self.n_keyframes = int(b.n_frames)
+        self.backend.run(7)
+        gb = self.backend.run(self.config.backend.backend_iters, update_depth=False)
+        self.backend_edges = int(gb.ii.numel())
+        mark("global_ba_done_seconds")
+        self.inner_filler.set_start_idx(b.n_frames)
+        for frame_idx, fl in enumerate(frames):  # SLAM pass 2/2 (system.py:284-294)
+            images, masks = self._precompute_features(fl)
+            self._add_keyframe(frame_idx, images, masks, fl, phase=2)
+            if self.inner_filler.check() or frame_idx == total - 1:
+                self.inner_filler.compute()
+        mark("pass2_done_seconds")
+        self.work["total"] = {k: _fg.WORK[k] - work0[k] for k in work0}
+
     @torch.no_grad()
     def run(self, frames, rig=None, camera_type="pinhole"):
         """frames: sequence (length T) of per-view lists of `Frame` (a single `Frame` per step for one view)."""
@@ -126,30 +190,16 @@ class SLAMSystem:
         self.config.frontend.has_init_pose = frames[0][0].pose is not None
         self._build_components(height, width, n_views, rig, camera_type)
         b = self.buffer
-        n_keyframes = []
-        for frame_idx, fl in enumerate(frames):  # SLAM pass 1/2
-            images, masks = self._precompute_features(fl)
-            if self.sparse_tracks is not None:
-                self.sparse_tracks.track_image(fl)
-            kept = self.motion_filter.check(images, masks)
-            is_keyframe = kept or frame_idx == total - 1
-            if is_keyframe:
-                mf = self.motion_filter  # a frame the filter kept has its features and context there already
-                self._add_keyframe(frame_idx, images, masks, fl, phase=1,
-                                   reuse=(mf.f_fmap, mf.f_net, mf.f_inp) if kept else None)
-            self.frontend.run()
-            # the backend in between corrects intrinsics / extrinsics early (system.py:269-272)
-            if is_keyframe and b.n_frames in self.config.frontend_backend_iters:
-                self.backend.run_if_necessary(5)
-            n_keyframes.append(b.n_frames)
-        self.backend.run(7)
-        self.backend.run(self.config.backend.backend_iters, update_depth=False)
-        self.inner_filler.set_start_idx(b.n_frames)
-        for frame_idx, fl in enumerate(frames):  # SLAM pass 2/2
-            images, masks = self._precompute_features(fl)
-            self._add_keyframe(frame_idx, images, masks, fl, phase=2)
-            if self.inner_filler.check() or frame_idx == total - 1:
-                self.inner_filler.compute()
+        import gc
+        gc_was = self.config.pause_gc and gc.isenabled()
+        if gc_was:
+            gc.collect()
+            gc.disable()
+        try:
+            self._run_passes(frames, total)
+        finally:
+            if gc_was:
+                gc.enable()
         filled = self.inner_filler.get_result()
         if filled.poses.data.shape[0] != total:
             raise ValueError("fewer poses than frames: the frame sequence changed between the passes")

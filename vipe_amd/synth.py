@@ -220,3 +220,19 @@ def make_tracks(g, seed):
     hit = rng.random(g.weight.shape[:-1] + (1,)) < 0.04
     weight = (hit * rng.uniform(0.5, 3.0, g.weight.shape)).astype(np.float32)
     return target, weight
+
+
+def headline_update_module_inputs():
+    """the inputs / weights `make_golden.gen_headline` fed the reference UpdateModule (re-created from the seeds)"""
+    import torch
+
+    from .slam.networks import UpdateModule
+    torch.manual_seed(0)
+    um = UpdateModule().eval()
+    E, ht, wd = 4, 48, 64
+    gen = torch.Generator().manual_seed(21)
+    net = torch.randn(1, E, 128, ht, wd, generator=gen).tanh()
+    inp = torch.randn(1, E, 128, ht, wd, generator=gen).relu()
+    cor = torch.randn(1, E, 196, ht, wd, generator=gen)
+    flow = torch.randn(1, E, 4, ht, wd, generator=gen) * 4
+    return um, net, inp, cor, flow
