@@ -259,14 +259,18 @@ def make_clip_runner(device, pipelined=True, height=384, width=512):
     torch.manual_seed(0)
     dn = DroidNet()
 
-    def run_clip(seed, n_frames, filter_thresh=0.0):
-        frames = synthetic_frames(device, seed, n_frames, height, width)
+    def run_clip(seed, n_frames, keep_every=1, frames=None, release_cached_memory=False, backend_lock=None):
+        from vipe_amd.slam.motion_filter import MotionFilter
+        if frames is None:
+            frames = synthetic_frames(device, seed, n_frames, height, width)
         # keyframe_thresh = 0: the frontend never drops the second newest keyframe (random-weight flow would otherwise
         # make its distance test drop about half of them and the window would hold ~16 instead of <= 48 edges);
-        # filter_thresh = 0: every frame becomes a keyframe (the stress case); > 0: the scripted keep rate
-        cfg = SLAMConfig(buffer=n_frames + 48, filter_thresh=filter_thresh, frontend=FrontendArgs(keyframe_thresh=0.0),
-                         pipeline_filter=pipelined)
-        sysm = SLAMSystem(device, cfg, droid_net=dn)
+        # filter_thresh = 0: every frame becomes a keyframe (the stress case); keep_every = k: every k-th (scripted_filter)
+        cfg = SLAMConfig(buffer=n_frames + 48, filter_thresh=0.0, frontend=FrontendArgs(keyframe_thresh=0.0),
+                         pipeline_filter=pipelined, release_cached_memory=release_cached_memory,
+                         backend_lock_path=backend_lock)
+        sysm = SLAMSystem(device, cfg, droid_net=dn,
+                          motion_filter_cls=MotionFilter if keep_every <= 1 else scripted_filter(keep_every))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out = sysm.run(frames)
@@ -279,18 +283,28 @@ def make_clip_runner(device, pipelined=True, height=384, width=512):
                 "seconds_to_global_ba_done": tm["global_ba_done_seconds"], "seconds_to_pass2_done": tm["pass2_done_seconds"],
                 "seconds": dt, "finite": bool(torch.isfinite(traj).all()), "update_iterations": sysm.frontend.n_updates,
                 "edges_final": int(sysm.frontend.graph.ii.numel()), "backend_edges": sysm.backend_edges,
-                "filter_scores": list(sysm.motion_filter.scores), "filter_thresh": filter_thresh,
+                "filter_scores": list(sysm.motion_filter.scores), "keep_every": keep_every,
+                "backend_lock_wait_seconds": tm.get("backend_lock_wait_seconds"),
                 "work_pass1": sysm.work["pass1"], "work": sysm.work["total"]}
 
     return run_clip
 
 
-def keep_rate_threshold(scores, keep=0.25):
-    """The motion-filter threshold that keeps about `keep` of the frames of THIS synthetic clip family: the (1 - keep)
-    quantile of the dense scores a threshold-0 clip recorded (random-weight flow on seeded noise frames has no meaningful
-    scale; with a checkpoint the reference's 2.4 px applies)."""
-    s = sorted(scores)
-    return float(s[min(len(s) - 1, int(round((1.0 - keep) * len(s))))]) if s else 0.0
+def scripted_filter(keep_every):
+    """A MotionFilter whose threshold is scripted per frame so that every `keep_every`-th frame becomes a keyframe: the
+    score of a random-weight flow network has no meaningful scale (it barely depends on the frame at all), so a fixed
+    threshold keeps either everything or nothing.  ALL of the filter's work still runs for every frame (feature encoder,
+    pyramid against the last keyframe, one application of the update operator, the score's read-back); only the
+    comparison is replaced.  With a checkpoint the reference's fixed 2.4 px threshold applies."""
+    from vipe_amd.slam.motion_filter import MotionFilter
+
+    class ScriptedMotionFilter(MotionFilter):
+        def finish(self, h):
+            if self.initialized:
+                self.thresh = -1.0 if (self.current_frame_idx + 1) % keep_every == 0 else float("inf")
+            return super().finish(h)
+
+    return ScriptedMotionFilter
 
 
 def clip_figures(r):
@@ -298,7 +312,7 @@ def clip_figures(r):
             "through_global_ba": r["frames"] / r["seconds_to_global_ba_done"],
             "through_pass2": r["frames"] / r["seconds_to_pass2_done"],
             "frames": r["frames"], "keyframes": r["keyframes"], "update_iterations": r["update_iterations"],
-            "backend_edges": r["backend_edges"], "state_finite": r["finite"], "filter_thresh": r["filter_thresh"]}
+            "backend_edges": r["backend_edges"], "state_finite": r["finite"], "keep_every": r["keep_every"]}
 
 
 # SURVEY 8(d), per edge at 512x384 (P = 3072): one application of the update iteration moves 4.27 MB (lookup fused into
@@ -322,21 +336,22 @@ def video_mode(args, D):
     """BASELINE config 4 / the frames/s figure of SURVEY 8(d): `--clips` (default: one per rank) independent synthetic
     clips of `--frames` frames, clip i on rank i mod world (clip_shard.run_sharded), each ONE `SLAMSystem.run` (pass 1,
     global BA, pass 2); ONE all_gather of the padded trajectories at the end (RCCL), rank 0 writes the pose / intrinsics
-    artifacts.  `--filter-keep R` (0 < R < 1): the motion filter's threshold is scripted so that about R of the frames
-    become keyframes (default: every frame)."""
+    artifacts.  `--keep-every K`: the motion filter's decision is scripted so that every K-th frame becomes a keyframe
+    (default 1: every frame)."""
     from vipe_amd.driver import artifacts
     from vipe_amd.driver.clip_shard import ClipResult, run_sharded
 
     dev, world, rank = D.device, D.world, D.rank
     D.init()
     run_clip = make_clip_runner(dev, pipelined=not args.no_pipeline, height=args.height, width=args.width)
-    w = run_clip(seed=10_000 + rank, n_frames=24)  # untimed warm-up clip: code objects, workspaces, allocator pools
-    thresh = keep_rate_threshold(w["filter_scores"], args.filter_keep) if 0.0 < args.filter_keep < 1.0 else 0.0
+    run_clip(seed=10_000 + rank, n_frames=24)  # untimed warm-up clip: code objects, workspaces, allocator pools
+    from vipe_amd.slam.factor_graph import warm_volume_pool
+    warm_volume_pool(dev, 110)  # ... and the memory the 200-keyframe global BA will take (a worker that has run a clip before)
     n_clips = args.clips or world
     stats = []
 
     def process(cid):
-        r = run_clip(seed=cid, n_frames=args.frames, filter_thresh=thresh)
+        r = run_clip(seed=cid, n_frames=args.frames, keep_every=max(1, args.keep_every))
         stats.append(r)
         return ClipResult(cid, r["poses"], r["intrinsics"], ok=r["finite"])
 
@@ -384,21 +399,24 @@ def clip_worker_mode(args, D):
     `--out-dir`/traj_<seed>.npy for the bit-comparison against the K = 1 run)."""
     run_clip = make_clip_runner(D.device, pipelined=not args.no_pipeline, height=args.height, width=args.width)
     run_clip(seed=10_000, n_frames=24)
+    frames = synthetic_frames(D.device, args.seed, args.frames, args.height, args.width)  # resident before the start signal
     torch.cuda.synchronize()
     sys.stdout.write("READY\n")
     sys.stdout.flush()
     sys.stdin.readline()
     t0 = time.perf_counter()
-    r = run_clip(seed=args.seed, n_frames=args.frames)
+    r = run_clip(seed=args.seed, n_frames=args.frames, frames=frames, release_cached_memory=bool(args.share_card),
+                 backend_lock=args.share_card or None)
     dt = time.perf_counter() - t0
     if args.out_dir:
         np.save(os.path.join(args.out_dir, f"traj_{args.seed}.npy"), r["poses"].cpu().numpy())
     print(json.dumps({"seed": args.seed, "seconds": dt, "frames": r["frames"], "keyframes": r["keyframes"],
-                      "pass1_seconds": r["pass1_seconds"], "finite": r["finite"]}))
+                      "pass1_seconds": r["pass1_seconds"], "backend_lock_wait_seconds": r.get("backend_lock_wait_seconds"),
+                      "finite": r["finite"]}))
     sys.stdout.flush()
 
 
-def clips_per_gpu_figure(args, ks=(1, 2, 4)):
+def clips_per_gpu_figure(args, ks=(1, 2, 3, 4)):
     """K independent clips at once on ONE GPU, one fresh process per clip (clips are independent: the partitioning of
     SURVEY 8e applied below the GPU boundary).  All K workers warm up, then start together; aggregate frames/s = K x
     frames / (release -> last worker's result).  Clip `seed 0` runs at every K: its trajectory is compared with the
@@ -407,6 +425,10 @@ def clips_per_gpu_figure(args, ks=(1, 2, 4)):
     tmp = tempfile.mkdtemp(prefix="vipe_amd_kclips_")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # The global BA keeps the correlation pyramids of all its edges (33 MB per edge at 48 x 64: ~3000 edges of a
+    # 200-keyframe clip are 99 GB, VIPE_AMD_BACKEND_VOLUME_GB = 160 by default) and fills the chip by itself: the K
+    # clips' global-BA phases take turns on a file lock (SLAMConfig.backend_lock_path) and hand their blocks back to the
+    # driver afterwards (release_cached_memory); what runs concurrently is pass 1 / pass 2 of the other clips
     ref = None
     try:
         for K in ks:
@@ -414,7 +436,9 @@ def clips_per_gpu_figure(args, ks=(1, 2, 4)):
             os.makedirs(d)
             procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--mode", "clip-worker", "--seed", str(k),
                                        "--frames", str(args.frames), "--height", str(args.height), "--width", str(args.width),
-                                       "--out-dir", d], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env)
+                                       "--out-dir", d] + (["--share-card", os.path.join(d, "backend.lock")] if K > 1 else []),
+                                      stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True,
+                                      env=env)
                      for k in range(K)]
             try:
                 for pr in procs:
@@ -437,7 +461,8 @@ def clips_per_gpu_figure(args, ks=(1, 2, 4)):
             if ref is None:
                 ref = traj0
             out[str(K)] = {"frames_per_s": K * args.frames / dt, "seconds": dt,
-                           "per_clip_seconds": [r["seconds"] for r in res], "all_finite": all(r["finite"] for r in res),
+                           "per_clip_seconds": [r["seconds"] for r in res],
+                           "backend_lock_wait_seconds": [r.get("backend_lock_wait_seconds") for r in res], "all_finite": all(r["finite"] for r in res),
                            "clip0_trajectory_equal_to_K1": bool(np.array_equal(traj0, ref)),
                            "clip0_max_abs_diff_to_K1": float(np.abs(traj0 - ref).max())}
             _log(f"clips per GPU: K = {K}: {out[str(K)]['frames_per_s']:.1f} frames/s")
@@ -582,6 +607,95 @@ def conv_roofline(graph, step, device, prof_steps):
             len(rec) // max(1, prof_steps))
 
 
+def profile_counter_bytes(substr, names=("r04_summary.json", "r03_summary.json")):
+    """HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE) of the kernel whose summary key contains `substr`, from the
+    builder's rocprofv3 --pmc passes of the bench command (profiles/rNN_summary.json) -> (bytes or None, source or None)"""
+    for name in names:
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", name)))
+            row = next(v for k, v in prof.items() if substr in k and "hbm_read_MB_per_launch" in v)
+            return ((row["hbm_read_MB_per_launch"] + row.get("hbm_write_MB_per_launch", 0.0)) * 1e6,
+                    f"profiles/{name} (builder-side --pmc passes of this command, not this run)")
+        except Exception:  # noqa: BLE001
+            pass
+    return None, None
+
+
+def hbm_kernel_rooflines(graph, step, device, n=8):
+    """The three HBM-bound kernels north_star names, each as event-timed launches on this run's own data, against the
+    algorithmic bytes of SURVEY 8(d) and the 8 TB/s nominal peak; `traffic` = the counter bytes of the builder's --pmc
+    passes.  (i) fused lookup (`corr_lookup_conv_kernel`: 4-level 7x7 lookup + the correlation encoder's 1x1, launched
+    alone on the step's own pyramid / coordinates); (ii) BA accumulate (`ba_accum_mfma_kernel`, the last Gauss-Newton
+    iteration's launch inside real eager steps, bracketed by events the library records: vipe_ba_params.profile_ev0/1 -
+    it runs beside the staged gate convolution there, as in the timed region); (iii) pyramid build
+    (`corr_pyramid_build_kernel`, all E edges rebuilt into their own pool slots)."""
+    from vipe_amd.ext import droid_net_ext, slam_ext
+    E = int(graph.ii.numel())
+    P = graph.ht * graph.wd
+    eng = graph.update_op.engine(device)
+    out = {}
+
+    def entry(kernel, ms, alg_bytes, key, what):
+        traffic, src = profile_counter_bytes(key)
+        ach = alg_bytes / (ms * 1e-3) / 1e9
+        return {"kernel": kernel, "bound": "hbm", "avg_launch_ms": ms, "algorithmic_bytes": alg_bytes, "achieved": ach,
+                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": traffic,
+                "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None, "traffic_source": src, "what": what}
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b in ev:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in ev) / n
+
+    # (i) fused lookup
+    plan = graph._edge_plan()
+    corr = graph.corr.lookup_deferred(plan["io"][0])
+    if isinstance(corr, tuple):
+        c1 = torch.empty((E, graph.ht, graph.wd, 128), dtype=torch.float16, device=device)
+        ms = timed(lambda: droid_net_ext.corr_lookup_conv1x1(corr[1], corr[2], eng.corr0.packed, eng.corr0.bias, c1, act="relu",
+                                                             slots=corr[3], grid=corr[4]))
+        per_edge = P * (4 * 64 * 2 + 8 + 128 * 2)  # 8 x 8 taps x 4 levels x 2 B read + coords + 128 fp16 channels written
+        out["corr_lookup_conv_kernel"] = entry("corr_lookup_conv_kernel<true>", ms, E * per_edge, "corr_lookup_conv_kernel",
+                                               "1.573 MB taps + 0.025 MB coords + 0.786 MB written per edge")
+    # (ii) BA accumulate: the library records the two events around the last iteration's launch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); e1.record()
+    torch.cuda.synchronize()
+    slam_ext.PROFILE_EVENTS = (e0, e1)
+    try:
+        tot = 0.0
+        step()
+        for _ in range(n):
+            step()
+            torch.cuda.synchronize()
+            tot += e0.elapsed_time(e1)
+    finally:
+        slam_ext.PROFILE_EVENTS = None
+    out["ba_accum_mfma_kernel"] = entry("ba_accum_mfma_kernel<0,0>", tot / n, E * P * (2 * 8 + 4) + 48 * P * 16,
+                                        "ba_accum_mfma_kernel",
+                                        "0.061 MB per edge and iteration (target, weight, disparity) + 4 node-side maps per "
+                                        "keyframe; latency- / reduction-bound by construction (SURVEY F5)")
+    # (iii) pyramid build of all edges, into the slots they already own
+    V = graph.buffer.n_views
+    pi, qi, pj, qj = (plan[k] for k in ("pi", "qi", "pj", "qj"))
+    f1, f2 = (pi, pj) if V == 1 else (pi * V + qi, pj * V + qj)
+    fm = graph.buffer.flattened_fmaps
+    if getattr(graph.corr, "blocked", False):
+        ms = timed(lambda: droid_net_ext.corr_pyramid_build_indexed(fm, f1.contiguous(), f2.contiguous(), levels=graph.corr.pool,
+                                                                    slots=graph.corr.slots,
+                                                                    frame_range=(0, graph.buffer.n_frames * V)))
+        out["corr_pyramid_build_kernel"] = entry("corr_pyramid_build_kernel<true>", ms,
+                                                 E * (2 * 128 * P * 2 + int(P * P * 2 * (1 + 1 / 4 + 1 / 16 + 1 / 64))),
+                                                 "corr_pyramid_build_kernel", "2 x 0.786 MB maps read + 25.1 MB pyramid written per edge")
+    return out
+
+
 def capture_two_steps(step):
     """two consecutive update iterations as one HIP graph (see update_mode); None when capture is not possible"""
     side = torch.cuda.Stream()
@@ -694,7 +808,7 @@ def secondary_figures(args, device, graph, step, headline_px_rate=None):
     # filter's threshold scripted to keep about one frame in four (400 frames)
     try:
         run_clip = make_clip_runner(device)
-        w = run_clip(seed=10_000, n_frames=24)
+        run_clip(seed=10_000, n_frames=24)
         r = run_clip(seed=0, n_frames=args.frames)
         fps = clip_figures(r)
         fps.update({
@@ -706,11 +820,10 @@ def secondary_figures(args, device, graph, step, headline_px_rate=None):
                     "frame f+1 on a side stream under keyframe f's frontend step; backend.run(7) + backend.run(24); pass 2: "
                     "every frame encoded again, chunks of 16 through the InnerFiller; extract_slam_map); pass1 / "
                     "through_global_ba / through_pass2 = the same clip up to that phase boundary (SLAMSystem.timings)"})
-        thr = keep_rate_threshold(w["filter_scores"] + r["filter_scores"], 0.25)
-        r4 = run_clip(seed=1, n_frames=2 * args.frames, filter_thresh=thr)
+        r4 = run_clip(seed=1, n_frames=2 * args.frames, keep_every=4)
         fps["keep_one_in_four"] = dict(clip_figures(r4), keep_rate=r4["keyframes"] / r4["frames"],
-                                       what="the same with the filter threshold scripted to the 75 % quantile of this clip "
-                                            "family's scores: non-keyframes cost one filter check in pass 1 and one "
+                                       what="the same with the filter's decision scripted to keep every 4th frame "
+                                            "(bench.scripted_filter): non-keyframes cost one filter check in pass 1 and one "
                                             "InnerFiller slot in pass 2")
         out["frames_per_s"] = fps
     except Exception as e:  # noqa: BLE001
@@ -735,6 +848,23 @@ def secondary_figures(args, device, graph, step, headline_px_rate=None):
             out["frames_per_s"]["clips_per_gpu"] = f"failed: {type(e).__name__}: {e}"
     _log("secondary: clips per GPU done")
     return out
+
+
+def iteration_roofline(graph, E, n_kf, P, steps_per_s, device):
+    """The whole update iteration against both nominal peaks, per GPU.  `mfma_frac_executed` counts the FLOPs this build
+    EXECUTES per iteration; `mfma_frac_reference_equivalent` counts the reference's (14.03 GFLOP per edge +
+    1.37 per source node), i.e. it also credits the context-feature part of the GRU gates - conv3x3(inp; W_{z|r|q}[:,
+    128:256]), constant per edge like the correlation volume - which is computed once at add_factors and NOT per iteration."""
+    eng = graph.update_op.engine(device)
+    ref_tf = (E * GF_PER_EDGE_UPDATE + n_kf * 1.37) / 1e3
+    hoisted_tf = (E * P * eng.gates_inp.flops_per_pixel / 1e12) if getattr(graph, "pgate", None) is not None else 0.0
+    gb = E * MB_PER_EDGE_UPDATE / 1e3
+    return {"algorithmic_GB": gb, "hbm_frac": gb * steps_per_s / PEAK_HBM_GBS,
+            "executed_TFLOP": ref_tf - hoisted_tf, "mfma_frac_executed": (ref_tf - hoisted_tf) * steps_per_s / PEAK_FP16_TFLOPS,
+            "reference_equivalent_TFLOP": ref_tf, "mfma_frac_reference_equivalent": ref_tf * steps_per_s / PEAK_FP16_TFLOPS,
+            "hoisted_gate_context_TFLOP": hoisted_tf,
+            "what": "one update iteration over the measured step time, per GPU; executed = reference-equivalent minus the "
+                    "gate-context convolution hoisted out of the iteration (computed once per edge)"}
 
 
 # ---------------------------------------------------------------------------------------------- headline
@@ -858,14 +988,14 @@ def update_mode(args, D):
                          "launches_per_step": launches_per_step, "pmc": mfma_pmc},
             # the whole update iteration against both nominal peaks (SURVEY 8d totals per edge; N source nodes add
             # 1.37 GFLOP each): MFMA-bound by construction, the HBM figure is what north_star asks to see beside it
-            "iteration_roofline": {
-                "algorithmic_GB": E * MB_PER_EDGE_UPDATE / 1e3,
-                "algorithmic_TFLOP": (E * GF_PER_EDGE_UPDATE + args.keyframes * 1.37) / 1e3,
-                "hbm_frac": E * MB_PER_EDGE_UPDATE / 1e3 * args.steps / dt / 8000.0,
-                "mfma_frac": (E * GF_PER_EDGE_UPDATE + args.keyframes * 1.37) / 1e3 * args.steps / dt / 2500.0,
-                "what": "reference-equivalent work of one update iteration (incl. the gate terms this build computes once "
-                        "per edge) over the measured step time, per GPU"},
+            "iteration_roofline": iteration_roofline(graph, E, args.keyframes, g.ht * g.wd, args.steps / dt / world, device),
         }
+        if world == 1:
+            try:
+                out["roofline_hbm_kernels"] = hbm_kernel_rooflines(graph, step, device)
+            except Exception as e:  # noqa: BLE001
+                out["roofline_hbm_kernels"] = f"failed: {type(e).__name__}: {e}"
+            _log("HBM-bound kernels timed")
         if world == 1 and not args.no_secondary:
             out.update(secondary_figures(args, device, graph, step, out["value"] * E * g.ht * g.wd))
         out["cpu_baseline"] = cpu_baseline() if (world == 1 and not args.no_cpu_baseline) else None
@@ -899,10 +1029,12 @@ def main():
     ap.add_argument("--out-dir", default=None, help="video mode: keep rank 0's pose / intrinsics artifacts here")
     ap.add_argument("--no-hipgraph", action="store_true",
                     help="update mode: time eager launches instead of replaying the captured two-step HIP graph")
-    ap.add_argument("--filter-keep", type=float, default=0.0,
-                    help="video mode: script the motion filter's threshold so that about this share of the frames become "
-                         "keyframes (0: every frame)")
+    ap.add_argument("--keep-every", type=int, default=1,
+                    help="video mode: script the motion filter so that every K-th frame becomes a keyframe (1: every frame)")
     ap.add_argument("--seed", type=int, default=0, help="clip-worker mode: the clip's seed")
+    ap.add_argument("--share-card", default="",
+                    help="clip-worker mode: other clips run on this GPU - path of the lock file their global-BA phases "
+                         "take turns on (SLAMConfig.backend_lock_path, release_cached_memory)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="video mode: SLAMConfig.pipeline_filter = False (the motion filter of every frame on the main stream, "
                          "strictly before the frontend step)")

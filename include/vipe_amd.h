@@ -270,6 +270,9 @@ typedef struct {
   void* overlap_user;
   int solver_options;          /* 0 = the default kernel selection.  VIPE_BA_OPT_* bits pick the equivalent general forms, for
                                   validating the specialised kernels against them (tests/test_gpu_parity.py) */
+  void* profile_ev0;           /* optional pair of hipEvent_t (created with timing enabled by the caller): recorded on the BA */
+  void* profile_ev1;           /* stream right before / right after the accumulate kernels (ba_accum_mfma_kernel, or the walk +
+                                  Schur pair) of the LAST Gauss-Newton iteration - bench.py times that launch with them; NULL: none */
 } vipe_ba_params;
 #define VIPE_BA_OPT_ONE_CHAIN 1           /* band solve: eliminate the pose chain from one end (default: both ends at once) */
 #define VIPE_BA_OPT_GENERAL_ACCUMULATE 2  /* accumulate: the walk + Schur kernel pair for every source-frame degree */
@@ -492,6 +495,36 @@ int vipe_update_gate_state_piece(void* user, int piece, int n_pieces, void* stre
  * extra[E,384] = bias + (glo_sum[E,128] / hw) @ wT[128,384]   (all f32) */
 int vipe_glo_context(const float* d_glo_sum, const float* d_wT, const float* d_bias, float* d_extra, int E, int hw,
                      void* stream);
+
+/* Per-edge state of a factor graph in stores with spare capacity (vipe_amd/slam/factor_graph.py `_EdgeState`).  The
+ * reference concatenates - i.e. copies - every per-edge tensor in `add_factors` (factor_graph.py:147-173) and compacts each
+ * with a boolean mask in `rm_factors` (:175-202).  Both are ONE launch here, for all tensors together (at most 8 jobs):
+ *   vipe_rows_gather: for every job, dst row (dst_row0 + r) = src row idx[r] (r itself if idx is NULL), r < n_rows; a row
+ *     is n_seg segments of seg_bytes bytes every seg_pitch bytes (a channel slice of a channels-last tensor: one segment
+ *     per pixel), rows start every src_row_pitch / dst_row_pitch bytes.  All sizes multiples of 16; src != dst.
+ *   vipe_gather_nchw_to_nhwc_f16: dst[dst_row0 + r][p][dst_coff + c] = src[frame[r]][c][p] for c < C <= 128, p < P:
+ *     `buffer.nets[ii].permute(0, 2, 3, 1)` / `buffer.inps[ii]...` of the new edges' source frames, written straight into
+ *     the tail of the channels-last stores (dst rows of dst_row_pitch halves, dst_ctot channels per pixel). */
+typedef struct {
+  const void* src;
+  void* dst;
+  const int64_t* idx;
+  int64_t src_row_pitch, dst_row_pitch;
+  int64_t seg_bytes, seg_pitch;
+  int n_seg;
+  int n_rows;
+  int dst_row0;
+} vipe_rows_job;
+int vipe_rows_gather(const vipe_rows_job* jobs, int n_jobs, void* stream);
+typedef struct {
+  const void* src;          /* [N, C, P] f16 */
+  const int64_t* frame;     /* [n_rows] */
+  void* dst;
+  int64_t dst_row_pitch;    /* halves */
+  int dst_ctot, dst_coff;
+  int dst_row0;
+} vipe_nhwc_job;
+int vipe_gather_nchw_to_nhwc_f16(const vipe_nhwc_job* jobs, int n_jobs, int n_rows, int C, int P, void* stream);
 
 /* [fused] tail of FactorGraph.update (factor_graph.py:270-276): target = coords1 + delta, weight = (masked source frame
  * ? 0 : w), damping[du[k]] = eta[k].  coords1 / target / weight [E,ht,wd,2] f32, dw [E,ht,wd,4] f32, mask [E,ht,wd] bytes

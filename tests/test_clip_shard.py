@@ -293,24 +293,27 @@ def test_depth_artifacts_round_trip_and_exr_layout(tmp_path):
     assert [g_[0] for g_ in got] == [0, 2, 3, 4] and bool(torch.isnan(got[3][1]).all())
 
 
-def test_growable_store_append_and_select_match_cat_and_index():
-    """`factor_graph._Growable` (backing store of the operator's per-edge input buffer and hoisted gate context): appends
-    behind the live rows, compaction into the other buffer - always the tensor `torch.cat` / `x[idx]` would give."""
+def test_factor_graph_index_tensors_follow_the_host_mirror():
+    """`FactorGraph.ii / jj / age / ii_inac / jj_inac` are device views of the host mirror made on demand
+    (factor_graph._index_property): edits of the mirror invalidate them, an assignment from outside makes the mirror
+    follow the tensor."""
+    import numpy as np
     import torch
-    from vipe_amd.slam.factor_graph import _Growable
+    from vipe_amd.slam.factor_graph import FactorGraph
 
-    g = torch.Generator().manual_seed(0)
-    st, ref = _Growable(), None
-    assert st.view is None
-    for step in range(12):
-        x = torch.randn(int(torch.randint(1, 9, (1,), generator=g)), 3, 5, generator=g).half()
-        ref = x if ref is None else torch.cat([ref, x], 0)
-        v = st.append(x)
-        assert v.is_contiguous() and torch.equal(v, ref)
-        if step % 3 == 2:  # drop a few rows (keep order), as rm_factors does
-            keep = torch.nonzero(torch.rand(ref.shape[0], generator=g) > 0.3).reshape(-1)
-            ref = ref[keep]
-            v = st.select(keep)
-            assert v.is_contiguous() and torch.equal(v, ref)
-    v = st.select(torch.zeros(0, dtype=torch.long))  # everything removed
-    assert v.shape[0] == 0 and st.append(torch.ones(2, 3, 5).half()).shape[0] == 2
+    g = object.__new__(FactorGraph)
+    g.device = torch.device("cpu")
+    g.ii, g.jj = torch.tensor([3, 4, 5]), torch.tensor([1, 2, 3])
+    g.ii_inac = g.jj_inac = torch.zeros(0, dtype=torch.long)
+    h = g.host_edges()
+    assert h["ii"].tolist() == [3, 4, 5] and h["age"].tolist() == [0, 0, 0] and h["ii_inac"].shape == (0,)
+    h["age"] += 2
+    h["ii"] = np.array([7, 8], dtype=np.int64)
+    h["jj"] = np.array([5, 6], dtype=np.int64)
+    h["age"] = h["age"][:2]
+    g._mirror_changed("ii", "jj", "age")
+    assert g.ii.tolist() == [7, 8] and g.jj.tolist() == [5, 6] and g.age.tolist() == [2, 2]
+    assert g.ii is g.ii  # cached until the mirror changes again
+    g.ii = torch.tensor([1])  # replaced from outside: the mirror is rebuilt from the tensors
+    g.jj = torch.tensor([0])
+    assert g.host_edges()["ii"].tolist() == [1] and g.host_edges()["age"].tolist() == [0]

@@ -3456,7 +3456,11 @@ int overlap_piece(const vipe_ba_params& p, hipEvent_t ev, int piece, int n_piece
   hipStream_t side = (hipStream_t)p.overlap_stream;
   if (gated && ev) {
     if (hipStreamWaitEvent(side, ev, 0) != hipSuccess) return VIPE_EINVAL;
-    overlap_delay_kernel<<<1, 64, 0, side>>>(400);
+    // Head start of the solve (4 us at the 100 MHz wall clock).  A scheduling HINT, not a dependency: results never depend
+    // on it, only which of two ready kernels gets a free CU first.  VIPE_AMD_OVERLAP_DELAY_TICKS overrides (0: no delay
+    // kernel) - the A/B of DESIGN.md section 5.
+    static const int ticks = [] { const char* e = getenv("VIPE_AMD_OVERLAP_DELAY_TICKS"); return e ? atoi(e) : 400; }();
+    if (ticks > 0) overlap_delay_kernel<<<1, 64, 0, side>>>(ticks);
   }
   return p.overlap_fn(p.overlap_user, piece, n_pieces, p.overlap_stream);
 }
@@ -3516,11 +3520,14 @@ int run_iters(const BAArgs& a, hipStream_t s, int* pieces_done) {
     }
     // path_hint (vipe_ba_params): what the caller learnt from an earlier call with this plan; 0 launches everything
     const int hint = a.force_general ? 0 : a.p.path_hint;
+    const bool prof = a.p.profile_ev0 && a.p.profile_ev1 && it == a.p.n_iters - 1;
+    if (prof && hipEventRecord((hipEvent_t)a.p.profile_ev0, s) != hipSuccess) return VIPE_EINVAL;
     if (!(hint & 2)) ba_accum_mfma_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, accum_mfma_lds(), s>>>(a);
     if (!(hint & 1)) {
       ba_walk_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, walk_lds(), s>>>(a);
       ba_schur_kernel<F><<<dim3(SC_GRID, a.nF), TILE, 0, s>>>(a);
     }
+    if (prof && hipEventRecord((hipEvent_t)a.p.profile_ev1, s) != hipSuccess) return VIPE_EINVAL;
     if (ev && hipEventRecord(ev, s) != hipSuccess) return VIPE_EINVAL;
     if (!(hint & 8)) ba_solve_band_kernel<<<1, 2 * BAND_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)));
     if (!(hint & 16)) ba_solve_dense_kernel<<<1, DN_T, band_lds, s>>>(a, (int)(band_lds / sizeof(double)));

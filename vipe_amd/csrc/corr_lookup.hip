@@ -367,6 +367,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const bool rowok = (y1 >= 0) & (y1 < h2l);
       lo[l] = uint4v{0, 0, 0, 0};
       hi[l] = uint4v{0, 0, 0, 0};
+#ifdef VIPE_LOOKUP_SKIP_LEVEL  // measurement builds only (scratch/build_variant_src.sh): what the loads of one level cost
+      if (l == VIPE_LOOKUP_SKIP_LEVEL) continue;
+#endif
       if (BLK && l < 2) {
         // VIPE_PYRAMID_BLOCKED (include/vipe_amd.h): 16-byte piece (row y1, columns 8 c ..) of source pixel pc lives in
         // run ((x-strip) * (R >> l) + y1 / 4) of the pixel's group of 64, tile c % T, tile row y1 % 4

@@ -88,19 +88,21 @@ def update_finish(coords1, dw, mask, target, weight, eta, du, damping):
 
 
 BA_OPT_ONE_CHAIN, BA_OPT_GENERAL_ACCUMULATE = 1, 2  # VIPE_BA_OPT_* (include/vipe_amd.h)
+PROFILE_EVENTS = None  # measurement aid (bench.py): a pair of timing events every dense_ba call records around its last accumulate launch
 PLAN_REUSE = True  # False: rebuild the edge plan on every call and launch every kernel of both paths (validation aid)
 
 
 def dense_ba(poses, disps, disps_sens, intrinsics, rig, target, weight, disp_damping, pi, qi, pj, qj, di, t0, t1,
              n_iters, pose_damping, pose_ep, motion_only=False, limited_disp=False, optimize_intrinsics=False,
              optimize_rig_rotation=False, camera="pinhole", alpha=0.001, n_poses=None, want_info=False, state=None,
-             plan_key=None, overlap=None, solver_options=0):
+             plan_key=None, overlap=None, solver_options=0, profile_events=None):
     """Live dense BA (GraphBuffer.bundle_adjustment, buffer.py:373-525), IN PLACE on poses / disps / intrinsics.
 
     `overlap` = (stream address, vipe_overlap_fn address, user address) or None: independent work of the caller that the
     library enqueues on that stream in max(n_iters, 1) pieces, each behind the start of a Gauss-Newton iteration's
     single-workgroup solve (include/vipe_amd.h, vipe_overlap_fn).  `solver_options`: VIPE_BA_OPT_* bits (BA_OPT_ONE_CHAIN,
     BA_OPT_GENERAL_ACCUMULATE) - the general forms of the specialised kernels, for validating one against the other.
+    `profile_events`: see vipe_ba_params.profile_ev0 (the last iteration's accumulate launch between two events).
 
     poses [>=n_poses,7]; disps, disps_sens, disp_damping [>=n_poses*V,ht,wd] (flattened views);
     target, weight [M,ht*wd,2]; pi..di [M] int64.  `n_poses` bounds the pose/frame indices that occur
@@ -121,6 +123,10 @@ def dense_ba(poses, disps, disps_sens, intrinsics, rig, target, weight, disp_dam
                  weight_scale=0.001, intr_factor=8.0, reuse_plan=0, path_hint=0, solver_options=int(solver_options))
     if overlap is not None:
         p.overlap_stream, p.overlap_fn, p.overlap_user = overlap
+    if profile_events is None:
+        profile_events = PROFILE_EVENTS
+    if profile_events is not None:  # two torch.cuda.Event(enable_timing=True), each recorded once before (so that they exist)
+        p.profile_ev0, p.profile_ev1 = (int(e.cuda_event) for e in profile_events)
     L = lib()
     nbytes = L.vipe_dense_ba_workspace_bytes(ctypes.byref(p))
     require(nbytes > 0, "bad BA parameters")

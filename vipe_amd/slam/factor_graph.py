@@ -6,12 +6,13 @@ correlation lookup -> flow-update operator -> dense BA.  Per iteration it issues
 scatter_mean's index.max(), every _tmult_mat_elements and the CPU spsolve).
 """
 
+import ctypes
 import os
 
 import numpy as np
 import torch
 
-from .._lib import upload, upload_many
+from .._lib import check, lib, parse_struct, stream_ptr, upload, upload_many
 from ..ext import slam_ext
 from .networks import AltCorrBlock, CorrBlock, CorrPool
 
@@ -20,45 +21,147 @@ from .networks import AltCorrBlock, CorrBlock, CorrPool
 WORK = {"edge_updates": 0, "pyramids_built": 0}
 
 
-class _Growable:
-    """Per-edge state with spare capacity: `append` writes the new rows behind the live ones (the reference concatenates,
-    i.e. copies the whole tensor, on every `add_factors`: factor_graph.py:160-170 - 4.4 MB per edge for the operator's
-    input buffer and the hoisted gate context), `select` gathers the surviving rows into the OTHER of two backing buffers.
-    `view` is what the rest of the code sees: an ordinary contiguous tensor [n, ...]."""
+def warm_volume_pool(device, gigabytes=None):
+    """Map the memory the first global BA of this process will ask for (`update_batch` keeps up to
+    VIPE_AMD_BACKEND_VOLUME_GB of correlation pyramids) into torch's caching allocator NOW: a fresh process pays the
+    driver ~0.9 s for the first 100 GB it maps (measured: the same 200-keyframe clip runs its two backend passes in
+    1.7 s in a process that has held the memory before, 2.6 s in one that has not).  A long-lived worker that processes
+    clip after clip is warm after its first clip; a benchmark's untimed warm-up should leave the process in that state."""
+    if torch.device(device).type != "cuda":
+        return 0
+    want = float(gigabytes if gigabytes is not None else os.environ.get("VIPE_AMD_BACKEND_VOLUME_GB", "160")) * 2**30
+    free, _ = torch.cuda.mem_get_info(device)
+    n = int(min(want, 0.85 * free))
+    if n <= 0:
+        return 0
+    x = torch.empty(n, dtype=torch.uint8, device=device)
+    x[::1 << 21].zero_()  # touch every 2 MiB page
+    del x
+    return n
 
-    def __init__(self):
-        self.bufs = [None, None]
-        self.cur = 0
-        self.n = 0
 
-    @property
-    def view(self):
-        return None if self.bufs[self.cur] is None else self.bufs[self.cur][:self.n]
+RowsJob = parse_struct("vipe_rows_job")   # include/vipe_amd.h
+NhwcJob = parse_struct("vipe_nhwc_job")
 
-    def _room(self, which, rows, like):
-        b = self.bufs[which]
-        if b is None or b.shape[0] < rows or b.shape[1:] != like.shape[1:] or b.dtype != like.dtype or b.device != like.device:
-            # 25 % spare: the frontend's window oscillates by a few edges; the backend's graphs (tens of GB) must not double
-            nb = torch.empty((max(rows + rows // 4, 64),) + tuple(like.shape[1:]), dtype=like.dtype, device=like.device)
-            if b is not None and which == self.cur and self.n:
-                nb[:self.n] = b[:self.n]
-            self.bufs[which] = nb
-        return self.bufs[which]
 
-    def append(self, x):
-        b = self._room(self.cur, self.n + x.shape[0], x)
-        b[self.n:self.n + x.shape[0]] = x
-        self.n += x.shape[0]
-        return self.view
+class _EdgeStores:
+    """The big per-edge tensors of an incremental graph - hidden state `net` [n,h,w,128], operator input `xbuf`
+    [n,h,w,320] (context features in channels [0,128), the rest scratch), hoisted gate context `pgate` [n,h,w,384] - in
+    backing buffers with spare capacity, two banks each.  The reference concatenates (copies the whole tensor) on every
+    `add_factors` and compacts with boolean masks on every `rm_factors` (factor_graph.py:160-170, 190-201: 4.4 MB per
+    edge); here `append` is ONE launch that reads the new edges' source frames from the keyframe buffer and writes them
+    channels-last behind the live rows (`vipe_gather_nchw_to_nhwc_f16`), and `compact` is ONE launch that moves the
+    surviving rows of all tensors (and whatever small per-edge arrays the caller adds) into the other bank
+    (`vipe_rows_gather`).  The operator ping-pongs `net` between its two banks (`net_spare`)."""
 
-    def select(self, idx):
-        src = self.view
-        other = self.cur ^ 1
-        dst = self._room(other, max(int(idx.shape[0]), 1), src)
-        if idx.shape[0]:
-            torch.index_select(src, 0, idx, out=dst[:idx.shape[0]])
-        self.cur, self.n = other, int(idx.shape[0])
-        return self.view
+    def __init__(self, ht, wd, device, with_pgate):
+        self.ht, self.wd, self.device, self.with_pgate = ht, wd, device, with_pgate
+        self.cap = 0
+        self.net, self.xb, self.pg = [None, None], [None, None], [None, None]
+        self.cur = 0  # bank of xbuf / pgate
+
+    def _alloc(self, cap):
+        f16 = dict(dtype=torch.float16, device=self.device)
+        shp = (cap, self.ht, self.wd)
+        return ([torch.empty(shp + (128,), **f16) for _ in range(2)], [torch.empty(shp + (320,), **f16) for _ in range(2)],
+                [torch.empty(shp + (384,), **f16) if self.with_pgate else None for _ in range(2)])
+
+    def bank_of(self, net_n):
+        """which net bank `net_n` is a view of (None: a tensor from outside)"""
+        if net_n is not None and self.net[0] is not None:
+            for k in (0, 1):
+                if net_n.data_ptr() == self.net[k].data_ptr():
+                    return k
+        return None
+
+    def reserve(self, rows, net_n, n_live):
+        """room for `rows` rows; -> net_n (re-homed when the stores grew or `net_n` came from outside)"""
+        grow = rows > self.cap
+        if grow:
+            cap = max(rows + rows // 4, 64)  # 25 % spare: the frontend's window oscillates by a few edges
+            net, xb, pg = self._alloc(cap)
+            if n_live and self.cap:
+                xb[0][:n_live, ..., :128] = self.xb[self.cur][:n_live, ..., :128]
+                if self.with_pgate:
+                    pg[0][:n_live] = self.pg[self.cur][:n_live]
+            old = net_n
+            self.net, self.xb, self.pg, self.cur, self.cap = net, xb, pg, 0, cap
+            if n_live and old is not None:
+                self.net[0][:n_live] = old
+                return self.net[0][:n_live]
+            return None
+        if n_live and self.bank_of(net_n) is None:  # assigned from outside (tests restore a saved state): adopt it
+            self.net[0][:n_live] = net_n
+            return self.net[0][:n_live]
+        return net_n
+
+    def net_spare(self, net_n):
+        k = self.bank_of(net_n)
+        return None if k is None else self.net[1 - k][:net_n.shape[0]]
+
+    def append(self, buffer_nets, buffer_inps, frames, net_n, n_live):
+        """rows [n_live, n_live + k): hidden state and context features of the frames `frames` [k] int64 (device) of the
+        keyframe buffer's flattened [N,128,h*w] maps -> (net_n, xbuf, new xbuf rows)"""
+        k = int(frames.shape[0])
+        net_n = self.reserve(n_live + k, net_n, n_live)
+        nb = 0 if net_n is None else self.bank_of(net_n)
+        P = self.ht * self.wd
+        jobs = (NhwcJob * 2)()
+        for j, (src, dst, ctot) in enumerate(((buffer_nets, self.net[nb], 128), (buffer_inps, self.xb[self.cur], 320))):
+            jobs[j].src, jobs[j].frame, jobs[j].dst = src.data_ptr(), frames.data_ptr(), dst.data_ptr()
+            jobs[j].dst_row_pitch, jobs[j].dst_ctot, jobs[j].dst_coff, jobs[j].dst_row0 = P * ctot, ctot, 0, n_live
+        check(lib().vipe_gather_nchw_to_nhwc_f16(ctypes.addressof(jobs), 2, k, 128, P, stream_ptr(frames)), "gather_nchw_to_nhwc")
+        n = n_live + k
+        return self.net[nb][:n], self.xb[self.cur][:n], self.xb[self.cur][n_live:n]
+
+    def compact(self, keep, n_keep, net_n, extra_jobs=()):
+        """rows `keep` [n_keep] int64 (device, ascending) of every store -> the other bank, in ONE launch together with
+        `extra_jobs` = (src, dst, idx, n_rows, row_bytes, dst_row0) of small per-edge arrays; -> (net_n, xbuf, pgate)"""
+        P = self.ht * self.wd
+        nb = self.bank_of(net_n)
+        jobs = (RowsJob * 8)()
+        n = 0
+
+        def job(src, dst, idx, n_rows, row_bytes, dst_row0=0, seg=None):
+            nonlocal n
+            j = jobs[n]
+            j.src, j.dst, j.idx = src.data_ptr(), dst.data_ptr(), (idx.data_ptr() if idx is not None else None)
+            j.src_row_pitch = j.dst_row_pitch = row_bytes
+            j.seg_bytes, j.seg_pitch, j.n_seg = seg if seg is not None else (row_bytes, row_bytes, 1)
+            j.n_rows, j.dst_row0 = int(n_rows), int(dst_row0)
+            n += 1
+
+        if n_keep:
+            job(self.net[nb], self.net[1 - nb], keep, n_keep, P * 128 * 2)
+            job(self.xb[self.cur], self.xb[1 - self.cur], keep, n_keep, P * 320 * 2, seg=(256, 640, P))  # context features only
+            if self.with_pgate:
+                job(self.pg[self.cur], self.pg[1 - self.cur], keep, n_keep, P * 384 * 2)
+        for e in extra_jobs:
+            job(*e)
+        check(lib().vipe_rows_gather(ctypes.addressof(jobs), n, stream_ptr(keep)), "rows_gather")
+        self.cur ^= 1
+        return (self.net[1 - nb][:n_keep], self.xb[self.cur][:n_keep], self.pg[self.cur][:n_keep] if self.with_pgate else None)
+
+
+def _index_property(name):
+    """Device copy of one integer array of the edge bookkeeping (`ii`, `jj`, `age`, `ii_inac`, `jj_inac`): the host mirror
+    (`host_edges`) is what this class works on; the device tensor the reference keeps (factor_graph.py:66-75) is made from
+    it when somebody reads the attribute, and an assignment from outside makes the mirror follow the tensor."""
+    def get(self):
+        dev = self.__dict__.setdefault("_dev", {})
+        t = dev.get(name)
+        if t is None:
+            h = self.__dict__.get("_h")
+            if h is None:
+                return None
+            t = dev[name] = upload(h[name], self.device)
+        return t
+
+    def put(self, value):
+        self.__dict__.setdefault("_dev", {})[name] = value
+        self.__dict__["_h"] = None  # replaced from outside: the mirror is rebuilt from the tensors on next use
+
+    return property(get, put)
 
 
 class FactorGraph:
@@ -71,17 +174,18 @@ class FactorGraph:
         self.cross_view = cross_view and buffer.n_views > 1  # factor_graph.py:62
         ht, wd = buffer.height // 8, buffer.width // 8
         self.ht, self.wd = ht, wd
-        self.ii = torch.as_tensor([], dtype=torch.long, device=device)
-        self.jj = torch.as_tensor([], dtype=torch.long, device=device)
-        self._age = torch.as_tensor([], dtype=torch.long, device=device)
-        self._age_lag = 0
+        # integer edge bookkeeping: the host mirror is authoritative, `ii` / `jj` / `age` / `ii_inac` / `jj_inac` are device
+        # views of it made on demand (_index_property)
+        z = np.zeros(0, dtype=np.int64)
+        self._h = {"ii": z, "jj": z.copy(), "age": z.copy(), "ii_inac": z.copy(), "jj_inac": z.copy()}
+        self._dev = {}
         self.damping = 1e-6 * torch.ones_like(buffer.flattened_disps)  # factor_graph.py:76
         self.target = torch.zeros([1, 0, ht, wd, 2], device=device, dtype=torch.float)
         self.weight = torch.zeros([1, 0, ht, wd, 2], device=device, dtype=torch.float)
         # channels-last state of the flow-update operator: hidden state [E,h,w,128] and [inp | corr | flow] features
         self.corr, self.net_n, self.xbuf = None, None, None
         self.pgate = None  # [E,h,w,384]: context-feature part of the GRU gates, computed once per edge
-        self._xbuf_store, self._pgate_store = _Growable(), _Growable()  # backing stores of xbuf / pgate (spare capacity)
+        self._stores = None  # _EdgeStores: backing buffers of net_n / xbuf / pgate (incremental graphs)
         # hidden-state part of the gates for the CURRENT net_n (UpdateEngine.hidden_gate_state), computed on a second
         # stream in the shadow of the previous iteration's BA; None whenever net_n / the edge set changed since
         self._gate_state = None
@@ -93,39 +197,39 @@ class FactorGraph:
         self.gate_overlap_mode = "gated"
         self.gate_overlap_share = 0.5
         self.gate_overlap_fractions = [0.4, 0.4, 0.2]
-        self.ii_inac = torch.as_tensor([], dtype=torch.long, device=device)
-        self.jj_inac = torch.as_tensor([], dtype=torch.long, device=device)
         self.target_inac = torch.zeros([1, 0, ht, wd, 2], device=device, dtype=torch.float)
         self.weight_inac = torch.zeros([1, 0, ht, wd, 2], device=device, dtype=torch.float)
         self._plan = None
         self._plan_serial = 0   # counts rebuilt edge plans: (serial, kind) identifies the index arrays handed to the BA
         self._ba_state = {}     # private BA workspace + the key of the plan it holds (slam_ext.dense_ba)
-        self._h = None  # host mirror of the integer edge state (ii, jj, age, ii_inac, jj_inac), see host_edges()
 
-    @property
-    def age(self):
-        """factor_graph.py:72 - edge ages on the device.  `update` only counts its calls (the host mirror is what the
-        scheduling logic reads); the device tensor catches up when somebody looks at it."""
-        if self._age_lag:
-            self._age += self._age_lag
-            self._age_lag = 0
-        return self._age
+    ii = _index_property("ii")
+    jj = _index_property("jj")
+    age = _index_property("age")  # factor_graph.py:72
+    ii_inac = _index_property("ii_inac")
+    jj_inac = _index_property("jj_inac")
 
-    @age.setter
-    def age(self, value):
-        self._age, self._age_lag = value, 0
+    def _mirror_changed(self, *names):
+        """the host mirror's arrays `names` were edited: their device copies are stale"""
+        dev = self.__dict__.setdefault("_dev", {})
+        for n in names:
+            dev[n] = None
 
     def host_edges(self):
-        """Host-side copy of the integer edge bookkeeping {ii, jj, age, ii_inac, jj_inac} (numpy int64).  Every method
-        of this class that changes the edge lists updates the mirror alongside the device tensors, so the scheduling
-        logic around the update iteration (duplicate filtering, suppression, age eviction, plan building) reads no
-        device memory back.  If the tensors were replaced from outside, the mirror is rebuilt from them (one read-back)."""
-        h = getattr(self, "_h", None)
-        age = getattr(self, "age", None)
-        if (h is None or h["ii"].shape[0] != self.ii.shape[0] or h["ii_inac"].shape[0] != self.ii_inac.shape[0]
-                or (age is not None and h["age"].shape[0] != age.shape[0])):
-            h = {k: getattr(self, k).detach().cpu().numpy().astype(np.int64).copy() for k in ("ii", "jj", "ii_inac", "jj_inac")}
-            h["age"] = age.detach().cpu().numpy().astype(np.int64).copy() if age is not None else np.zeros_like(h["ii"])
+        """Host-side copy of the integer edge bookkeeping {ii, jj, age, ii_inac, jj_inac} (numpy int64) - what every method
+        of this class works on, so that the scheduling logic around the update iteration (duplicate filtering, suppression,
+        age eviction, plan building) reads no device memory back and issues no index arithmetic on the device.  If the
+        attributes were assigned from outside, the mirror is rebuilt from those tensors (one read-back)."""
+        h = self.__dict__.get("_h")
+        if h is None:
+            dev = self.__dict__.setdefault("_dev", {})
+            h = {}
+            for k in ("ii", "jj", "ii_inac", "jj_inac"):
+                t = dev.get(k)
+                h[k] = np.zeros(0, dtype=np.int64) if t is None else t.detach().cpu().numpy().astype(np.int64).copy()
+            t = dev.get("age")
+            h["age"] = (t.detach().cpu().numpy().astype(np.int64).copy() if t is not None and t.shape[0] == h["ii"].shape[0]
+                        else np.zeros_like(h["ii"]))
             self._h = h
         return h
 
@@ -154,7 +258,7 @@ class FactorGraph:
         ii_h, jj_h = self._filter_repeated_edges(ii_h, jj_h)
         if ii_h.shape[0] == 0:
             return
-        if (self.max_factors > 0 and self.ii.shape[0] + ii_h.shape[0] > self.max_factors and self.corr is not None
+        if (self.max_factors > 0 and self.host_edges()["ii"].shape[0] + ii_h.shape[0] > self.max_factors and self.corr is not None
                 and remove):
             # factor_graph.py:136-139 (the reference's `arange[argsort(age)]` is the permutation itself; torch's sort
             # leaves the order of equal ages unspecified - the stable order is used here)
@@ -162,35 +266,39 @@ class FactorGraph:
             self.rm_factors(ix >= self.max_factors - ii_h.shape[0], store=True)
         ii, jj = upload_many([ii_h, jj_h], self.device)
         pi, qi, _, pj, qj, _ = self.buffer.expand_edge_multiview(ii, jj)
+        V = self.buffer.n_views
+        n_live = 0 if self.net_n is None else int(self.net_n.shape[0])
+        f1, f2 = (pi, pj) if V == 1 else (pi * V + qi, pj * V + qj)  # one view: frame index = pose index
         if self.incremental:
             if self.corr is None:
                 self.corr = CorrPool(capacity=max(64, self.max_factors + 16))
-            V = self.buffer.n_views
             lo, hi = int(min(ii_h.min(), jj_h.min())), int(max(ii_h.max(), jj_h.max()))
-            f1, f2 = (pi, pj) if V == 1 else (pi * V + qi, pj * V + qj)  # one view: frame index = pose index
             # a cross-view self edge (i, i) is re-targeted to cross_view_idx[i, v] by expand_edge_multiview - after an
             # adaptive cross-view pass that may be ANY keyframe of the buffer: the host (ii, jj) do not bound the frames
             rng = (0, self.buffer.n_frames * V) if (self.cross_view and V > 1) else (lo * V, (hi + 1) * V)
             self.corr.add_edges(self.buffer.flattened_fmaps, f1, f2, frame_range=rng)
             WORK["pyramids_built"] += int(pi.shape[0])
-            xb = torch.zeros((ii.shape[0] * self.buffer.n_views, self.ht, self.wd, 320), dtype=torch.half,
-                             device=self.device)
-            xb[..., 0:128] = self.buffer.inps[pi, qi].permute(0, 2, 3, 1)
-            self.xbuf = self._xbuf_store.append(xb)
             eng = self.update_op.engine(self.device)
-            if eng.supports_gate_split(self.ht, self.wd):
-                self.pgate = self._pgate_store.append(eng.gate_context(xb))
+            if self._stores is None:
+                self._stores = _EdgeStores(self.ht, self.wd, self.device, eng.supports_gate_split(self.ht, self.wd))
+            # hidden state and context features of the new edges' source frames, straight from the keyframe buffer into
+            # the stores' tails (one launch; the reference gathers, permutes and concatenates: factor_graph.py:147-170)
+            self.net_n, self.xbuf, xb_new = self._stores.append(self.buffer.flattened_nets, self.buffer.flattened_inps,
+                                                                f1.contiguous(), self.net_n, n_live)
+            if self._stores.with_pgate:
+                pg = self._stores.pg[self._stores.cur]
+                eng.gate_context(xb_new, out=pg[n_live:n_live + xb_new.shape[0]])
+                self.pgate = pg[:n_live + xb_new.shape[0]]
+        else:
+            net = self.buffer.nets[pi, qi].permute(0, 2, 3, 1).contiguous()
+            self.net_n = net if self.net_n is None else torch.cat([self.net_n, net], 0)
         target, _ = self.buffer.reproject_dense_disp(ii, jj)
         target = target[None]
         h = self.host_edges()
         self._edge_set().update(zip(ii_h.tolist(), jj_h.tolist()))
         h["ii"], h["jj"] = np.concatenate([h["ii"], ii_h]), np.concatenate([h["jj"], jj_h])
         h["age"] = np.concatenate([h["age"], np.zeros_like(ii_h)])
-        self.ii = torch.cat([self.ii, ii], 0)
-        self.jj = torch.cat([self.jj, jj], 0)
-        self.age = torch.cat([self.age, torch.zeros_like(ii)], 0)
-        net = self.buffer.nets[pi, qi].permute(0, 2, 3, 1).contiguous()
-        self.net_n = net if self.net_n is None else torch.cat([self.net_n, net], 0)
+        self._mirror_changed("ii", "jj", "age")
         self._gate_state = None
         self.target = torch.cat([self.target, target], 1)
         self.weight = torch.cat([self.weight, torch.zeros_like(target)], 1)
@@ -198,40 +306,59 @@ class FactorGraph:
 
     @torch.no_grad()
     def rm_factors(self, mask, store=False):
-        """factor_graph.py:175-202.  The mask is read back ONCE; every tensor is then compacted with the same index
-        vectors (boolean-mask indexing would synchronise per tensor)."""
+        """factor_graph.py:175-202.  The mask is read ONCE (the callers of this package pass host arrays); the integer
+        bookkeeping is edited on the host mirror, and the surviving rows of every per-edge tensor - hidden state, context
+        features, gate context, targets, weights - and the rows that go to the inactive store move in ONE launch
+        (`_EdgeStores.compact`; the reference indexes each tensor with the boolean mask, a sync per tensor)."""
         m = (mask.detach().cpu().numpy() if torch.is_tensor(mask) else np.asarray(mask)).astype(bool)
+        if not m.any():
+            return
         h = self.host_edges()
         if store:
             h["ii_inac"] = np.concatenate([h["ii_inac"], h["ii"][m]])
             h["jj_inac"] = np.concatenate([h["jj_inac"], h["jj"][m]])
+            self._mirror_changed("ii_inac", "jj_inac")
         elif getattr(self, "_have", None) is not None:
             self._have.difference_update(zip(h["ii"][m].tolist(), h["jj"][m].tolist()))
         h["ii"], h["jj"], h["age"] = h["ii"][~m], h["jj"][~m], h["age"][~m]
+        self._mirror_changed("ii", "jj", "age")
         V = self.buffer.n_views
-        keep, drop = upload_many([np.flatnonzero(~m), np.flatnonzero(m)], self.device)
-        views = torch.arange(V, device=self.device)
-        keep_x = (keep[:, None] * V + views).view(-1) if V > 1 else keep
-        drop_x = (drop[:, None] * V + views).view(-1) if V > 1 else drop
-        keep_np = np.flatnonzero(~m)
+        keep_np, drop_np = np.flatnonzero(~m), np.flatnonzero(m)
         keep_x_np = (keep_np[:, None] * V + np.arange(V)).reshape(-1) if V > 1 else keep_np
-        if store:
-            self.ii_inac = torch.cat([self.ii_inac, self.ii[drop]], 0)
-            self.jj_inac = torch.cat([self.jj_inac, self.jj[drop]], 0)
-            self._append_inactive(self.target[:, drop_x], self.weight[:, drop_x])
-        self.ii, self.jj, self.age = self.ii[keep], self.jj[keep], self.age[keep]
+        drop_x_np = (drop_np[:, None] * V + np.arange(V)).reshape(-1) if V > 1 else drop_np
+        keep_x, drop_x = upload_many([keep_x_np, drop_x_np], self.device)
+        nk, nd = int(keep_x_np.shape[0]), int(drop_x_np.shape[0])
         if self.corr is not None:
             self.corr = self.corr[keep_x_np]  # host-side index: the pool only edits its slot vector
         self._gate_state = None
-        if self.net_n is not None:
-            self.net_n = self.net_n[keep_x]
-        if self.xbuf is not None:
-            self.xbuf = self._xbuf_store.select(keep_x)
-        if self.pgate is not None:
-            self.pgate = self._pgate_store.select(keep_x)
-        self.target = self.target[:, keep_x]
-        self.weight = self.weight[:, keep_x]
         self._plan = None
+        if not self.target.is_contiguous() or not self.weight.is_contiguous():
+            self.target, self.weight = self.target.contiguous(), self.weight.contiguous()
+        row = int(self.target.shape[2] * self.target.shape[3] * 2 * 4)  # one edge's [h, w, 2] f32
+        new_t = torch.empty((1, nk) + tuple(self.target.shape[2:]), dtype=self.target.dtype, device=self.device)
+        new_w = torch.empty_like(new_t)
+        extra = [(self.target, new_t, keep_x, nk, row, 0), (self.weight, new_w, keep_x, nk, row, 0)] if nk else []
+        if store and nd:
+            ti, wi, n0 = self._inactive_room(nd)
+            extra += [(self.target, ti, drop_x, nd, row, n0), (self.weight, wi, drop_x, nd, row, n0)]
+        st = self._stores
+        if st is not None and self.net_n is not None and st.bank_of(self.net_n) is None and self.net_n.shape[0]:
+            self.net_n = st.reserve(self.net_n.shape[0], self.net_n, self.net_n.shape[0])  # assigned from outside: adopt
+        if st is not None and self.net_n is not None and st.bank_of(self.net_n) is not None:
+            self.net_n, self.xbuf, pg = st.compact(keep_x, nk, self.net_n, extra)
+            if self.pgate is not None:
+                self.pgate = pg
+        else:  # non-incremental graphs (the backend's): no stores, the small arrays in one launch all the same
+            if self.net_n is not None:
+                self.net_n = self.net_n[keep_x]
+            if extra:
+                jobs = (RowsJob * len(extra))()
+                for j, (src, dst, idx, n_rows, rb, r0) in zip(jobs, extra):
+                    j.src, j.dst, j.idx = src.data_ptr(), dst.data_ptr(), idx.data_ptr()
+                    j.src_row_pitch = j.dst_row_pitch = j.seg_bytes = j.seg_pitch = rb
+                    j.n_seg, j.n_rows, j.dst_row0 = 1, int(n_rows), int(r0)
+                check(lib().vipe_rows_gather(ctypes.addressof(jobs), len(extra), stream_ptr(keep_x)), "rows_gather")
+        self.target, self.weight = new_t, new_w
 
     def add_neighborhood_factors(self, t0, t1, r=3):
         """factor_graph.py:396-409 (mono: c = 0)."""
@@ -318,23 +445,20 @@ class FactorGraph:
         self._have = None  # frame indices shift: the edge set is rebuilt on next use
         h = self.host_edges()
         m = (h["ii_inac"] == ix) | (h["jj_inac"] == ix)
-        self.ii_inac = self.ii_inac - (self.ii_inac >= ix).long()
-        self.jj_inac = self.jj_inac - (self.jj_inac >= ix).long()
         h["ii_inac"] = h["ii_inac"] - (h["ii_inac"] >= ix)
         h["jj_inac"] = h["jj_inac"] - (h["jj_inac"] >= ix)
         if m.any():
             V = self.buffer.n_views
             keep = upload(np.flatnonzero(~m), self.device)
             keep_x = (keep[:, None] * V + torch.arange(V, device=self.device)).view(-1) if V > 1 else keep
-            self.ii_inac, self.jj_inac = self.ii_inac[keep], self.jj_inac[keep]
             self.target_inac = self.target_inac[:, keep_x]
             self.weight_inac = self.weight_inac[:, keep_x]
             h["ii_inac"], h["jj_inac"] = h["ii_inac"][~m], h["jj_inac"][~m]
         m = (h["ii"] == ix) | (h["jj"] == ix)
-        self.ii = self.ii - (self.ii >= ix).long()
-        self.jj = self.jj - (self.jj >= ix).long()
         h["ii"] = h["ii"] - (h["ii"] >= ix)
         h["jj"] = h["jj"] - (h["jj"] >= ix)
+        self._mirror_changed("ii", "jj", "ii_inac", "jj_inac")
+        self._plan = None
         self.rm_factors(m, store=False)
 
     def get_edges_np(self):
@@ -354,7 +478,11 @@ class FactorGraph:
         return None if self.xbuf is None else self.xbuf[..., 0:128].permute(0, 3, 1, 2)[None]
 
     def _net_spare(self):
-        """Ping-pong buffer for the new hidden state (the Q epilogue cannot write in place: 3x3 halo)."""
+        """Ping-pong buffer for the new hidden state (the Q epilogue cannot write in place: 3x3 halo): the other bank of
+        the edge stores, or - for graphs without stores and states assigned from outside - a private tensor."""
+        sp = self._stores.net_spare(self.net_n) if self._stores is not None else None
+        if sp is not None:
+            return sp
         sp = getattr(self, "_spare", None)
         if sp is None or sp.shape != self.net_n.shape or sp.data_ptr() == self.net_n.data_ptr():
             sp = torch.empty_like(self.net_n)
@@ -390,10 +518,11 @@ class FactorGraph:
                               t1=int(max(h["ii"].max(), h["jj"].max()) + 1))
         return self._plan
 
-    def _append_inactive(self, t_new, w_new):
+    def _inactive_room(self, k):
         """target_inac / weight_inac grow for the whole video (factor_graph.py:184-189 concatenates, i.e. copies the
-        whole store, on every eviction): append into buffers with spare capacity instead; the attributes stay views."""
-        n, k = self.target_inac.shape[1], t_new.shape[1]
+        whole store, on every eviction): backing buffers with spare capacity; -> (target buffer, weight buffer, first
+        free row) with room for k more rows, the attributes re-pointed to the n + k rows (the caller fills the new ones)."""
+        n = self.target_inac.shape[1]
         cap = getattr(self, "_inac_cap", None)
         if cap is None or cap[0].shape[1] < n + k or cap[0].data_ptr() != self.target_inac.data_ptr():
             size = max(2 * (n + k), 256)
@@ -402,9 +531,8 @@ class FactorGraph:
             cap[0][:, :n] = self.target_inac
             cap[1][:, :n] = self.weight_inac
             self._inac_cap = cap
-        cap[0][:, n:n + k] = t_new
-        cap[1][:, n:n + k] = w_new
         self.target_inac, self.weight_inac = cap[0][:, :n + k], cap[1][:, :n + k]
+        return cap[0], cap[1], n
 
     def _shift_plan(self, plan5, base):
         """(pi, qi, di, pj, qj) -> the same relative to keyframe `base` (+ base), see GraphBuffer.bundle_adjustment"""
@@ -485,11 +613,11 @@ class FactorGraph:
             if key not in P:
                 h = self.host_edges()
                 sel_h = np.flatnonzero((h["ii_inac"] >= t0 - 3) & (h["jj_inac"] >= t0 - 3))  # host mirror: no read-back
-                sel = upload(sel_h, self.device)
-                ii = torch.cat([self.ii_inac[sel], self.ii], 0)
-                jj = torch.cat([self.jj_inac[sel], self.jj], 0)
+                # [selected inactive | active] index vectors straight from the host mirror: one staged copy
                 V = buf.n_views
-                sel_exp = sel if V == 1 else (sel.view(-1, 1) * V + torch.arange(V, device=self.device).view(1, -1)).view(-1)
+                sel_x = sel_h if V == 1 else (sel_h[:, None] * V + np.arange(V)).reshape(-1)
+                ii, jj, sel_exp = upload_many([np.concatenate([h["ii_inac"][sel_h], h["ii"]]),
+                                               np.concatenate([h["jj_inac"][sel_h], h["jj"]]), sel_x], self.device)
                 base = int(min(h["ii"].min(), h["jj"].min(), *(h[k][sel_h].min() for k in ("ii_inac", "jj_inac") if sel_h.size)))
                 P[key] = (ii, jj, sel_exp, self._shift_plan(buf.expand_edge_multiview(ii, jj)[:5], base))
             ii, jj, sel_exp, plan = P[key]
@@ -526,9 +654,8 @@ class FactorGraph:
         if overlap:
             main.wait_stream(self._side)
             self._gate_state = gate_state
-        self._age_lag += 1
-        if getattr(self, "_h", None) is not None and self._h["age"].shape[0] == self._age.shape[0]:
-            self._h["age"] += 1
+        self.host_edges()["age"] += 1  # factor_graph.py:306
+        self._mirror_changed("age")
 
     @torch.no_grad()
     def update_batch(self, itrs, steps, optimize_intrinsics, optimize_rig_rotation, solver_verbose=False):
@@ -629,6 +756,7 @@ class FactorGraph:
                 if use_volume:
                     vol = vols.get(gi)
                     if vol is None:
+                        corr_n = None  # (holds the previous chunk's levels) they go back to the allocator BEFORE this chunk's are taken
                         vol = CorrBlock.from_buffer(buf.flattened_fmaps, c["pis"] * V + c["qis"], c["pjs"] * V + c["qjs"],
                                                     frame_range=(0, t * V) if (self.cross_view and V > 1) else
                                                     (int(min(ii_np.min(), jj_np.min())) * V,

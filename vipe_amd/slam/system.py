@@ -43,6 +43,11 @@ class SLAMConfig:
     # not in the reference's configuration - how THIS build schedules pass 1 (results do not depend on either):
     pipeline_filter: bool = True   # motion filter of frame f+1 on a side stream under keyframe f's frontend step
     pause_gc: bool = True          # keep the cyclic collector off during run() (its gen-2 sweeps cost up to 0.4 s per clip)
+    release_cached_memory: bool = False  # several clips share this card (one process each): hand the global BA's pyramid
+                                         # blocks back to the driver after each backend pass instead of caching them
+    backend_lock_path: str = None        # ... and let their global-BA phases - each fills the chip by itself and wants the
+                                         # pyramid budget to itself - take turns (an advisory file lock held around the two
+                                         # backend passes), while the other clips' pass 1 / pass 2 run beside it
 
 
 @dataclass
@@ -58,8 +63,10 @@ class Frame:
 
 
 class SLAMSystem:
-    def __init__(self, device=torch.device("cuda"), config=None, droid_net=None, depth_model=None, sparse_tracks=None):
+    def __init__(self, device=torch.device("cuda"), config=None, droid_net=None, depth_model=None, sparse_tracks=None,
+                 motion_filter_cls=MotionFilter):
         self.device, self.config = device, config or SLAMConfig()
+        self.motion_filter_cls = motion_filter_cls  # pluggable keyframe selection (same constructor / check / prefetch)
         self.droid_net = droid_net if droid_net is not None else DroidNet()
         self.metric_depth = depth_model  # system.py:114-127 builds it from `keyframe_depth`; here the caller's
         self.sparse_tracks = sparse_tracks
@@ -72,7 +79,8 @@ class SLAMSystem:
                                   cross_view_idx=c.cross_view_idx, camera_type=camera_type, device=self.device)
         self.buffer.rig[:] = rig.data.to(self.device)
         self.buffer.sparse_tracks = self.sparse_tracks
-        self.motion_filter = MotionFilter(self.droid_net, sparse_tracks=self.sparse_tracks, thresh=c.filter_thresh, device=self.device)
+        self.motion_filter = self.motion_filter_cls(self.droid_net, sparse_tracks=self.sparse_tracks, thresh=c.filter_thresh,
+                                                    device=self.device)
         self.frontend = SLAMFrontend(self.droid_net.update, self.buffer, c.frontend, self.device)
         self.backend = SLAMBackend(self.droid_net.update, self.buffer, c.backend, self.device)
         self.inner_filler = InnerFiller(self.droid_net.update, self.buffer, c.infill, self.device)
@@ -164,9 +172,32 @@ class SLAMSystem:
         mark("pass1_seconds")
         self.work["pass1"] = {k: _fg.WORK[k] - work0[k] for k in work0}
         self.n_keyframes = int(b.n_frames)
-        self.backend.run(7)
-        gb = self.backend.run(self.config.backend.backend_iters, update_depth=False)
-        self.backend_edges = int(gb.ii.numel())
+        release = on_gpu and self.config.release_cached_memory
+        lock = None
+        if self.config.backend_lock_path:
+            import fcntl
+            lock = open(self.config.backend_lock_path, "a")
+            t_wait = time.perf_counter()
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            self.timings["backend_lock_wait_seconds"] = time.perf_counter() - t_wait
+        try:
+            self.backend.run(7)
+            if release:
+                self.backend.last_graph = None
+                torch.cuda.empty_cache()
+            gb = self.backend.run(self.config.backend.backend_iters, update_depth=False)
+            self.backend_edges = int(gb.host_edges()["ii"].shape[0])
+            if release:
+                del gb
+                self.backend.last_graph = None
+                torch.cuda.synchronize(self.device)
+                torch.cuda.empty_cache()
+        finally:
+            if lock is not None:
+                if on_gpu:
+                    torch.cuda.synchronize(self.device)  # the next holder gets the chip and the memory, not a queue behind ours
+                fcntl.flock(lock, fcntl.LOCK_UN)
+                lock.close()
         mark("global_ba_done_seconds")
         self.inner_filler.set_start_idx(b.n_frames)
         for frame_idx, fl in enumerate(frames):  # SLAM pass 2/2 (system.py:284-294)

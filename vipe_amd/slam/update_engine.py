@@ -159,13 +159,14 @@ class UpdateEngine:
         reference's resize to 384 x 512 pixels of area produces (vipe/slam/system.py:46-59: 41 x 73 for 16:9 video)."""
         return (wd % 64 == 0 and ht % 4 == 0) or wd <= 126
 
-    def gate_context(self, xbuf):
+    def gate_context(self, xbuf, out=None):
         """The part of the three GRU gate convolutions that only depends on the context features `inp`
         (xbuf[..., 0:128]; constant for the lifetime of an edge): [E,h,w,384] fp16 = conv3x3(inp; W_{z|r|q}[:, 128:256]).
         Handed back to `forward_nhwc(pgate=...)`, where it is the initial value of the gate accumulators, so that the
-        per-iteration gate convolutions run over 320 instead of 448 input channels (19 % of the operator's FLOPs)."""
+        per-iteration gate convolutions run over 320 instead of 448 input channels (19 % of the operator's FLOPs).
+        `out`: a contiguous [E,h,w,384] fp16 destination (the tail of a store) instead of a fresh tensor."""
         E, H, W, _ = xbuf.shape
-        pg = torch.empty((E, H, W, 384), dtype=torch.float16, device=xbuf.device)
+        pg = out if out is not None else torch.empty((E, H, W, 384), dtype=torch.float16, device=xbuf.device)
         self._conv(self.gates_inp, xbuf, 0, E, H, W, y=pg, act="none", cin=128)
         return pg
 
