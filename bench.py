@@ -405,13 +405,15 @@ def clip_worker_mode(args, D):
     sys.stdout.flush()
     sys.stdin.readline()
     t0 = time.perf_counter()
-    r = run_clip(seed=args.seed, n_frames=args.frames, frames=frames, release_cached_memory=bool(args.share_card),
+    r = run_clip(seed=args.seed, n_frames=args.frames, frames=frames, release_cached_memory=args.release_cache,
                  backend_lock=args.share_card or None)
     dt = time.perf_counter() - t0
     if args.out_dir:
         np.save(os.path.join(args.out_dir, f"traj_{args.seed}.npy"), r["poses"].cpu().numpy())
     print(json.dumps({"seed": args.seed, "seconds": dt, "frames": r["frames"], "keyframes": r["keyframes"],
-                      "pass1_seconds": r["pass1_seconds"], "backend_lock_wait_seconds": r.get("backend_lock_wait_seconds"),
+                      "pass1_seconds": r["pass1_seconds"], "seconds_to_global_ba_done": r["seconds_to_global_ba_done"],
+                      "seconds_to_pass2_done": r["seconds_to_pass2_done"],
+                      "backend_lock_wait_seconds": r.get("backend_lock_wait_seconds"),
                       "finite": r["finite"]}))
     sys.stdout.flush()
 
@@ -427,8 +429,10 @@ def clips_per_gpu_figure(args, ks=(1, 2, 3, 4)):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # The global BA keeps the correlation pyramids of all its edges (33 MB per edge at 48 x 64: ~3000 edges of a
     # 200-keyframe clip are 99 GB, VIPE_AMD_BACKEND_VOLUME_GB = 160 by default) and fills the chip by itself: the K
-    # clips' global-BA phases take turns on a file lock (SLAMConfig.backend_lock_path) and hand their blocks back to the
-    # driver afterwards (release_cached_memory); what runs concurrently is pass 1 / pass 2 of the other clips
+    # clips' global-BA phases take turns on a file lock (SLAMConfig.backend_lock_path); from K = 3 on they also hand their
+    # blocks back to the driver afterwards (release_cached_memory: the cached blocks of three processes do not fit side by
+    # side - at the price of mapping 100 GB again for every backend pass, ~1.2 s).  What runs concurrently is pass 1 /
+    # pass 2 of the other clips
     ref = None
     try:
         for K in ks:
@@ -436,7 +440,8 @@ def clips_per_gpu_figure(args, ks=(1, 2, 3, 4)):
             os.makedirs(d)
             procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--mode", "clip-worker", "--seed", str(k),
                                        "--frames", str(args.frames), "--height", str(args.height), "--width", str(args.width),
-                                       "--out-dir", d] + (["--share-card", os.path.join(d, "backend.lock")] if K > 1 else []),
+                                       "--out-dir", d] + (["--share-card", os.path.join(d, "backend.lock")] if K > 1 else [])
+                                      + (["--release-cache"] if K > 2 else []),
                                       stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True,
                                       env=env)
                      for k in range(K)]
@@ -461,8 +466,11 @@ def clips_per_gpu_figure(args, ks=(1, 2, 3, 4)):
             if ref is None:
                 ref = traj0
             out[str(K)] = {"frames_per_s": K * args.frames / dt, "seconds": dt,
+                           "pass1_frames_per_s": K * args.frames / max(r["pass1_seconds"] for r in res),
                            "per_clip_seconds": [r["seconds"] for r in res],
-                           "backend_lock_wait_seconds": [r.get("backend_lock_wait_seconds") for r in res], "all_finite": all(r["finite"] for r in res),
+                           "backend_lock_wait_seconds": [r.get("backend_lock_wait_seconds") for r in res],
+                           "phase_ends_seconds": [[r["pass1_seconds"], r["seconds_to_global_ba_done"], r["seconds_to_pass2_done"]]
+                                                  for r in res], "all_finite": all(r["finite"] for r in res),
                            "clip0_trajectory_equal_to_K1": bool(np.array_equal(traj0, ref)),
                            "clip0_max_abs_diff_to_K1": float(np.abs(traj0 - ref).max())}
             _log(f"clips per GPU: K = {K}: {out[str(K)]['frames_per_s']:.1f} frames/s")
@@ -1032,9 +1040,12 @@ def main():
     ap.add_argument("--keep-every", type=int, default=1,
                     help="video mode: script the motion filter so that every K-th frame becomes a keyframe (1: every frame)")
     ap.add_argument("--seed", type=int, default=0, help="clip-worker mode: the clip's seed")
+    ap.add_argument("--release-cache", action="store_true",
+                    help="clip-worker mode: SLAMConfig.release_cached_memory (more than two clips on one card: their cached "
+                         "pyramid blocks would not fit side by side)")
     ap.add_argument("--share-card", default="",
                     help="clip-worker mode: other clips run on this GPU - path of the lock file their global-BA phases "
-                         "take turns on (SLAMConfig.backend_lock_path, release_cached_memory)")
+                         "take turns on (SLAMConfig.backend_lock_path)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="video mode: SLAMConfig.pipeline_filter = False (the motion filter of every frame on the main stream, "
                          "strictly before the frontend step)")

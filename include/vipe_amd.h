@@ -501,7 +501,8 @@ int vipe_glo_context(const float* d_glo_sum, const float* d_wT, const float* d_b
  * with a boolean mask in `rm_factors` (:175-202).  Both are ONE launch here, for all tensors together (at most 8 jobs):
  *   vipe_rows_gather: for every job, dst row (dst_row0 + r) = src row idx[r] (r itself if idx is NULL), r < n_rows; a row
  *     is n_seg segments of seg_bytes bytes every seg_pitch bytes (a channel slice of a channels-last tensor: one segment
- *     per pixel), rows start every src_row_pitch / dst_row_pitch bytes.  All sizes multiples of 16; src != dst.
+ *     per pixel), rows start every src_row_pitch / dst_row_pitch bytes.  Sizes, pitches and addresses multiples of 4 (copied
+ *     in the largest of 16 / 8 / 4 bytes they are all multiples of); src != dst.
  *   vipe_gather_nchw_to_nhwc_f16: dst[dst_row0 + r][p][dst_coff + c] = src[frame[r]][c][p] for c < C <= 128, p < P:
  *     `buffer.nets[ii].permute(0, 2, 3, 1)` / `buffer.inps[ii]...` of the new edges' source frames, written straight into
  *     the tail of the channels-last stores (dst rows of dst_row_pitch halves, dst_ctot channels per pixel). */

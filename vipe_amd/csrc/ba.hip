@@ -3433,13 +3433,6 @@ __global__ void clamp_min_kernel(float* __restrict__ x, int64_t n, float lo) {
     x[i] = fmaxf(x[i], lo);  // NaN stays NaN? fmaxf(NaN, lo) = lo; torch.clamp keeps NaN - disparities are finite here
 }
 
-// a few microseconds on one wave: head start for the solve kernel on the BA stream before a piece of the caller's
-// independent work fills the chip (vipe_overlap_fn)
-__global__ void overlap_delay_kernel(int ticks) {
-  const uint64_t t0 = wall_clock64();  // 100 MHz
-  while (wall_clock64() - t0 < (uint64_t)ticks) __builtin_amdgcn_s_sleep(16);
-}
-
 // Event `after the accumulate kernels of this iteration` on the BA stream; see overlap_piece
 hipEvent_t overlap_event() {
   static thread_local hipEvent_t ev[64] = {};
@@ -3450,18 +3443,15 @@ hipEvent_t overlap_event() {
   return e;
 }
 
-// vipe_overlap_fn protocol: piece `it` goes to the caller's stream behind (event after this iteration's accumulate
-// kernels) + a short delay, so that it starts when the single-workgroup solve already owns a CU
+// vipe_overlap_fn protocol: piece `it` goes to the caller's stream behind the event after this iteration's accumulate
+// kernels, i.e. it becomes eligible together with the single-workgroup solve
 int overlap_piece(const vipe_ba_params& p, hipEvent_t ev, int piece, int n_pieces, bool gated) {
   hipStream_t side = (hipStream_t)p.overlap_stream;
-  if (gated && ev) {
-    if (hipStreamWaitEvent(side, ev, 0) != hipSuccess) return VIPE_EINVAL;
-    // Head start of the solve (4 us at the 100 MHz wall clock).  A scheduling HINT, not a dependency: results never depend
-    // on it, only which of two ready kernels gets a free CU first.  VIPE_AMD_OVERLAP_DELAY_TICKS overrides (0: no delay
-    // kernel) - the A/B of DESIGN.md section 5.
-    static const int ticks = [] { const char* e = getenv("VIPE_AMD_OVERLAP_DELAY_TICKS"); return e ? atoi(e) : 400; }();
-    if (ticks > 0) overlap_delay_kernel<<<1, 64, 0, side>>>(ticks);
-  }
+  // (Rounds 2-3 put a 4 us wall-clock delay kernel behind the event so that the solve kernel would win the race for a free
+  // CU.  Round 4 A/B on the headline, three runs each: 256.5 / 256.1 / 256.7 it/s with it, 257.5 / 256.5 / 257.9 without,
+  // 254.4 / 253.6 / 254.8 with 16 us - the two-chain band solve and the staged share of 0.5 left nothing for it to fix.
+  // Removed: the ordering is the event alone.)
+  if (gated && ev && hipStreamWaitEvent(side, ev, 0) != hipSuccess) return VIPE_EINVAL;
   return p.overlap_fn(p.overlap_user, piece, n_pieces, p.overlap_stream);
 }
 

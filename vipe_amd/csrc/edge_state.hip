@@ -14,23 +14,34 @@ constexpr int MAX_JOBS = 8;
 
 struct RowsArgs {
   vipe_rows_job job[MAX_JOBS];
-  int64_t chunks[MAX_JOBS];  // 16-byte chunks of job j
+  int64_t chunks[MAX_JOBS];  // copy units of job j
+  int unit[MAX_JOBS];        // bytes per unit: 16, 8 or 4
 };
 
 typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 
-// grid (x, n_jobs): grid-stride over the 16-byte chunks of job blockIdx.y
-__global__ __launch_bounds__(256) void rows_gather_kernel(RowsArgs a) {
-  const vipe_rows_job& j = a.job[blockIdx.y];
-  const int64_t per_seg = j.seg_bytes >> 4, per_row = per_seg * j.n_seg, total = a.chunks[blockIdx.y];
+template <typename U>
+__device__ __forceinline__ void rows_gather_job(const vipe_rows_job& j, int64_t total) {
+  constexpr int SH = sizeof(U) == 16 ? 4 : (sizeof(U) == 8 ? 3 : 2);
+  const int64_t per_seg = j.seg_bytes >> SH, per_row = per_seg * j.n_seg;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t r = i / per_row, w = i % per_row;
     const int64_t seg = w / per_seg, c = w % per_seg;
     const int64_t sr = j.idx ? j.idx[r] : r;
-    const char* src = (const char*)j.src + sr * j.src_row_pitch + seg * j.seg_pitch + (c << 4);
-    char* dst = (char*)j.dst + (r + j.dst_row0) * j.dst_row_pitch + seg * j.seg_pitch + (c << 4);
-    *reinterpret_cast<uint4v*>(dst) = *reinterpret_cast<const uint4v*>(src);
+    const char* src = (const char*)j.src + sr * j.src_row_pitch + seg * j.seg_pitch + (c << SH);
+    char* dst = (char*)j.dst + (r + j.dst_row0) * j.dst_row_pitch + seg * j.seg_pitch + (c << SH);
+    *reinterpret_cast<U*>(dst) = *reinterpret_cast<const U*>(src);
   }
+}
+
+// grid (x, n_jobs): grid-stride over the chunks of job blockIdx.y (16-, 8- or 4-byte units, whatever the job's sizes,
+// pitches and addresses are all multiples of: a [h, w, 2] f32 map of an odd pixel count is not a multiple of 16 bytes)
+__global__ __launch_bounds__(256) void rows_gather_kernel(RowsArgs a) {
+  const vipe_rows_job& j = a.job[blockIdx.y];
+  const int u = a.unit[blockIdx.y];
+  if (u == 16) rows_gather_job<uint4v>(j, a.chunks[blockIdx.y]);
+  else if (u == 8) rows_gather_job<unsigned long long>(j, a.chunks[blockIdx.y]);
+  else rows_gather_job<unsigned int>(j, a.chunks[blockIdx.y]);
 }
 
 struct NhwcArgs {
@@ -68,13 +79,16 @@ VIPE_EXPORT int vipe_rows_gather(const vipe_rows_job* jobs, int n_jobs, void* st
   int64_t most = 0;
   for (int k = 0; k < n_jobs; ++k) {
     const vipe_rows_job& j = jobs[k];
-    VIPE_CHECK_ARG(j.n_rows >= 0 && j.dst_row0 >= 0 && j.n_seg >= 1 && j.seg_bytes > 0 && (j.seg_bytes & 15) == 0);
-    VIPE_CHECK_ARG((j.seg_pitch & 15) == 0 && (j.src_row_pitch & 15) == 0 && (j.dst_row_pitch & 15) == 0);
+    VIPE_CHECK_ARG(j.n_rows >= 0 && j.dst_row0 >= 0 && j.n_seg >= 1 && j.seg_bytes > 0);
     if (j.n_rows == 0) continue;
     VIPE_CHECK_ARG(j.src && j.dst && j.src != j.dst);
-    VIPE_CHECK_ARG((((uintptr_t)j.src | (uintptr_t)j.dst) & 15) == 0);
+    const uint64_t all = (uint64_t)j.seg_bytes | (uint64_t)j.seg_pitch | (uint64_t)j.src_row_pitch | (uint64_t)j.dst_row_pitch |
+                         (uint64_t)(uintptr_t)j.src | (uint64_t)(uintptr_t)j.dst;
+    VIPE_CHECK_ARG((all & 3) == 0);
+    const int unit = (all & 15) == 0 ? 16 : ((all & 7) == 0 ? 8 : 4);
     a.job[live] = j;
-    a.chunks[live] = (int64_t)j.n_rows * j.n_seg * (j.seg_bytes >> 4);
+    a.unit[live] = unit;
+    a.chunks[live] = (int64_t)j.n_rows * j.n_seg * (j.seg_bytes / unit);
     most = a.chunks[live] > most ? a.chunks[live] : most;
     ++live;
   }
