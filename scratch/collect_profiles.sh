@@ -33,8 +33,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/video -o v -- python3
 echo video done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/video41 -o v -- python3 $R/bench.py --mode video --frames 200 $G > $O/video41.log 2>&1
 echo video 584x328 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/videob -o v -- python3 $R/bench.py --mode video --frames 200 > $O/videob.log 2>&1
-echo video+backend done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/videok -o v -- python3 $R/bench.py --mode video --frames 400 --keep-every 4 > $O/videok.log 2>&1
+echo video keep-every-4 done
 export VIPE_AMD_BACKEND_ALTCORR=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/backend_alt -o v -- python3 $R/bench.py --mode backend --steps 5 --warmup 2 > $O/backend_alt.log 2>&1
 unset VIPE_AMD_BACKEND_ALTCORR

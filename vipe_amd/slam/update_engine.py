@@ -21,6 +21,7 @@ scratch/miopen_ab.py (diagnostic, not importable from the package).
 """
 
 import ctypes
+import os
 
 import torch
 
@@ -69,7 +70,7 @@ class UpdateEngine:
         # second stream of the natively sequenced operator (vipe_update_buffers.side_stream): worth its four event
         # operations only when the kernels are long enough, i.e. for large edge sets
         self._op_side = None
-        self.op_side_min_edges = 64
+        self.op_side_min_edges = int(os.environ.get("VIPE_AMD_OP_SIDE_MIN_EDGES", "64"))
         # A staged gate state (hidden_gate_state / gate_state_job) lives in THIS engine's scratch buffers (pzr, extra, glo),
         # and one engine serves every FactorGraph of an UpdateModule (frontend, backend, infill): any later call that
         # writes those buffers bumps the generation, and a state of an older generation no longer matches
