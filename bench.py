@@ -418,7 +418,7 @@ def clip_worker_mode(args, D):
     sys.stdout.flush()
 
 
-def clips_per_gpu_figure(args, ks=(1, 2, 3, 4)):
+def clips_per_gpu_figure(args, ks=(1, 2, 4)):
     """K independent clips at once on ONE GPU, one fresh process per clip (clips are independent: the partitioning of
     SURVEY 8e applied below the GPU boundary).  All K workers warm up, then start together; aggregate frames/s = K x
     frames / (release -> last worker's result).  Clip `seed 0` runs at every K: its trajectory is compared with the

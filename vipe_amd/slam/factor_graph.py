@@ -193,7 +193,7 @@ class FactorGraph:
         # tuning of that stage ("the BA's shadow"): taken from this many active edges on; released by
         # the BA per Gauss-Newton iteration ("gated") or launched at once ("free"); share of the edges whose z|r part is
         # staged; shares of the pieces
-        self.gate_overlap_min_edges = 64
+        self.gate_overlap_min_edges = int(os.environ.get("VIPE_AMD_GATE_OVERLAP_MIN_EDGES", "64"))
         self.gate_overlap_mode = "gated"
         self.gate_overlap_share = 0.5
         self.gate_overlap_fractions = [0.4, 0.4, 0.2]
