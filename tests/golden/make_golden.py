@@ -508,6 +508,35 @@ def gen_splat(R):
     print("splat: weight sum", float(wgt.sum()))
 
 
+CORR_SAMPLER_CASES = {
+    # name: (B, C, H, W), (kH, kW, patchH, patchW, padH, padW, dilH, dilW, dil_patchH, dil_patchW, dH, dW)
+    "k1_patch5": ((2, 5, 9, 11), (1, 1, 5, 5, 0, 0, 1, 1, 2, 1, 1, 1)),
+    "k3_pad_stride": ((2, 4, 10, 12), (3, 3, 3, 5, 1, 1, 1, 1, 1, 2, 2, 1)),
+    "k2_dilated": ((1, 3, 8, 9), (2, 3, 7, 1, 2, 1, 2, 1, 1, 1, 1, 2)),
+    "even_patch": ((1, 6, 7, 7), (1, 1, 4, 2, 0, 0, 1, 1, 1, 3, 1, 1)),
+}
+
+
+def gen_corr_sampler(R):
+    """`corr_ext` against the reference's OWN CPU implementation, compiled here from
+    /root/reference/csrc/corr_ext/correlation.cpp by oracle/build_ref.py (oracle/_ref/ref_corr.so): forward and backward
+    on four geometries (kernel, patch, padding, both dilations, strides, an even patch size), float32."""
+    from oracle.build_ref import build_ref_corr
+    ref = build_ref_corr(REF)
+    out = {}
+    gen = torch.Generator().manual_seed(17)
+    for name, (shape, geom) in CORR_SAMPLER_CASES.items():
+        a = torch.randn(*shape, generator=gen)
+        b = torch.randn(*shape, generator=gen)
+        y = ref.forward(a, b, *geom)
+        go = torch.randn(y.shape, generator=gen)
+        g1, g2 = ref.backward(a, b, go, *geom)
+        for k, v in dict(a=a, b=b, out=y, grad_out=go, grad1=g1, grad2=g2).items():
+            out[f"{name}/{k}"] = _np(v)
+        print("corr sampler", name, tuple(y.shape))
+    np.savez_compressed(os.path.join(HERE, "corr_sampler_reference.npz"), **out)
+
+
 def gen_headline(R):
     """Headline-size fixtures from the reference itself (BASELINE configs[2]: 512 x 384, 48 keyframes, E = 276, depth
     prior on - the graph `bench.py` times):
@@ -545,6 +574,9 @@ def gen_headline(R):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     R = load_reference()
+    if os.environ.get("GOLDEN_ONLY") == "corr_sampler":
+        gen_corr_sampler(R)
+        sys.exit(0)
     if os.environ.get("GOLDEN_ONLY") == "headline":
         gen_headline(R)
         sys.exit(0)
@@ -574,4 +606,5 @@ if __name__ == "__main__":
     gen_corr(R)
     gen_encoder(R)
     gen_headline(R)
+    gen_corr_sampler(R)
     print("golden fixtures written to", HERE)

@@ -123,6 +123,41 @@ def test_corr_ext_host_path_against_torch_autograd():
     assert torch.allclose(g1, r1, atol=1e-5) and torch.allclose(g2, r2, atol=1e-5)
 
 
+def _corr_sampler_cases():
+    import os
+    src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden.py")).read()
+    ns = {}
+    exec(src[src.index("CORR_SAMPLER_CASES = {"):src.index("def gen_corr_sampler")], ns)
+    return ns["CORR_SAMPLER_CASES"]
+
+
+def test_corr_ext_host_path_matches_the_reference_cpu_implementation(golden_dir):
+    """`corr_ext` on CPU tensors vs outputs of the reference's own CPU sampler (csrc/corr_ext/correlation.cpp, compiled
+    in the build container by oracle/build_ref.py, frozen by make_golden.gen_corr_sampler): forward and backward, four
+    geometries.  Where oracle/_ref/ref_corr.so is present (build container, and it travels to the GPU box) the compiled
+    reference is also called directly on fresh inputs."""
+    import os
+    from vipe_amd.ext import corr_ext
+    G = np.load(os.path.join(golden_dir, "corr_sampler_reference.npz"))
+    for name, (shape, geom) in _corr_sampler_cases().items():
+        a, b, go = (torch.from_numpy(G[f"{name}/{k}"]) for k in ("a", "b", "grad_out"))
+        out = corr_ext.forward(a, b, *geom)
+        assert out.shape == G[f"{name}/out"].shape and np.allclose(out.numpy(), G[f"{name}/out"], atol=1e-5), name
+        g1, g2 = corr_ext.backward(a, b, go, *geom)
+        assert np.allclose(g1.numpy(), G[f"{name}/grad1"], atol=1e-5) and np.allclose(g2.numpy(), G[f"{name}/grad2"], atol=1e-5), name
+    from oracle.build_ref import load_ref_corr
+    ref = load_ref_corr()
+    if ref is not None:
+        gen = torch.Generator().manual_seed(3)
+        a, b = torch.randn(2, 7, 12, 10, generator=gen), torch.randn(2, 7, 12, 10, generator=gen)
+        geom = (3, 1, 5, 3, 1, 0, 1, 1, 2, 2, 1, 1)
+        want = ref.forward(a, b, *geom)
+        assert torch.allclose(corr_ext.forward(a, b, *geom), want, atol=1e-5)
+        go = torch.randn(want.shape, generator=gen)
+        for x, y in zip(corr_ext.backward(a, b, go, *geom), ref.backward(a, b, go, *geom)):
+            assert torch.allclose(x, y, atol=1e-5)
+
+
 def test_gate_state_piece_validates_its_job_without_a_gpu():
     """`vipe_update_gate_state_piece` (the vipe_overlap_fn the BA calls): argument checks happen before any launch."""
     import ctypes

@@ -689,6 +689,39 @@ def test_corr_ext_sampler_against_torch_loops():
     assert torch.allclose(g1, a_.grad, atol=1e-4) and torch.allclose(g2, b_.grad, atol=1e-4)
 
 
+def test_corr_ext_device_kernels_match_the_reference_cpu_implementation():
+    """The HIP sampler kernels vs outputs of the reference's own CPU implementation (csrc/corr_ext/correlation.cpp compiled
+    in the build container, tests/golden/corr_sampler_reference.npz): forward and backward on every geometry with an odd
+    patch size; for the EVEN patch the reference's CUDA forward kernel centres the patch differently from its CPU code
+    and from its own CUDA backward kernels (correlation_cuda_kernel.cu:43-51 vs :96-117 / correlation.cpp:73-74) - the
+    device forward follows the CUDA forward (checked against that formula), the device backward the fixture."""
+    from test_abi import _corr_sampler_cases
+    from vipe_amd.ext import corr_ext
+    G = np.load(os.path.join(GOLD, "corr_sampler_reference.npz"))
+    for name, (shape, geom) in _corr_sampler_cases().items():
+        a, b, go = (T(G[f"{name}/{k}"]) for k in ("a", "b", "grad_out"))
+        out = corr_ext.forward(a, b, *geom)
+        if name != "even_patch":
+            assert np.allclose(out.cpu().numpy(), G[f"{name}/out"], atol=1e-4), name
+        else:
+            kH, kW, pH, pW, padH, padW, dilH, dilW, dpH, dpW, dH, dW = geom
+            assert (kH, kW, padH, padW, dH, dW) == (1, 1, 0, 0, 1, 1)
+            B, C, H, W = shape
+            want = torch.zeros(B, pH, pW, H, W)
+            ac, bc = a.cpu(), b.cpu()
+            for ph in range(pH):
+                for pw in range(pW):
+                    sy, sx = ph * dpH - dpH * (pH - 1) // 2, pw * dpW - dpW * (pW - 1) // 2
+                    for y in range(H):
+                        for x in range(W):
+                            if 0 <= y + sy < H and 0 <= x + sx < W:
+                                want[:, ph, pw, y, x] = (ac[:, :, y, x] * bc[:, :, y + sy, x + sx]).sum(1)
+            assert torch.allclose(out.cpu(), want, atol=1e-4)
+        g1, g2 = corr_ext.backward(a, b, go, *geom)
+        assert np.allclose(g1.cpu().numpy(), G[f"{name}/grad1"], atol=1e-4), name
+        assert np.allclose(g2.cpu().numpy(), G[f"{name}/grad2"], atol=1e-4), name
+
+
 def test_corr_pyramid_lookup_row_kernel_bit_exact():
     """Widths that are multiples of 64 take the 8-lanes-per-pixel kernel: bit-exact vs the oracle, both layouts,
     windows hanging over every border."""

@@ -315,6 +315,7 @@ __global__ void corr_sampler_forward_kernel(const T* __restrict__ in1, const T* 
                                             int patchW, int padH, int padW, int dilH, int dilW, int dpH, int dpW, int dH,
                                             int dW) {
   const int64_t total = (int64_t)B * patchH * patchW * oH * oW;
+  // correlation_cuda_kernel.cu:43-51 (forward): radius = dilation * (patch - 1) / 2 in integer arithmetic
   const int radH = dpH * (patchH - 1) / 2, radW = dpW * (patchW - 1) / 2;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int w = (int)(i % oW), h = (int)((i / oW) % oH);
@@ -343,7 +344,9 @@ __global__ void corr_sampler_backward_kernel(const float* __restrict__ in1, cons
                                              int kW, int patchH, int patchW, int padH, int padW, int dilH, int dilW,
                                              int dpH, int dpW, int dH, int dW) {
   const int64_t total = (int64_t)B * patchH * patchW * oH * oW;
-  const int radH = dpH * (patchH - 1) / 2, radW = dpW * (patchW - 1) / 2;
+  // correlation_cuda_kernel.cu:96-117,157-179: the reference's backward kernels centre the patch at (patch - 1) / 2 BEFORE
+  // scaling by the patch dilation - its forward kernel (:43-51) after; the two differ for even patch sizes with odd dilation
+  const int radH = dpH * ((patchH - 1) / 2), radW = dpW * ((patchW - 1) / 2);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int w = (int)(i % oW), h = (int)((i / oW) % oH);
     const int pw = (int)((i / ((int64_t)oW * oH)) % patchW), ph = (int)((i / ((int64_t)oW * oH * patchW)) % patchH);
@@ -520,9 +523,10 @@ VIPE_EXPORT int vipe_corr_sampler_backward(const void* d_in1, const void* d_in2,
   return vipe_launch_status();
 }
 
-// Host-memory twins of the correlation sampler for CPU tensors (the reference dispatches them to correlation_cpu.cpp:
-// correlation_sampler.cpp:44-58).  The same index arithmetic and accumulation order as the kernels above, one output
-// (forward) / one gradient sample (backward) after the other - float32 only.
+// Host-memory twins of the correlation sampler for CPU tensors (the reference dispatches them to correlation.cpp:
+// correlation_sampler.cpp:44-58; pinned by outputs of that very file, tests/golden/corr_sampler_reference.npz).  The
+// accumulation order of the kernels above, one output (forward) / one gradient sample (backward) after the other -
+// float32 only.
 VIPE_EXPORT int vipe_corr_sampler_forward_host(const float* h_in1, const float* h_in2, float* h_out, int B, int C, int H, int W,
                                                int kH, int kW, int patchH, int patchW, int padH, int padW, int dilH, int dilW,
                                                int dil_patchH, int dil_patchW, int dH, int dW) {
@@ -531,7 +535,8 @@ VIPE_EXPORT int vipe_corr_sampler_forward_host(const float* h_in1, const float* 
   const int64_t total = (int64_t)B * patchH * patchW * oH * oW;
   if (total <= 0) return VIPE_OK;
   VIPE_CHECK_ARG(h_in1 && h_in2 && h_out);
-  const int radH = dil_patchH * (patchH - 1) / 2, radW = dil_patchW * (patchW - 1) / 2;
+  // correlation.cpp:73-74,100-101: the CPU implementation centres the patch at (patch - 1) / 2 before the dilation
+  const int radH = dil_patchH * ((patchH - 1) / 2), radW = dil_patchW * ((patchW - 1) / 2);
   for (int64_t i = 0; i < total; ++i) {
     const int w = (int)(i % oW), h = (int)((i / oW) % oH);
     const int pw = (int)((i / ((int64_t)oW * oH)) % patchW), ph = (int)((i / ((int64_t)oW * oH * patchW)) % patchH);
@@ -563,7 +568,8 @@ VIPE_EXPORT int vipe_corr_sampler_backward_host(const float* h_in1, const float*
   const int64_t total = (int64_t)B * patchH * patchW * oH * oW;
   if (total <= 0) return VIPE_OK;
   VIPE_CHECK_ARG(h_in1 && h_in2 && h_grad_out && h_grad1 && h_grad2);  // gradients are accumulated into: caller zeroes
-  const int radH = dil_patchH * (patchH - 1) / 2, radW = dil_patchW * (patchW - 1) / 2;
+  // correlation.cpp:73-74,100-101: the CPU implementation centres the patch at (patch - 1) / 2 before the dilation
+  const int radH = dil_patchH * ((patchH - 1) / 2), radW = dil_patchW * ((patchW - 1) / 2);
   for (int64_t i = 0; i < total; ++i) {
     const int w = (int)(i % oW), h = (int)((i / oW) % oH);
     const int pw = (int)((i / ((int64_t)oW * oH)) % patchW), ph = (int)((i / ((int64_t)oW * oH * patchW)) % patchH);
