@@ -166,6 +166,11 @@ int vipe_lie_projector(int group_id, const void* X, void* P, int64_t n, int dtyp
                        void* stream); /* P [n,N,N] */
 int vipe_lie_jinv(int group_id, const void* X, const void* a, void* b, int64_t n, int dtype, int on_device,
                   void* stream);
+/* [fused] the keyframe frontend's preparation of the NEXT frame's slot (vipe/slam/components/frontend.py:70-76 `_init_pose`,
+ * :118-122 / :147-151): poses[t1] = Exp(0.5 Log(G_{t1-1} G_{t1-2}^-1)) G_{t1-1} when init_pose, and disps[t1, v] =
+ * mean(disps[t1 - n_mean .. t1 - 1, v]) for every view.  poses [>= t1+1, 7], disps [>= t1+1, n_views, P] f32. */
+int vipe_frontend_next_frame(float* d_poses, float* d_disps, int t1, int n_views, int P, int n_mean, int init_pose,
+                             void* stream);
 /* [fused] broadcast forms: one group element per `rows_per_elem` consecutive rows of a/p (the Python
  * wrapper in the reference replicates X per row, broadcasting.py:32-35). */
 int vipe_lie_adjT_bcast(int group_id, const void* X, const void* a, void* b, int64_t n_elem, int64_t rows_per_elem,
@@ -526,6 +531,11 @@ typedef struct {
   int dst_row0;
 } vipe_nhwc_job;
 int vipe_gather_nchw_to_nhwc_f16(const vipe_nhwc_job* jobs, int n_jobs, int n_rows, int C, int P, void* stream);
+
+/* [fused] MotionFilter's dense score (vipe/slam/components/motion_filter.py:103-110): score[v] = mean over pixels of
+ * |(half) delta| (masked: sum(|delta| (1 - invalid)) / P / (mean(1 - invalid) + 1e-6)).  dw [n_views, P, 4] f32 = the update
+ * operator's (delta_x, delta_y, weight_x, weight_y); invalid [n_views, P] bytes (bool) or NULL; score [n_views] f32. */
+int vipe_flow_score(const float* d_dw, const unsigned char* d_invalid, float* d_score, int n_views, int P, void* stream);
 
 /* [fused] tail of FactorGraph.update (factor_graph.py:270-276): target = coords1 + delta, weight = (masked source frame
  * ? 0 : w), damping[du[k]] = eta[k].  coords1 / target / weight [E,ht,wd,2] f32, dw [E,ht,wd,4] f32, mask [E,ht,wd] bytes

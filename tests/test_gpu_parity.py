@@ -961,6 +961,44 @@ def test_dense_ba_dense_window_takes_lds_dense_solver():
         assert np.abs(k - ok_).max() <= 1e-4 * np.abs(ok_).max()
 
 
+@pytest.mark.parametrize("kind", ["band", "dense", "global"])
+def test_dense_ba_path_hints_across_calls_with_one_plan(kind):
+    """The caller-side plan state of `slam_ext.dense_ba` (`state=`, `plan_key=`): call 1 launches every accumulate / solve
+    kernel and learns from d_info[4..7] which ones the plan uses; later calls with the SAME key reuse the plan and pass
+    the hint, so the kernels that would only start to exit are not launched at all.  For a band-solved chain, a dense
+    window (band solver declines, LDS dense solver takes it) and a system too large for LDS (both decline, tiled
+    Cholesky): every call - before the hint exists, while it is pending, with it - starts from the same state and must
+    give the fp64 oracle's answer with the same solver (info[5]: 1 band, 2 dense, 0 global)."""
+    import time
+    from vipe_amd.ext import slam_ext
+    g = {"band": lambda: make_graph(n=14, height=96, width=128, radius=2, seed=71),
+         "dense": lambda: make_graph(n=20, height=96, width=128, radius=19, seed=91),
+         "global": lambda: make_graph(n=70, height=96, width=128, radius=3, extra_edges=260, seed=101)}[kind]()
+    n, E = len(g.poses), len(g.ii)
+    bk = dict(t0=1, t1=n, n_iters=2, pose_damping=1e-3, pose_ep=0.1)
+    op, od, _, _ = oba.bundle_adjustment(g.poses, g.disps[:, None], g.disps_sens[:, None], g.intrinsics, ose3.se3_identity(1),
+                                         g.target.reshape(E, -1, 2), g.weight.reshape(E, -1, 2), g.eta[:, None], g.ii, g.jj, **bk)
+    z = np.zeros_like(g.ii)
+    idx = [T(x) for x in (g.ii, z, g.jj, z, g.ii)]  # the SAME index tensors every call (their addresses are part of the key)
+    tgt, wgt, eta, sens = T(g.target.reshape(E, -1, 2)), T(g.weight.reshape(E, -1, 2)), T(g.eta), T(g.disps_sens)
+    intr, rig = T(g.intrinsics), T(ose3.se3_identity(1))
+    state, want_solver, hints_seen = {}, {"band": 1, "dense": 2, "global": 0}[kind], []
+    for call in range(4):
+        poses, disps = T(g.poses).clone(), T(g.disps).clone()
+        info = slam_ext.dense_ba(poses, disps, sens, intr, rig, tgt, wgt, eta, *idx, want_info=True, state=state,
+                                 plan_key=("one plan",), **bk)
+        torch.cuda.synchronize()
+        time.sleep(0.01)  # let the learnt facts arrive (pinned buffer + event)
+        info = info.cpu().numpy()
+        hints_seen.append(slam_ext._path_hint(state, state.get("key")))
+        assert info[2] == 0 and info[5] == want_solver, (kind, call, info)
+        assert np.abs(poses.cpu().numpy() - op).max() <= 1e-4 * max(1.0, np.abs(op).max()), (kind, call)
+        assert np.abs(disps.cpu().numpy() - od[:, 0]).max() <= 1e-4 * np.abs(od).max(), (kind, call)
+    assert hints_seen[-1] != 0, "the plan's kernel selection must have been learnt by the last call"
+    solved_bits = {1: 4 | 16, 2: 4 | 8, 0: 8 | 16}[want_solver]
+    assert hints_seen[-1] & solved_bits == solved_bits
+
+
 @pytest.mark.parametrize("intr", [False, True])
 def test_dense_ba_large_dense_system_takes_tiled_cholesky(intr):
     """The global BA's reduced systems (hundreds of coupled poses): 64 x 64 tiled Cholesky spread over the chip (potrf in
@@ -2149,6 +2187,31 @@ def test_slam_system_two_passes_over_rgb_frames():
         assert bool((sysm.buffer.masks[:len(want)] == 0).all())  # all-valid masks -> nothing marked invalid
         if every > 1:
             assert calls["backend"] == 1  # 10 keyframes reached once
+
+
+def test_frontend_next_frame_kernel_matches_the_group_operations():
+    """`vipe_frontend_next_frame` (frontend.py:70-76 + :118-122 / :147-151 in one launch) against the same steps through
+    the lietorch operators and torch means: constant-velocity pose, per-view mean disparity over the last 1 / 4 keyframes,
+    poses untouched when the caller supplies them."""
+    from vipe_amd._lib import check, lib, ptr, stream_ptr
+    from vipe_amd.ext.lietorch import SE3
+    gen = torch.Generator().manual_seed(3)
+    N, V, h, w = 9, 2, 5, 7
+    xi = torch.randn(N, 6, generator=gen) * torch.tensor([0.3, 0.3, 0.3, 0.2, 0.2, 0.2])
+    poses0 = SE3.exp(xi.to(dev())).data.contiguous()
+    disps0 = torch.rand(N, V, h, w, generator=gen).to(dev()) + 0.1
+    for t1, n_mean, init in ((6, 1, 1), (8, 4, 1), (5, 1, 0)):
+        poses, disps = poses0.clone(), disps0.clone()
+        check(lib().vipe_frontend_next_frame(ptr(poses), ptr(disps), t1, V, h * w, n_mean, init, stream_ptr(poses)), "next_frame")
+        want_p = poses0.clone()
+        if init:
+            p1, p2 = SE3(poses0[t1 - 2][None]), SE3(poses0[t1 - 1][None])
+            want_p[t1] = (SE3.exp((p2 * p1.inv()).log() * 0.5) * p2).data[0]
+        assert torch.allclose(poses, want_p, atol=1e-6) and torch.equal(poses[:t1], poses0[:t1])
+        want_d = disps0.clone()
+        for v in range(V):
+            want_d[t1, v] = disps0[t1 - n_mean:t1, v].mean()
+        assert torch.allclose(disps, want_d, rtol=1e-6, atol=1e-7)
 
 
 def test_edge_stores_append_and_compact_match_cat_and_index():

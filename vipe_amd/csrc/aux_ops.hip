@@ -661,3 +661,36 @@ VIPE_EXPORT int vipe_nearest_neighbours(const float* d_query, int qdim, const fl
   return vipe_launch_status();
 }
 
+// ---- [fused] the motion filter's keyframe score (motion_filter.py:103-110): per view the mean magnitude of the one-iteration
+// flow (the operator's fp16 head output) over the usable pixels.  The reference: slice, cast, norm, two means, a division
+// - six launches per frame; here one block per view.
+namespace {
+__global__ __launch_bounds__(256) void flow_score_kernel(const float* __restrict__ dw, const unsigned char* __restrict__ invalid,
+                                                         float* __restrict__ score, int P) {
+  const int v = blockIdx.x;
+  float sf = 0.0f, sw = 0.0f;
+  for (int k = threadIdx.x; k < P; k += 256) {
+    const float4 d = reinterpret_cast<const float4*>(dw)[(int64_t)v * P + k];
+    const float fx = (float)(half_t)d.x, fy = (float)(half_t)d.y;  // the heads are fp16 under autocast (droid_net.py:486-487)
+    const float w = invalid ? (invalid[(int64_t)v * P + k] ? 0.0f : 1.0f) : 1.0f;
+    sf += sqrtf(fx * fx + fy * fy) * w;
+    sw += w;
+  }
+  __shared__ float red[2][4];
+  sf = wave_sum(sf);
+  sw = wave_sum(sw);
+  if (lane_id() == 0) { red[0][wave_id()] = sf; red[1][wave_id()] = sw; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float f = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)P;
+    const float w = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)P;
+    score[v] = invalid ? f / (w + 1e-6f) : f;
+  }
+}
+}  // namespace
+
+VIPE_EXPORT int vipe_flow_score(const float* d_dw, const unsigned char* d_invalid, float* d_score, int n_views, int P, void* stream) {
+  VIPE_CHECK_ARG(d_dw && d_score && n_views > 0 && P > 0);
+  flow_score_kernel<<<n_views, 256, 0, as_stream(stream)>>>(d_dw, d_invalid, d_score, P);
+  return vipe_launch_status();
+}

@@ -483,3 +483,41 @@ VIPE_EXPORT int vipe_lie_act_backward(int g, const void* grad, const void* X, co
 VIPE_EXPORT int vipe_lie_act4_backward(int g, const void* grad, const void* X, const void* p, void* dX, void* dp, int64_t n, int dt, int dev, void* st) {
   return dispatch_bwd<BwAct4>(g, grad, X, p, dX, dp, n, dt, dev, st);
 }
+
+// ---- [fused] what the keyframe frontend does to the NEXT frame's slot after every keyframe (frontend.py:70-76, 118-122,
+// 147-151): constant-velocity pose  poses[t1] = Exp(0.5 Log(G_{t1-1} G_{t1-2}^-1)) G_{t1-1}  (`init_pose`; skipped when the
+// caller supplies poses) and  disps[t1, v] = mean(disps[t1-n_mean .. t1-1, v])  (n_mean = 1 per keyframe, 4 after the
+// initialisation).  The reference issues inv, mul, log, scale, exp, mul on the poses and mean + fill per view: 9+ launches
+// of a few microseconds each; here one.  Same group formulas as vipe_lie_* (lie_math.h).  grid = n_views blocks.
+namespace {
+__global__ __launch_bounds__(256) void frontend_next_frame_kernel(float* __restrict__ poses, float* __restrict__ disps, int t1,
+                                                                  int V, int P, int n_mean, int init_pose) {
+  const int v = blockIdx.x;
+  if (v == 0 && threadIdx.x == 0 && init_pose) {
+    const SE3<float> p1(poses + 7 * (t1 - 2)), p2(poses + 7 * (t1 - 1));
+    float w[6];
+    (p2 * p1.inv()).log(w);
+    for (int i = 0; i < 6; ++i) w[i] *= 0.5f;
+    (SE3<float>::exp(w) * p2).store(poses + 7 * t1);
+  }
+  __shared__ float red[4];
+  float s = 0.0f;
+  for (int m = 1; m <= n_mean; ++m) {
+    const float* d = disps + ((int64_t)(t1 - m) * V + v) * P;
+    for (int k = threadIdx.x; k < P; k += 256) s += d[k];
+  }
+  s = wave_sum(s);
+  if (lane_id() == 0) red[wave_id()] = s;
+  __syncthreads();
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)((int64_t)P * n_mean);
+  float* o = disps + ((int64_t)t1 * V + v) * P;
+  for (int k = threadIdx.x; k < P; k += 256) o[k] = mean;
+}
+}  // namespace
+
+VIPE_EXPORT int vipe_frontend_next_frame(float* d_poses, float* d_disps, int t1, int n_views, int P, int n_mean, int init_pose,
+                                         void* stream) {
+  VIPE_CHECK_ARG(d_poses && d_disps && n_views > 0 && P > 0 && n_mean >= 1 && t1 >= n_mean && (!init_pose || t1 >= 2));
+  frontend_next_frame_kernel<<<n_views, 256, 0, as_stream(stream)>>>(d_poses, d_disps, t1, n_views, P, n_mean, init_pose);
+  return vipe_launch_status();
+}

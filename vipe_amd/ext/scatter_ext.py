@@ -12,6 +12,8 @@ reductions share one Function whose backward follows the table below (the adjoin
     min/max dL/dsrc[e] = g[slot] where e is the slot's arg row, else 0
 """
 
+import os
+
 import torch
 
 from .._lib import DTYPE_CODE, check, lib, ptr, require, stream_ptr
@@ -49,6 +51,12 @@ def _launch(src, index, out, arg, dim, reduce, rows):
         inner *= int(s)
     L = lib()
     if src.is_cuda:
+        if os.environ.get("VIPE_AMD_CHECK_INDICES") and index.numel():
+            # The kernels SKIP slots outside [0, out.shape[dim]) instead of writing out of bounds; torch's scatter and the
+            # reference's scatter_cuda assert.  This opt-in check (a device-to-host sync) turns a wrong dim_size or a
+            # corrupted index into the error the host path raises, so that forward and backward cannot quietly disagree.
+            lo, hi = int(index.min()), int(index.max())
+            require(0 <= lo and hi < out.shape[dim], f"scatter index out of range: [{lo}, {hi}] vs dim size {out.shape[dim]}")
         fn = L.vipe_scatter_rows if rows else L.vipe_scatter
         check(fn(ptr(src), ptr(index), ptr(out), ptr(arg), outer, src.shape[dim], inner, out.shape[dim],
                  _REDUCE[reduce], DTYPE_CODE[src.dtype], stream_ptr(src)), "scatter_" + reduce)

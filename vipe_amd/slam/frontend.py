@@ -46,6 +46,22 @@ class SLAMFrontend:
         w = (p2 * p1.inv()).log() * 0.5
         self.video.poses[self.t1] = (SE3.exp(w) * p2).data[0]
 
+    def _next_frame(self, n_mean):
+        """frontend.py:118-122 / 147-151 in ONE launch (`vipe_frontend_next_frame`): the constant-velocity pose of the frame
+        that will be appended next (unless the caller supplies poses) and its disparity = the mean of the last `n_mean`
+        keyframes' maps, per view.  CPU buffers (tests of the scheduling logic) take the torch formulation."""
+        v = self.video
+        if not v.poses.is_cuda:
+            if not self.args.has_init_pose:
+                self._init_pose()
+            for q in range(v.n_views):
+                v.disps[self.t1, q] = v.disps[self.t1 - n_mean:self.t1, q].mean()
+            return
+        from .._lib import check, lib, ptr, stream_ptr
+        check(lib().vipe_frontend_next_frame(ptr(v.poses), ptr(v.disps), int(self.t1), int(v.n_views),
+                                             int(v.disps.shape[2] * v.disps.shape[3]), int(n_mean),
+                                             int(not self.args.has_init_pose), stream_ptr(v.poses)), "frontend_next_frame")
+
     def _iterate(self, n, **kw):
         for _ in range(n):
             self.graph.update(use_inactive=True, fixed_motion=self.args.has_init_pose, **kw)
@@ -106,10 +122,7 @@ class SLAMFrontend:
             self.t1 -= 1
         else:
             self._iterate(self.iters2)
-        if not a.has_init_pose:
-            self._init_pose()
-        for v in range(self.video.n_views):
-            self.video.disps[self.t1, v] = self.video.disps[self.t1 - 1, v].mean()
+        self._next_frame(1)
         self.video.dirty[int(self.graph.host_edges()["ii"].min()):self.t1] = True  # frontend.py:124 (host mirror: no read-back)
         self.video.touch()
         self._prefetch_proximity()
@@ -123,10 +136,7 @@ class SLAMFrontend:
         if not a.seq_init:
             self.graph.add_proximity_factors(0, 0, rad=2, nms=2, thresh=a.frontend_thresh, remove=False)
             self._iterate(8, t0=1)
-        if not a.has_init_pose:
-            self._init_pose()
-        for v in range(self.video.n_views):
-            self.video.disps[self.t1, v] = self.video.disps[self.t1 - 4:self.t1, v].mean()
+        self._next_frame(4)
         self.video.dirty[:self.t1] = True
         self.is_initialized = True
         self.graph.rm_factors(self.graph.host_edges()["ii"] < a.warmup - 4, store=True)

@@ -10,7 +10,7 @@ GRU) is prepared once per keyframe.  The sparse-track score (`motion_filter.py:1
 tracker reports (`get_correspondences`, `get_observations`); the trackers themselves are outside the path."""
 import torch
 
-from .._lib import require
+from .._lib import check, lib, ptr, require, stream_ptr
 from .encoders import DroidEncoders, normalize_images
 from .networks import CorrBlock, UpdateModule
 
@@ -123,14 +123,14 @@ class MotionFilter:
                 eng = self._engine(gmap.device)
                 corr = CorrBlock(self.f_fmap[None], gmap[None]).lookup_deferred(self._coords0)
                 _, dw, _, _ = eng.forward_nhwc(self._net_nhwc, self._xbuf, corr, self._motn0, pgate=self._pgate)
-                dense_flow = dw[..., 0:2].half().float().norm(dim=-1)  # fp16 head output, norm in fp32 (autocast rules)
-                if self.f_mask is not None:
-                    f_weight = (~self.f_mask).float()
-                    score = (dense_flow * f_weight).mean([1, 2]) / (f_weight.mean([1, 2]) + 1e-6)
-                else:
-                    score = dense_flow.mean([1, 2])
-                host = torch.empty((), dtype=torch.float32, pin_memory=True)
-                host.copy_(score.min(), non_blocking=True)
+                # mean |flow| per view over the usable pixels (fp16 head output, norm in fp32: autocast rules) in one
+                # launch; the minimum over the views is taken on the host once the scores have arrived
+                V, ht, wd, _ = dw.shape
+                score = torch.empty(V, dtype=torch.float32, device=dw.device)
+                mask = self.f_mask.contiguous() if self.f_mask is not None else None
+                check(lib().vipe_flow_score(ptr(dw), ptr(mask), ptr(score), V, ht * wd, stream_ptr(dw)), "flow_score")
+                host = torch.empty(V, dtype=torch.float32, pin_memory=True)
+                host.copy_(score, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
                 h["score"], h["event"] = host, ev
@@ -151,7 +151,7 @@ class MotionFilter:
                 return True
             self.current_frame_idx += 1
             h["event"].synchronize()
-            self.last_score = float(h["score"])
+            self.last_score = float(h["score"].min())
             self.scores.append(self.last_score)
             sparse = self._sparse_motion_score(h["images"].shape[0])
             # the track score is a sum over keypoints' mean displacement, not a pixel average: twice the threshold
