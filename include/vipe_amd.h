@@ -305,6 +305,16 @@ int vipe_frame_distance(const float* d_poses, const float* d_disps, const float*
                         const int64_t* d_pj, const int64_t* d_qi, const int64_t* d_qj, const int64_t* d_di,
                         float* d_dist, int M, int ht, int wd, float beta, void* stream);
 
+/* [fused] GraphBuffer.frame_distance_dense_disp (vipe/slam/components/buffer.py:550-593, geom.py:335-343) in one launch:
+ * candidate m = (keyframe pi[m], view qi[m]) -> (pj[m], qj[m]); the per-view poses R_q^-1 G_p and the pinhole intrinsics at
+ * 1 / intr_factor scale are formed in the kernel (the reference expands the poses of ALL frames and rescales the
+ * intrinsics on the host side, then calls frame_distance twice and averages).  poses [N,7], rig [V,7], disps [N*V,ht,wd],
+ * intrinsics [V, intr_dim] at full resolution (intr_dim 4 pinhole, 5 MEI), dist [M]; bidirectional: 0.5 (d_ij + d_ji). */
+int vipe_frame_distance_rig(const float* d_poses, const float* d_rig, const float* d_disps, const float* d_intrinsics,
+                            int intr_dim, float intr_factor, const int64_t* d_pi, const int64_t* d_qi, const int64_t* d_pj,
+                            const int64_t* d_qj, float* d_dist, int M, int n_views, int ht, int wd, float beta,
+                            int bidirectional, void* stream);
+
 /* depth_filter: replaces depth_filter_cuda, geom_kernels.cu:1462-1486 (kernel :678-793).
  * poses [n,7], disps [n,ht,wd], intrinsics [4], inds [num] int64, thresh [num] f32, counter [num,ht,wd] f32. */
 int vipe_depth_filter(const float* d_poses, const float* d_disps, const float* d_intrinsics, const int64_t* d_inds,

@@ -2189,6 +2189,37 @@ def test_slam_system_two_passes_over_rgb_frames():
             assert calls["backend"] == 1  # 10 keyframes reached once
 
 
+@pytest.mark.parametrize("camera", ["pinhole", "mei"])
+def test_fused_frame_distance_equals_the_operator_sequence(camera):
+    """`GraphBuffer.frame_distance_dense_disp` in one launch (`vipe_frame_distance_rig`: per-view poses R_v^-1 G_n,
+    1/8-scale pinhole intrinsics, both directions, the mean) against the reference's sequence of operators it replaces
+    (lietorch inv / mul over all frames, two `frame_distance` calls, the average: `fused=False`): the SAME bits - the edge
+    proposal compares these numbers with thresholds and orders by them.  One camera and a two-camera rig with a view
+    offset, pinhole and MEI, one- and two-directional."""
+    from vipe_amd.slam.buffer import GraphBuffer
+    from vipe_amd.ext.lietorch import SE3
+    gen = torch.Generator().manual_seed(9)
+    for V in (1, 2):
+        n = 7
+        buf = GraphBuffer(96, 128, n_views=V, buffer_size=8, camera_type=camera, device=dev())
+        buf.n_frames = n
+        xi = torch.randn(8, 6, generator=gen) * torch.tensor([0.2, 0.2, 0.2, 0.05, 0.05, 0.05])
+        buf.poses[:] = SE3.exp(xi.to(dev())).data
+        buf.disps[:] = (0.2 + torch.rand(8, V, 12, 16, generator=gen)).to(dev())
+        k = [110.0, 105.0, 64.0, 48.0] + ([0.3] if camera == "mei" else [])
+        buf.intrinsics[:] = torch.tensor([k, [x * 1.03 for x in k]][:V], device=dev())
+        if V == 2:
+            buf.rig[1] = SE3.exp(torch.tensor([[0.3, 0.02, -0.01, 0.01, 0.2, -0.02]], device=dev())).data[0]
+        ii, jj = torch.meshgrid(torch.arange(n), torch.arange(n), indexing="ij")
+        ii, jj = ii.reshape(-1).to(dev()), jj.reshape(-1).to(dev())
+        for bidir in (True, False):
+            for off in range(V):
+                a = buf.frame_distance_dense_disp(ii, jj, beta=0.3, bidirectional=bidir, view_offset=off)
+                b = buf.frame_distance_dense_disp(ii, jj, beta=0.3, bidirectional=bidir, view_offset=off, fused=False)
+                assert a.shape == b.shape == (n * n, V) and torch.equal(a, b), (V, bidir, off, (a - b).abs().max().item())
+        assert float(a.max()) > 1.0  # not vacuous
+
+
 def test_frontend_next_frame_kernel_matches_the_group_operations():
     """`vipe_frontend_next_frame` (frontend.py:70-76 + :118-122 / :147-151 in one launch) against the same steps through
     the lietorch operators and torch means: constant-velocity pose, per-view mean disparity over the last 1 / 4 keyframes,

@@ -6,6 +6,7 @@
 // MIN_DEPTH = 0.25 (:33), float math except where the reference's double literals promote (depth_filter's
 // 1.0 / d terms, :783-790).
 #include "common.cuh"
+#include "lie_math.h"
 
 #pragma clang fp contract(off)
 
@@ -50,26 +51,11 @@ __device__ __forceinline__ Rel rel_se3(const float* pi, const float* pj) {
   return r;
 }
 
-// one workgroup per candidate pair; lanes stride over the pixels, wave-shuffle + LDS reduction
-__global__ __launch_bounds__(256) void frame_distance_kernel(const float* __restrict__ poses,
-                                                             const float* __restrict__ disps,
-                                                             const float* __restrict__ intr,
-                                                             const int64_t* __restrict__ pi,
-                                                             const int64_t* __restrict__ pj,
-                                                             const int64_t* __restrict__ ri,
-                                                             const int64_t* __restrict__ rj,
-                                                             const int64_t* __restrict__ di, float* __restrict__ dist,
-                                                             int ht, int wd, float beta) {
-  const int b = blockIdx.x;
-  __shared__ Rel T;
-  __shared__ float red[3][4];
-  if (threadIdx.x == 0) T = rel_se3(poses + 7 * pi[b], poses + 7 * pj[b]);
-  __syncthreads();
-  const float* Ii = intr + 4 * ri[b];
-  const float* Ij = intr + 4 * rj[b];
+// the distance of one ordered pair: lanes stride over the pixels, wave-shuffle + LDS reduction; valid in thread 0
+__device__ __forceinline__ float pair_distance(const Rel& T, const float* Ii, const float* Ij, const float* __restrict__ d, int ht,
+                                               int wd, float beta, float (*red)[4]) {
   const float fxi = Ii[0], fyi = Ii[1], cxi = Ii[2], cyi = Ii[3];
   const float fxj = Ij[0], fyj = Ij[1], cxj = Ij[2], cyj = Ij[3];
-  const float* d = disps + (int64_t)di[b] * ht * wd;
   float accum = 0.f, valid = 0.f, total = 0.f;
   for (int k = threadIdx.x; k < ht * wd; k += blockDim.x) {
     const float u = (float)(k % wd), v = (float)(k / wd);
@@ -98,18 +84,79 @@ __global__ __launch_bounds__(256) void frame_distance_kernel(const float* __rest
   accum = wave_sum(accum);
   valid = wave_sum(valid);
   total = wave_sum(total);
+  __syncthreads();  // red may still be read by thread 0 of an earlier call
   if (lane_id() == 0) {
     red[0][wave_id()] = accum;
     red[1][wave_id()] = valid;
     red[2][wave_id()] = total;
   }
   __syncthreads();
+  const float a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  const float vv = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  const float tt = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+  return (vv / (tt + 1e-8) < 0.75) ? 1000.0f : a / vv;  // geom_kernels.cu:674
+}
+
+// one workgroup per candidate pair
+__global__ __launch_bounds__(256) void frame_distance_kernel(const float* __restrict__ poses,
+                                                             const float* __restrict__ disps,
+                                                             const float* __restrict__ intr,
+                                                             const int64_t* __restrict__ pi,
+                                                             const int64_t* __restrict__ pj,
+                                                             const int64_t* __restrict__ ri,
+                                                             const int64_t* __restrict__ rj,
+                                                             const int64_t* __restrict__ di, float* __restrict__ dist,
+                                                             int ht, int wd, float beta) {
+  const int b = blockIdx.x;
+  __shared__ Rel T;
+  __shared__ float red[3][4];
+  if (threadIdx.x == 0) T = rel_se3(poses + 7 * pi[b], poses + 7 * pj[b]);
+  __syncthreads();
+  const float r = pair_distance(T, intr + 4 * ri[b], intr + 4 * rj[b], disps + (int64_t)di[b] * ht * wd, ht, wd, beta, red);
+  if (threadIdx.x == 0) dist[b] = r;
+}
+
+// [fused] GraphBuffer.frame_distance_dense_disp (buffer.py:550-593) for one candidate (keyframe pi, view qi) -> (pj, qj):
+// the per-view poses R_q^-1 G_p (geom.py:338: the reference expands them for ALL frames on the host side), the pinhole
+// intrinsics at 1 / factor scale (geom.py:335; MEI through its pinhole equivalent, cameras.py:338-343), the distance and -
+// `bidir` - the reverse one, averaged.  The group operations are lie_math.h's, applied exactly as the lietorch calls of the
+// unfused path apply them (every operand re-normalised when it is loaded), so both paths give the same bits.
+__global__ __launch_bounds__(256) void frame_distance_rig_kernel(const float* __restrict__ poses, const float* __restrict__ rig,
+                                                                 const float* __restrict__ disps,
+                                                                 const float* __restrict__ intr_full, int idim, float factor,
+                                                                 const int64_t* __restrict__ pi, const int64_t* __restrict__ qi,
+                                                                 const int64_t* __restrict__ pj, const int64_t* __restrict__ qj,
+                                                                 float* __restrict__ dist, int V, int ht, int wd, float beta,
+                                                                 int bidir) {
+  const int b = blockIdx.x;
+  __shared__ Rel Tij, Tji;
+  __shared__ float I[2][4];
+  __shared__ float red[3][4];
   if (threadIdx.x == 0) {
-    const float a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    const float vv = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    const float tt = red[2][0] + red[2][1] + red[2][2] + red[2][3];
-    dist[b] = (vv / (tt + 1e-8) < 0.75) ? 1000.0f : a / vv;  // geom_kernels.cu:674
+    float e[2][7];
+    const int64_t pp[2] = {pi[b], pj[b]}, qq[2] = {qi[b], qj[b]};
+    for (int s = 0; s < 2; ++s) {
+      float tmp[7];
+      lie::SE3<float>(rig + 7 * qq[s]).inv().store(tmp);  // lietorch inv, stored ...
+      (lie::SE3<float>(tmp) * lie::SE3<float>(poses + 7 * pp[s])).store(e[s]);  // ... and loaded again by the product
+      const float* k = intr_full + (int64_t)idim * qq[s];
+      for (int c = 0; c < 4; ++c) I[s][c] = k[c] / factor;
+      if (idim == 5) {  // MEI: f / (1 + k1)
+        I[s][0] = I[s][0] / (1 + k[4]);
+        I[s][1] = I[s][1] / (1 + k[4]);
+      }
+    }
+    Tij = rel_se3(e[0], e[1]);
+    Tji = rel_se3(e[1], e[0]);
   }
+  __syncthreads();
+  const int64_t P = (int64_t)ht * wd;
+  float r = pair_distance(Tij, I[0], I[1], disps + (pi[b] * V + qi[b]) * P, ht, wd, beta, red);
+  if (bidir) {
+    const float r2 = pair_distance(Tji, I[1], I[0], disps + (pj[b] * V + qj[b]) * P, ht, wd, beta, red);
+    r = 0.5f * (r + r2);
+  }
+  if (threadIdx.x == 0) dist[b] = r;
 }
 
 // one lane per (keyframe slot, pixel): walks the 6 temporal neighbours itself, so the count needs no atomics
@@ -212,6 +259,18 @@ VIPE_EXPORT int vipe_frame_distance(const float* d_poses, const float* d_disps, 
   VIPE_CHECK_ARG(d_poses && d_disps && d_intrinsics && d_pi && d_pj && d_qi && d_qj && d_di && d_dist);
   frame_distance_kernel<<<M, 256, 0, as_stream(stream)>>>(d_poses, d_disps, d_intrinsics, d_pi, d_pj, d_qi, d_qj, d_di,
                                                           d_dist, ht, wd, beta);
+  return vipe_launch_status();
+}
+
+VIPE_EXPORT int vipe_frame_distance_rig(const float* d_poses, const float* d_rig, const float* d_disps, const float* d_intrinsics,
+                                        int intr_dim, float intr_factor, const int64_t* d_pi, const int64_t* d_qi,
+                                        const int64_t* d_pj, const int64_t* d_qj, float* d_dist, int M, int n_views, int ht,
+                                        int wd, float beta, int bidirectional, void* stream) {
+  VIPE_CHECK_ARG(M >= 0 && ht > 0 && wd > 0 && n_views > 0 && (intr_dim == 4 || intr_dim == 5) && intr_factor > 0);
+  if (M == 0) return VIPE_OK;
+  VIPE_CHECK_ARG(d_poses && d_rig && d_disps && d_intrinsics && d_pi && d_pj && d_qi && d_qj && d_dist);
+  frame_distance_rig_kernel<<<M, 256, 0, as_stream(stream)>>>(d_poses, d_rig, d_disps, d_intrinsics, intr_dim, intr_factor, d_pi,
+                                                              d_qi, d_pj, d_qj, d_dist, n_views, ht, wd, beta, bidirectional);
   return vipe_launch_status();
 }
 

@@ -197,6 +197,20 @@ def frame_distance(poses, disps, intrinsics, pi, pj, qi, qj, di, beta):
     return dist
 
 
+def frame_distance_rig(poses, rig, disps, intrinsics, pi, qi, pj, qj, beta, bidirectional=True, intr_factor=8.0):
+    """[fused] buffer.py:550-593 in one launch: poses [N,7], rig [V,7], disps [N*V,ht,wd], intrinsics [V,4|5] at full
+    resolution, (pi, qi) -> (pj, qj) [M] int64 -> dist [M] (`vipe_frame_distance_rig`)."""
+    check_gpu_contig(poses, rig, disps, intrinsics, pi, qi, pj, qj)
+    M = pi.shape[0]
+    _, ht, wd = disps.shape
+    dist = torch.empty(M, dtype=torch.float32, device=poses.device)
+    check(lib().vipe_frame_distance_rig(ptr(poses), ptr(rig), ptr(disps), ptr(intrinsics), int(intrinsics.shape[1]),
+                                        float(intr_factor), ptr(_i64(pi)), ptr(_i64(qi)), ptr(_i64(pj)), ptr(_i64(qj)), ptr(dist),
+                                        M, int(rig.shape[0]), ht, wd, float(beta), int(bool(bidirectional)), stream_ptr(poses)),
+          "frame_distance_rig")
+    return dist
+
+
 def depth_filter(poses, disps, intrinsics, ix, thresh):
     """geom_kernels.cu:1462-1486 -> counter [num,ht,wd] float32."""
     check_gpu_contig(poses, disps, intrinsics, ix, thresh)

@@ -255,12 +255,20 @@ class GraphBuffer:
         new_inds[keep_old] = self.cross_view_idx[:n][keep_old]
         self.cross_view_idx[:n] = new_inds
 
-    def frame_distance_dense_disp(self, ii, jj, beta=0.3, bidirectional=True, view_offset=0, n_frames=None):
-        """buffer.py:550-593 -> [M, n_views].  `n_frames`: frames the indices may address (default: the buffer's count)."""
+    def frame_distance_dense_disp(self, ii, jj, beta=0.3, bidirectional=True, view_offset=0, n_frames=None, fused=True):
+        """buffer.py:550-593 -> [M, n_views].  `n_frames`: frames the indices may address (default: the buffer's count).
+        One launch (`vipe_frame_distance_rig`: the per-view poses R_v^-1 G_n of geom.py:338, the 1/8-scale pinhole
+        intrinsics of geom.py:335, both directions and their mean inside the kernel); `fused=False` is the reference's
+        sequence of operators - expanded poses for all frames, two `frame_distance` calls, the average - kept as the
+        comparison form (same bits: tests/test_gpu_parity.py)."""
         from ..ext.lietorch import SE3
 
         pi, qi, di, pj, qj, dj = self.expand_edge_multiview(ii, jj, cross=False, view_offset=view_offset)
         V = self.n_views
+        if fused and self.poses.is_cuda:
+            d = slam_ext.frame_distance_rig(self.poses, self.rig, self.flattened_disps, self.intrinsics, pi, qi, pj, qj, beta,
+                                            bidirectional)
+            return d.view(-1, V)
         poses = SE3(self.poses[: self.n_frames if n_frames is None else n_frames])
         rig = SE3(self.rig)
         # expand poses into (n v) space: R_v^-1 * G_n   (geom.py:338)

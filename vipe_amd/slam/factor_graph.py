@@ -103,6 +103,8 @@ class _EdgeStores:
         """rows [n_live, n_live + k): hidden state and context features of the frames `frames` [k] int64 (device) of the
         keyframe buffer's flattened [N,128,h*w] maps -> (net_n, xbuf, new xbuf rows)"""
         k = int(frames.shape[0])
+        if n_live == 0:
+            net_n = None  # (a zero-row view has no address to recognise its bank by)
         net_n = self.reserve(n_live + k, net_n, n_live)
         nb = 0 if net_n is None else self.bank_of(net_n)
         P = self.ht * self.wd
@@ -387,7 +389,8 @@ class FactorGraph:
             assert d.shape[0] == iin.shape[0]
         else:
             ii, jj = upload_many([iin, jjn], self.device)
-            d = self.buffer.frame_distance_dense_disp(ii, jj, beta=beta).mean(-1).cpu().numpy().astype(np.float32)
+            d = self.buffer.frame_distance_dense_disp(ii, jj, beta=beta)
+            d = (d[:, 0] if d.shape[1] == 1 else d.mean(-1)).cpu().numpy().astype(np.float32)
         nj = t - t1
 
         def suppress(i, j):

@@ -87,8 +87,8 @@ class SLAMFrontend:
         iin, jjn = np.meshgrid(np.arange(t0, t, dtype=np.int64), np.arange(t1, t, dtype=np.int64), indexing="ij")
         dev = self.video.device
         ii_d, jj_d = upload_many([iin.reshape(-1), jjn.reshape(-1)], dev)
-        d = self.video.frame_distance_dense_disp(ii_d, jj_d, beta=a.beta,
-                                                 n_frames=t).mean(-1)
+        d = self.video.frame_distance_dense_disp(ii_d, jj_d, beta=a.beta, n_frames=t)
+        d = d[:, 0] if d.shape[1] == 1 else d.mean(-1)
         host = torch.empty(d.shape, dtype=d.dtype, pin_memory=True)
         host.copy_(d, non_blocking=True)
         ev = torch.cuda.Event()
@@ -117,7 +117,7 @@ class SLAMFrontend:
         ii_d, jj_d = upload_many([[self.t1 - 3], [self.t1 - 2]], dev)
         d = self.video.frame_distance_dense_disp(ii_d, jj_d, beta=a.beta,
                                                  bidirectional=True)
-        if d.max().item() < a.keyframe_thresh:
+        if float(d.cpu().max()) < a.keyframe_thresh:  # one small copy (the read-back is the sync either way)
             self.graph.rm_second_newest_keyframe(self.t1 - 2)
             self.t1 -= 1
         else:
