@@ -406,7 +406,7 @@ def clip_worker_mode(args, D):
     sys.stdin.readline()
     t0 = time.perf_counter()
     r = run_clip(seed=args.seed, n_frames=args.frames, frames=frames, release_cached_memory=args.release_cache,
-                 backend_lock=args.share_card or None)
+                 backend_lock=args.share_card or None, keep_every=max(1, args.keep_every))
     dt = time.perf_counter() - t0
     if args.out_dir:
         np.save(os.path.join(args.out_dir, f"traj_{args.seed}.npy"), r["poses"].cpu().numpy())
@@ -440,8 +440,10 @@ def clips_per_gpu_figure(args, ks=(1, 2, 4)):
             os.makedirs(d)
             procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--mode", "clip-worker", "--seed", str(k),
                                        "--frames", str(args.frames), "--height", str(args.height), "--width", str(args.width),
-                                       "--out-dir", d] + (["--share-card", os.path.join(d, "backend.lock")] if K > 1 else [])
-                                      + (["--release-cache"] if K > 2 else []),
+                                       "--out-dir", d, "--keep-every", str(max(1, args.keep_every))]
+                                      + (["--share-card", os.path.join(d, "backend.lock")] if K > 1 else [])
+                                      # every frame a keyframe: ~3000 backend edges = 99 GB of pyramids per clip
+                                      + (["--release-cache"] if K > 2 and args.keep_every <= 1 else []),
                                       stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True,
                                       env=env)
                      for k in range(K)]
@@ -477,7 +479,7 @@ def clips_per_gpu_figure(args, ks=(1, 2, 4)):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     best = max(out, key=lambda k: out[k]["frames_per_s"])
-    return {"by_K": out, "best_K": int(best), "frames": args.frames,
+    return {"by_K": out, "best_K": int(best), "frames": args.frames, "keep_every": max(1, args.keep_every),
             "what": "aggregate frames/s of K concurrent SLAMSystem.run clips on one GPU, one process per clip (each with "
                     "its own HIP context and queues), released together after their warm-up; whole run (pass 1 + global BA "
                     "+ pass 2)"}
