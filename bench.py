@@ -346,7 +346,7 @@ def video_mode(args, D):
     run_clip = make_clip_runner(dev, pipelined=not args.no_pipeline, height=args.height, width=args.width)
     run_clip(seed=10_000 + rank, n_frames=24)  # untimed warm-up clip: code objects, workspaces, allocator pools
     from vipe_amd.slam.factor_graph import warm_volume_pool
-    warm_volume_pool(dev, 110)  # ... and the memory the 200-keyframe global BA will take (a worker that has run a clip before)
+    warm_volume_pool(dev, 120)  # ... and the memory the 200-keyframe global BA will take (a worker that has run a clip before)
     n_clips = args.clips or world
     stats = []
 
@@ -399,6 +399,12 @@ def clip_worker_mode(args, D):
     `--out-dir`/traj_<seed>.npy for the bit-comparison against the K = 1 run)."""
     run_clip = make_clip_runner(D.device, pipelined=not args.no_pipeline, height=args.height, width=args.width)
     run_clip(seed=10_000, n_frames=24)
+    if not args.release_cache:
+        # a long-lived worker that keeps its pool from clip to clip (one or two per card: their ~134 GB each fit side by
+        # side): the global BA's memory is mapped before the start signal, as it is from a worker's second clip on.  Workers
+        # that must hand their blocks back (three or more per card) start cold every time - that is what they would see
+        from vipe_amd.slam.factor_graph import warm_volume_pool
+        warm_volume_pool(D.device, 120)
     frames = synthetic_frames(D.device, args.seed, args.frames, args.height, args.width)  # resident before the start signal
     torch.cuda.synchronize()
     sys.stdout.write("READY\n")
@@ -429,10 +435,8 @@ def clips_per_gpu_figure(args, ks=(1, 2, 4)):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # The global BA keeps the correlation pyramids of all its edges (33 MB per edge at 48 x 64: ~3000 edges of a
     # 200-keyframe clip are 99 GB, VIPE_AMD_BACKEND_VOLUME_GB = 160 by default) and fills the chip by itself: the K
-    # clips' global-BA phases take turns on a file lock (SLAMConfig.backend_lock_path); from K = 3 on they also hand their
-    # blocks back to the driver afterwards (release_cached_memory: the cached blocks of three processes do not fit side by
-    # side - at the price of mapping 100 GB again for every backend pass, ~1.2 s).  What runs concurrently is pass 1 /
-    # pass 2 of the other clips
+    # clips' global-BA phases take turns on a file lock (SLAMConfig.backend_lock_path); what runs concurrently is pass 1 /
+    # pass 2 of the other clips.  This function must run in a process that holds no GPU memory itself
     ref = None
     try:
         for K in ks:
@@ -442,8 +446,10 @@ def clips_per_gpu_figure(args, ks=(1, 2, 4)):
                                        "--frames", str(args.frames), "--height", str(args.height), "--width", str(args.width),
                                        "--out-dir", d, "--keep-every", str(max(1, args.keep_every))]
                                       + (["--share-card", os.path.join(d, "backend.lock")] if K > 1 else [])
-                                      # every frame a keyframe: ~3000 backend edges = 99 GB of pyramids per clip
-                                      + (["--release-cache"] if K > 2 and args.keep_every <= 1 else []),
+                                      # two clips' cached backend blocks (2 x ~134 GB) still fit side by side; from three on each
+                                      # hands its blocks back after its backend - and the next one pays the driver for scrubbing
+                                      # and re-mapping them (~2 s per 100 GB that change owner)
+                                      + (["--release-cache"] if K > 2 else []),
                                       stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True,
                                       env=env)
                      for k in range(K)]
@@ -817,8 +823,13 @@ def secondary_figures(args, device, graph, step, headline_px_rate=None):
     # on 200 RGB + depth frames resident in HBM - every frame a keyframe (stress case), then the same with the motion
     # filter's threshold scripted to keep about one frame in four (400 frames)
     try:
+        from vipe_amd.slam.factor_graph import warm_volume_pool
         run_clip = make_clip_runner(device)
         run_clip(seed=10_000, n_frames=24)
+        # the state of a worker that has run a clip of this size before: the global BA's ~100 GB already mapped, in one block
+        # (whatever this process cached for other shapes is handed back first)
+        torch.cuda.empty_cache()
+        warm_volume_pool(device, 120)
         r = run_clip(seed=0, n_frames=args.frames)
         fps = clip_figures(r)
         fps.update({
@@ -844,19 +855,13 @@ def secondary_figures(args, device, graph, step, headline_px_rate=None):
     try:
         run169 = make_clip_runner(device, height=328, width=584)
         run169(seed=10_000, n_frames=24)
+        torch.cuda.empty_cache()
+        warm_volume_pool(device, 120)
         r = run169(seed=0, n_frames=args.frames)
         out["frames_per_s_584x328"] = dict(clip_figures(r), grid=[41, 73])
     except Exception as e:  # noqa: BLE001
         out["frames_per_s_584x328"] = f"failed: {type(e).__name__}: {e}"
     _log("secondary: 16:9 video done")
-    # (5) K clips at once on this GPU, one process per clip
-    try:
-        torch.cuda.empty_cache()
-        out["frames_per_s"]["clips_per_gpu"] = clips_per_gpu_figure(args)
-    except Exception as e:  # noqa: BLE001
-        if isinstance(out.get("frames_per_s"), dict):
-            out["frames_per_s"]["clips_per_gpu"] = f"failed: {type(e).__name__}: {e}"
-    _log("secondary: clips per GPU done")
     return out
 
 
@@ -1008,6 +1013,8 @@ def update_mode(args, D):
             _log("HBM-bound kernels timed")
         if world == 1 and not args.no_secondary:
             out.update(secondary_figures(args, device, graph, step, out["value"] * E * g.ht * g.wd))
+            if isinstance(out.get("frames_per_s"), dict):
+                out["frames_per_s"]["clips_per_gpu"] = args.kclips
         out["cpu_baseline"] = cpu_baseline() if (world == 1 and not args.no_cpu_baseline) else None
         print(json.dumps(out))
     D.close()
@@ -1064,6 +1071,16 @@ def main():
     if args.mode == "clips-per-gpu":  # the parent only starts and times the workers: it never touches the GPU
         print(json.dumps(clips_per_gpu_figure(args)))
         return
+    kclips = None
+    if args.mode == "update" and world == 1 and not args.no_secondary:
+        # K clips per GPU, one process per clip: measured FIRST, while this process has not touched the GPU (its own
+        # problems and caches - tens of GB later on - would take the memory two concurrent global BAs need)
+        try:
+            kclips = clips_per_gpu_figure(args)
+        except Exception as e:  # noqa: BLE001 - a secondary figure must not take the headline down with it
+            kclips = f"failed: {type(e).__name__}: {e}"
+        _log("clips per GPU done")
+    args.kclips = kclips
     D = Dist(use_gpu=args.mode != "plumbing")
     {"update": update_mode, "video": video_mode, "backend": backend_mode, "plumbing": plumbing_mode,
      "clip-worker": clip_worker_mode}[args.mode](args, D)

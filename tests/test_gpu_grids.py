@@ -623,6 +623,41 @@ def test_slam_system_on_16_9_frames():
     assert out.slam_map is not None and len(out.slam_map.dense_disp_frame_inds) > 0
 
 
+def test_slam_system_on_a_two_camera_rig():
+    """`SLAMSystem.run` with two views per step and a rig (system.py:208-233: `n_views = len(video_streams)`, "Need rig for
+    multiple views"): the multi-view branches of every stage - per-view motion-filter score (minimum over the views),
+    keyframes with [V, ...] features, cross-view self edges in the frontend and the backend, per-view sensor disparities,
+    pass 2's batched encoder call sliced per frame and view, the rig in the output.  Random-init weights: pinned is the
+    bookkeeping."""
+    from vipe_amd.ext.lietorch import SE3
+    from vipe_amd.slam.frontend import FrontendArgs
+    from vipe_amd.slam.inner_filler import InfillArgs
+    from vipe_amd.slam.system import Frame, SLAMConfig, SLAMSystem
+
+    gen = torch.Generator().manual_seed(8)
+    T, V, H, W = 14, 2, 128, 512
+    rgb = torch.rand(T, V, H, W, 3, generator=gen).to(dev())
+    depth = (1.0 + 4.0 * torch.rand(T, V, H, W, generator=gen)).to(dev())
+    intr = torch.tensor([460.8, 460.8, 256.0, 64.0])
+    rig = SE3(torch.tensor([[0, 0, 0, 0, 0, 0, 1.0], [0.3, 0.0, 0.0, 0.0, 0.05, 0.0, 0.99875]], device=dev()))
+    frames = [[Frame(rgb=rgb[t, v], metric_depth=depth[t, v], intrinsics=intr * (1.0 + 0.02 * v)) for v in range(V)]
+              for t in range(T)]
+    torch.manual_seed(0)
+    cfg = SLAMConfig(buffer=40, filter_thresh=0.0, frontend_backend_iters=(), frontend=FrontendArgs(keyframe_thresh=0.0),
+                     infill=InfillArgs(infill_chunk_size=4))
+    sysm = SLAMSystem(dev(), cfg)
+    out = sysm.run(frames, rig=rig)
+    torch.cuda.synchronize()
+    assert out.keyframe_ids.tolist() == list(range(T)) and sysm.buffer.n_views == V
+    assert out.trajectory.data.shape == (T, 7) and bool(torch.isfinite(out.trajectory.data).all())
+    assert (out.trajectory.data[:, 3:].norm(dim=-1) - 1).abs().max().item() < 1e-4
+    assert out.intrinsics.shape == (V, 4) and torch.allclose(out.intrinsics[1].cpu(), intr * 1.02)
+    assert out.get_view_trajectory(1).data.shape == (T, 7)
+    g = sysm.frontend.graph
+    assert g.cross_view and g.net_n.shape[0] == V * g.host_edges()["ii"].shape[0] and len(sysm.motion_filter.scores) == T - 1
+    assert bool((sysm.buffer.disps_sens[:T] > 0).all())  # both views' sensor depth reached the prior
+
+
 def test_tile_convolution_beyond_4_gib_of_input():
     """The halo source offsets are formed in 64 bits: a 384-channel input of more than 4 GiB (the heads' input of a
     1900-edge backend chunk at 48 x 64) still takes the tile kernel and is right at both ends of the tensor."""

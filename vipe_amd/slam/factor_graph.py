@@ -397,13 +397,6 @@ class FactorGraph:
             if (t0 <= i < t) and (t1 <= j < t):
                 d[(i - t0) * nj + (j - t1)] = np.inf
 
-        def suppress_nms(i, j):
-            lim = max(min(abs(i - j) - 2, nms), 0)
-            for di in range(-nms, nms + 1):
-                for dj in range(-nms, nms + 1):
-                    if abs(di) + abs(dj) <= lim:
-                        suppress(i + di, j + dj)
-
         # edges already in the graph (active + inactive): the same suppression, all edges at once per window offset
         D = d.reshape(t - t0, nj)  # view of d
         h = self.host_edges()
@@ -427,7 +420,17 @@ class FactorGraph:
                 es.append((i, j))
                 es.append((j, i))
                 suppress(i, j)
-        for k in np.argsort(d, kind="stable"):
+        # candidates in order of increasing distance; only those not above the threshold NOW can ever be taken (suppression
+        # only raises distances): the global BA's 40 000 candidates shrink to a few thousand before the Python loop.  The
+        # suppression diamonds are index offsets precomputed per radius (factor_graph.py:455-460 loops di, dj per edge)
+        order = np.argsort(d, kind="stable")
+        order = order[d[order] <= thresh]
+        nt = t - t0
+        diamonds = []
+        for lim_k in range(nms + 1):
+            dd = [(di, dj) for di in range(-nms, nms + 1) for dj in range(-nms, nms + 1) if abs(di) + abs(dj) <= lim_k]
+            diamonds.append((np.array([x[0] for x in dd]), np.array([x[1] for x in dd])))
+        for k in order.tolist():
             if d[k] > thresh:
                 continue
             if len(es) > self.max_factors:
@@ -435,7 +438,10 @@ class FactorGraph:
             i, j = int(iin[k]), int(jjn[k])
             es.append((i, j))
             es.append((j, i))
-            suppress_nms(i, j)
+            ddi, ddj = diamonds[max(min(abs(i - j) - 2, nms), 0)]
+            a, b = i - t0 + ddi, j - t1 + ddj
+            ok = (a >= 0) & (a < nt) & (b >= 0) & (b < nj)
+            d[a[ok] * nj + b[ok]] = np.inf
         if len(es) == 0:
             return
         e = np.asarray(es, dtype=np.int64)

@@ -44,7 +44,8 @@ class SLAMConfig:
     pipeline_filter: bool = True   # motion filter of frame f+1 on a side stream under keyframe f's frontend step
     pause_gc: bool = True          # keep the cyclic collector off during run() (its gen-2 sweeps cost up to 0.4 s per clip)
     release_cached_memory: bool = False  # several clips share this card (one process each): hand the global BA's pyramid
-                                         # blocks back to the driver after each backend pass instead of caching them
+                                         # blocks (~100 GB at 200 keyframes) back to the driver after the second backend pass
+                                         # instead of keeping them cached for the next clip of this process
     backend_lock_path: str = None        # ... and let their global-BA phases - each fills the chip by itself and wants the
                                          # pyramid budget to itself - take turns (an advisory file lock held around the two
                                          # backend passes), while the other clips' pass 1 / pass 2 run beside it
@@ -182,9 +183,6 @@ class SLAMSystem:
             self.timings["backend_lock_wait_seconds"] = time.perf_counter() - t_wait
         try:
             self.backend.run(7)
-            if release:
-                self.backend.last_graph = None
-                torch.cuda.empty_cache()
             gb = self.backend.run(self.config.backend.backend_iters, update_depth=False)
             self.backend_edges = int(gb.host_edges()["ii"].shape[0])
             if release:
