@@ -819,6 +819,25 @@ def secondary_figures(args, device, graph, step, headline_px_rate=None):
     except Exception as e:  # noqa: BLE001 - a secondary figure must not take the headline down with it
         out["value_E768"] = f"failed: {type(e).__name__}: {e}"
     _log("secondary: E768 done")
+    # (2b) hot loop B (factor_graph.py:317-394): `update_batch(itrs=2, steps=1)` on the headline graph - reproject, correlation
+    # of all E edges, the operator, one global BA with 2 GN iterations - on the volume path (pyramids rebuilt per call: steps = 1
+    # keeps nothing) and on the reference's own volume-free AltCorr path
+    try:
+        _, _, gb = build_problem(device, args.keyframes, 384, 512, 3, 0, seed=1234)
+        call = lambda: gb.update_batch(itrs=2, steps=1, optimize_intrinsics=False, optimize_rig_rotation=False)  # noqa: E731
+        ub = {"volume_path": timed(call, 5)}
+        os.environ["VIPE_AMD_BACKEND_ALTCORR"] = "1"
+        try:
+            ub["altcorr_path"] = timed(call, 5)
+        finally:
+            del os.environ["VIPE_AMD_BACKEND_ALTCORR"]
+        ub["edges"] = int(gb.ii.numel())
+        out["update_batch_calls_per_s"] = ub
+        del gb
+        torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001
+        out["update_batch_calls_per_s"] = f"failed: {type(e).__name__}: {e}"
+    _log("secondary: update_batch done")
     # (3) synthetic video: the product's entry point, SLAMSystem.run (pass 1, the two global-BA passes, pass 2, the map),
     # on 200 RGB + depth frames resident in HBM - every frame a keyframe (stress case), then the same with the motion
     # filter's threshold scripted to keep about one frame in four (400 frames)
