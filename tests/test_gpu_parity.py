@@ -2004,11 +2004,15 @@ def test_update_batch_merged_chunks_equal_reference_groups_of_eight(monkeypatch)
     from vipe_amd.slam.networks import UpdateModule
     N = 20
 
-    def run(chunk_edges):
+    def run(chunk_edges, volume_gb=None):
         if chunk_edges is None:
             monkeypatch.delenv("VIPE_AMD_BACKEND_CHUNK_EDGES", raising=False)
         else:
             monkeypatch.setenv("VIPE_AMD_BACKEND_CHUNK_EDGES", str(chunk_edges))
+        if volume_gb is None:
+            monkeypatch.delenv("VIPE_AMD_BACKEND_VOLUME_GB", raising=False)
+        else:
+            monkeypatch.setenv("VIPE_AMD_BACKEND_VOLUME_GB", str(volume_gb))
         g = make_graph(n=N, height=64, width=512, radius=2, seed=53)
         buf = GraphBuffer(64, 512, buffer_size=N + 2, device=dev())
         buf.n_frames = N
@@ -2027,8 +2031,18 @@ def test_update_batch_merged_chunks_equal_reference_groups_of_eight(monkeypatch)
         return (graph.target.cpu().numpy(), graph.weight.cpu().numpy(), graph.net_n.float().cpu().numpy(),
                 graph.damping[:N].cpu().numpy(), buf.poses[:N].cpu().numpy(), buf.disps[:N, 0].cpu().numpy())
 
+    from vipe_amd.slam import factor_graph as fgm
     merged = run(None)
     grouped = run(1)
+    # pyramids that do not fit the volume budget: as many chunks as fit next to the working one stay resident over the
+    # passes, the others are rebuilt every pass - the same result, and the build count shows the partial residency
+    E = len(make_graph(n=N, height=64, width=512, radius=2, seed=53).ii)
+    built0 = fgm.WORK["pyramids_built"]
+    partial = run(1, volume_gb=0.04)  # ~0.7 MB per edge on the 8 x 64 grid: room for ~60 of the 74 pyramids
+    built = fgm.WORK["pyramids_built"] - built0
+    assert E < built < 2 * E, (E, built)
+    for a, b, tol in zip(merged, partial, (2e-3, 2e-3, 2e-3, 1e-4, 1e-4, 1e-4)):
+        assert a.shape == b.shape and np.abs(a - b).max() <= tol * max(1.0, np.abs(a).max()), (np.abs(a - b).max(), tol)
     # target / weight / hidden state / eta: the same kernels on the same rows; only the global-context mean inside a
     # workgroup reduction and the BA's atomics may reorder float sums (fp16 state: ~1e-3 px on the targets, 1e-5 on the map)
     for a, b, tol in zip(merged, grouped, (2e-3, 2e-3, 2e-3, 1e-4, 1e-4, 1e-4)):

@@ -690,7 +690,11 @@ class FactorGraph:
         # first pass and kept for the others while all of them fit VIPE_AMD_BACKEND_VOLUME_GB (default 160 of 288 GB).
         G_, S_, R_ = droid_net_ext.blocked_dims(self.ht, self.wd)[:3]  # the store is padded to G x 64 sources, R x 4 rows, S x 32 columns
         vol_bytes = self.ii.shape[0] * V * (G_ * 64) * (R_ * 4 * S_ * 32) * 2 * (1 + 1 / 4 + 1 / 16 + 1 / 64)
-        keep_vols = use_volume and steps > 1 and vol_bytes <= float(os.environ.get("VIPE_AMD_BACKEND_VOLUME_GB", "160")) * 2**30
+        budget = float(os.environ.get("VIPE_AMD_BACKEND_VOLUME_GB", "160")) * 2**30
+        keep_vols = use_volume and steps > 1 and vol_bytes <= budget
+        # ... and when they do not (more than ~4800 edges at 48 x 64: clips of 300+ keyframes), as MANY chunks as fit next
+        # to the one being worked on stay resident; the others are rebuilt every pass (8.5 us per edge)
+        keep_some = use_volume and steps > 1 and not keep_vols
         # The reference walks the source keyframes in groups of 8 (factor_graph.py:337-343) to bound memory.  The
         # operator couples edges only through GraphAgg's per-source-frame mean, so ANY partition that keeps every
         # source frame's edges together gives the same result: with 288 GB of HBM the groups are merged until a
@@ -703,8 +707,10 @@ class FactorGraph:
         # a chunk's pyramids must fit the volume budget (VIPE_AMD_BACKEND_VOLUME_GB) whatever the grid: 33 MB per edge at
         # 48 x 64, 238 MB at 64 x 128
         per_edge = vol_bytes / max(1, self.ii.shape[0] * V)
-        max_edges = max(8, min(int(os.environ.get("VIPE_AMD_BACKEND_CHUNK_EDGES", "4096")),
-                               int(float(os.environ.get("VIPE_AMD_BACKEND_VOLUME_GB", "160")) * 2**30 / per_edge)))
+        budget_rows = int(budget / per_edge)  # pyramids (one per edge and view) the budget holds
+        max_edges = max(8, min(int(os.environ.get("VIPE_AMD_BACKEND_CHUNK_EDGES", "4096")), budget_rows // V))
+        if keep_some:  # finer chunks: one eighth of the budget each, so that seven of eight budget shares can stay resident
+            max_edges = max(8, min(max_edges, max(256, budget_rows // (8 * V))))
         cnt = np.bincount(ii_np)
         groups, cur, cur_n = [], [], 0
         for g0 in range(0, len(cnt), 8):  # the reference's groups of 8 source frames are the merge unit
@@ -718,6 +724,7 @@ class FactorGraph:
             cur_n += n8
         if cur:
             groups.append(cur)
+        max_rows = max(int(sum(cnt[g0:g0 + 8].sum() for g0 in grp)) for grp in groups) * V  # the largest chunk's pyramids
         # Everything about a chunk that does not change during the `steps` passes is prepared once: index vectors, the
         # source-node CSR, the frame masks, the context features in the operator's input buffer and - like the
         # frontend does per edge - the context-feature part of the GRU gates (19 % of the operator's FLOPs per pass)
@@ -752,7 +759,7 @@ class FactorGraph:
             chunks[gi] = c
             return c
 
-        vols = {}
+        vols, kept_rows = {}, 0
         for _ in range(steps):
             coords1, motn = slam_ext.reproject_motion_nhwc(buf.poses, buf.flattened_disps, buf.intrinsics, buf.rig,
                                                            P["pi"], P["qi"], P["pj"], P["qj"], P["di"],
@@ -771,8 +778,9 @@ class FactorGraph:
                                                     (int(min(ii_np.min(), jj_np.min())) * V,
                                                      (int(max(ii_np.max(), jj_np.max())) + 1) * V))
                         WORK["pyramids_built"] += n
-                        if keep_vols:
+                        if keep_vols or (keep_some and kept_rows + n + max_rows <= budget_rows):
                             vols[gi] = vol
+                            kept_rows += n
                     corr_n = vol.lookup_deferred(c1)
                 else:
                     corr1 = corr_op(c1[None], c["dis"], c["djs"])  # [1,n,196,h,w] fp32
