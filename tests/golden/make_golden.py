@@ -537,6 +537,86 @@ def gen_corr_sampler(R):
     np.savez_compressed(os.path.join(HERE, "corr_sampler_reference.npz"), **out)
 
 
+def gen_schedules(R):
+    """The control flow AROUND the update iteration, from the reference's own files driven by recording fakes
+    (tests/golden/fakes.py): `SLAMFrontend` (frontend.py:32-167: initialisation, per-keyframe update with the keyframe
+    test, pose extrapolation, next-frame disparity), `SLAMBackend` (backend.py:31-122: graph construction, the depth-prior
+    branch, the empty-graph branch) and `InnerFiller.compute` (inner_filler.py:64-131: neighbour keyframes, interpolated
+    poses, the edges it adds, ten motion-only iterations).  Frozen: the exact call traces and the poses / disparities they
+    leave.  `omegaconf`, `vipe.priors.depth` and `rerun` are imported by those files for type annotations / logging only
+    and are absent here: empty stand-in modules."""
+    import json
+    sys.path.insert(0, HERE)
+    import fakes
+    for name, attrs in (("omegaconf", {"DictConfig": dict}), ("rerun", {}), ("vipe.priors", {}),
+                        ("vipe.priors.depth", {"DepthEstimationModel": object})):
+        m = sys.modules.get(name) or types.ModuleType(name)
+        m.__path__ = []
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+    comp = sys.modules.get("vipe.slam.components") or types.ModuleType("vipe.slam.components")
+    comp.__path__ = []
+    sys.modules["vipe.slam.components"] = comp
+    sys.modules["vipe.slam"].components = comp
+    for sub, attrs in (("buffer", {"GraphBuffer": object}), ("factor_graph", {"FactorGraph": fakes.FakeGraph})):
+        m = types.ModuleType("vipe.slam.components." + sub)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules["vipe.slam.components." + sub] = m
+        setattr(comp, sub, m)
+    fe = _load("vipe.slam.components.frontend", "vipe/slam/components/frontend.py")
+    be = _load("vipe.slam.components.backend", "vipe/slam/components/backend.py")
+    inf = _load("vipe.slam.components.inner_filler", "vipe/slam/components/inner_filler.py")
+    out = {}
+    NS = types.SimpleNamespace
+    # ---- frontend
+    for tag, has_pose, seq_init in (("frontend", False, True), ("frontend_init_pose_no_seq", True, False)):
+        args = NS(warmup=8, beta=0.3, frontend_nms=1, keyframe_thresh=4.0, frontend_window=25, frontend_thresh=16.0,
+                  frontend_radius=2, has_init_pose=has_pose, cross_view=True, seq_init=seq_init)
+        trace, poses, disps, t1, n = fakes.run_frontend(fe.SLAMFrontend, args, has_pose)
+        out[tag + "/trace"] = np.array(json.dumps(trace))
+        out[tag + "/poses"], out[tag + "/disps"] = _np(poses), _np(disps)
+        out[tag + "/t1_n"] = np.array([t1, n])
+        print(tag, len(trace), "calls; t1, n_frames =", t1, n)
+    # ---- backend: plain, with a depth model + intrinsics, a single keyframe (empty graph)
+    for tag, n_frames, depth, opt_intr, adaptive, edges in (("backend", 12, False, False, False, 3), ("backend_depth_intr", 12, True, True, True, 3),
+                                                            ("backend_single", 1, False, False, False, 0)):
+        video = fakes.FakeBuffer(n_frames)
+        video.disps_sens[0, 0, 0] = 0.7
+        fakes.FakeGraph.edges_per_add = edges
+        args = NS(beta=0.3, backend_thresh=22.0, backend_radius=2, backend_nms=3, optimize_intrinsics=opt_intr,
+                  optimize_rig_rotation=False, cross_view=True, adaptive_cross_view=adaptive, map_filter_thresh=0.05)
+        b = be.SLAMBackend(None, video, args, torch.device("cpu"))
+        b.depth_model = object() if depth else None
+        b.run(7)
+        b.run_if_necessary(5)
+        fakes.FakeGraph.edges_per_add = 3
+        out[tag + "/trace"] = np.array(json.dumps(video.trace))
+        out[tag + "/disps0"] = _np(video.disps[0])
+        print(tag, len(video.trace), "calls")
+    # ---- inner filler: keyframes at frames 0, 3, 6, 9; the 12 frames 0..11 appended behind them in two chunks of 6
+    for tag, dense in (("infill", False), ("infill_dense_disp", True)):
+        video = fakes.FakeBuffer(4, seed=3)
+        video.tstamp[:4] = torch.tensor([0, 3, 6, 9])
+        video.disps_sens[4:10, 0, 0] = 0.9
+        args = NS(infill_chunk_size=6, infill_dense_disp=dense)
+        f = inf.InnerFiller(None, video, args, torch.device("cpu"))
+        f.set_start_idx(4)
+        for frame in range(12):
+            video.tstamp[video.n_frames] = frame
+            video.n_frames += 1
+            if f.check() or frame == 11:
+                f.compute()
+        res = f.get_result()
+        out[tag + "/trace"] = np.array(json.dumps(video.trace))
+        out[tag + "/filled_poses"] = _np(res.poses.data)
+        if dense:
+            out[tag + "/filled_disps"] = _np(res.dense_disps)
+        print(tag, len(video.trace), "calls;", tuple(res.poses.data.shape))
+    np.savez_compressed(os.path.join(HERE, "schedule_reference.npz"), **out)
+
+
 def gen_headline(R):
     """Headline-size fixtures from the reference itself (BASELINE configs[2]: 512 x 384, 48 keyframes, E = 276, depth
     prior on - the graph `bench.py` times):
@@ -574,6 +654,9 @@ def gen_headline(R):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     R = load_reference()
+    if os.environ.get("GOLDEN_ONLY") == "schedules":
+        gen_schedules(R)
+        sys.exit(0)
     if os.environ.get("GOLDEN_ONLY") == "corr_sampler":
         gen_corr_sampler(R)
         sys.exit(0)
@@ -607,4 +690,5 @@ if __name__ == "__main__":
     gen_encoder(R)
     gen_headline(R)
     gen_corr_sampler(R)
+    gen_schedules(R)
     print("golden fixtures written to", HERE)

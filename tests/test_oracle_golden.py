@@ -426,3 +426,100 @@ def test_sparse_tracks_target_weight_matches_oracle_on_cpu():
     d = DummySparseTracks(2)
     d.track_image(None)
     assert not d.enabled and d.observations == [[{}], [{}]]
+
+
+def _schedule_fixture():
+    import json
+    G = np.load(os.path.join(GOLD, "schedule_reference.npz"))
+    return G, lambda tag: json.loads(str(G[tag + "/trace"]))
+
+
+def _as_lists(trace):
+    import json
+    return json.loads(json.dumps(trace))
+
+
+@pytest.mark.parametrize("tag,has_pose,seq_init", [("frontend", False, True), ("frontend_init_pose_no_seq", True, False)])
+def test_frontend_schedule_matches_the_reference_class(tag, has_pose, seq_init, monkeypatch):
+    """`SLAMFrontend` against the reference's own class (frontend.py:32-167, run in the build container with the recording
+    fakes of tests/golden/fakes.py): the exact sequence of graph / buffer calls over 8 warm-up + 9 further keyframes - two of
+    which fail the keyframe-distance test and are dropped again - with every argument (window bounds, radii, thresholds,
+    masks of aged edges, `use_inactive`, `fixed_motion`, `t0`), the extrapolated poses (Exp(0.5 Log(.)) through lietorch) and
+    the next-frame disparities."""
+    sys_path = os.path.join(GOLD)
+    import sys
+    sys.path.insert(0, sys_path)
+    import fakes
+    from vipe_amd.slam import frontend as fe
+    G, trace_of = _schedule_fixture()
+    monkeypatch.setattr(fe, "FactorGraph", fakes.FakeGraph)
+    args = fe.FrontendArgs(warmup=8, beta=0.3, keyframe_thresh=4.0, frontend_thresh=16.0, frontend_window=25, frontend_radius=2,
+                           frontend_nms=1, seq_init=seq_init, has_init_pose=has_pose, cross_view=True)
+    trace, poses, disps, t1, n = fakes.run_frontend(fe.SLAMFrontend, args, has_pose)
+    want = trace_of(tag)
+    got = _as_lists(trace)
+    assert len(got) == len(want)
+    for k, (a, b) in enumerate(zip(got, want)):
+        assert a == b, (k, a, b)
+    assert [t1, n] == G[tag + "/t1_n"].tolist()
+    assert np.abs(poses.numpy() - G[tag + "/poses"]).max() < 1e-6
+    assert np.abs(disps.numpy() - G[tag + "/disps"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("tag,n_frames,depth,opt_intr,adaptive,edges", [("backend", 12, False, False, False, 3),
+                                                                       ("backend_depth_intr", 12, True, True, True, 3),
+                                                                       ("backend_single", 1, False, False, False, 0)])
+def test_backend_schedule_matches_the_reference_class(tag, n_frames, depth, opt_intr, adaptive, edges, monkeypatch):
+    """`SLAMBackend.run` / `run_if_necessary` against the reference's class (backend.py:31-122): graph construction
+    (max_factors = 16 t, non-incremental), proximity arguments, the plain / depth-prior (half the passes, sensor disparities
+    refreshed, the rest with the intrinsics held) / single-keyframe branches, 16 instead of 8 GN iterations when intrinsics
+    are optimised."""
+    import sys
+    sys.path.insert(0, GOLD)
+    import fakes
+    from vipe_amd.slam import backend as be
+    G, trace_of = _schedule_fixture()
+    monkeypatch.setattr(be, "FactorGraph", fakes.FakeGraph)
+    monkeypatch.setattr(fakes.FakeGraph, "edges_per_add", edges)
+    video = fakes.FakeBuffer(n_frames)
+    video.disps_sens[0, 0, 0] = 0.7
+    args = be.BackendArgs(beta=0.3, backend_thresh=22.0, backend_radius=2, backend_nms=3, optimize_intrinsics=opt_intr,
+                          optimize_rig_rotation=False, cross_view=True, adaptive_cross_view=adaptive)
+    b = be.SLAMBackend(None, video, args, torch.device("cpu"))
+    b.depth_model = object() if depth else None
+    b.run(7)
+    b.run_if_necessary(5)
+    assert _as_lists(video.trace) == trace_of(tag)
+    assert np.abs(video.disps[0].numpy() - G[tag + "/disps0"]).max() == 0
+
+
+@pytest.mark.parametrize("tag,dense", [("infill", False), ("infill_dense_disp", True)])
+def test_inner_filler_matches_the_reference_class(tag, dense, monkeypatch):
+    """`InnerFiller` against the reference's class (inner_filler.py:46-138): for 12 frames appended behind keyframes at
+    frames 0, 3, 6, 9 in two chunks - the neighbouring keyframes of every frame (the edges handed to `add_factors`), the
+    constant-velocity poses, the ten `update` calls with their flags, the disparity initialisation of `infill_dense_disp`."""
+    import sys
+    sys.path.insert(0, GOLD)
+    import fakes
+    from vipe_amd.slam import inner_filler as inf
+    G, trace_of = _schedule_fixture()
+    monkeypatch.setattr(inf, "FactorGraph", fakes.FakeGraph)
+    video = fakes.FakeBuffer(4, seed=3)
+    video.tstamp[:4] = torch.tensor([0, 3, 6, 9])
+    video.disps_sens[4:10, 0, 0] = 0.9
+    f = inf.InnerFiller(None, video, inf.InfillArgs(infill_chunk_size=6, infill_dense_disp=dense), torch.device("cpu"))
+    f.set_start_idx(4)
+    for frame in range(12):
+        video.tstamp[video.n_frames] = frame
+        video.n_frames += 1
+        if f.check() or frame == 11:
+            f.compute()
+    res = f.get_result()
+    assert _as_lists(video.trace) == trace_of(tag)
+    # frames beyond the last keyframe divide log(G G^-1) - rounding noise around zero - by d_time = 1e-3 and multiply by the
+    # frame distance (inner_filler.py:73-77): the noise of two correct fp32 implementations differs by a few 1e-5 there
+    assert np.abs(res.poses.data.numpy() - G[tag + "/filled_poses"]).max() < 1e-4
+    inside = slice(0, 10)  # frames 0..9 lie between keyframes
+    assert np.abs(res.poses.data.numpy()[inside] - G[tag + "/filled_poses"][inside]).max() < 2e-6
+    if dense:
+        assert np.abs(res.dense_disps.numpy() - G[tag + "/filled_disps"]).max() < 1e-6

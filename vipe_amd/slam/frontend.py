@@ -75,8 +75,8 @@ class SLAMFrontend:
         next `_update` finds it there instead of draining the stream for it (a ~1.5 ms bubble per keyframe).  Used only
         if nothing touched the geometry in between (`GraphBuffer.geom_version`) and exactly one frame was appended."""
         a = self.args
-        if a.has_init_pose:  # the caller supplies the new frame's pose when it appends it: nothing to anticipate
-            self._prox = None
+        if a.has_init_pose or not self.video.poses.is_cuda:  # the caller supplies the new frame's pose when it appends it:
+            self._prox = None                                 # nothing to anticipate (host buffers: nothing to overlap)
             return
         t = self.t1 + 1
         t0, t1 = t - 5, max(t - a.frontend_window, 0)
