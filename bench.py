@@ -683,20 +683,23 @@ def hbm_kernel_rooflines(graph, step, device, n=8):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); e1.record()
     torch.cuda.synchronize()
-    slam_ext.PROFILE_EVENTS = (e0, e1)
     try:
-        tot = 0.0
+        tot, per_iter = 0.0, [0.0, 0.0, 0.0]
         step()
-        for _ in range(n):
+        for k in range(3 * n):  # every Gauss-Newton iteration's launch in turn: each shares the chip with another piece of the
+            slam_ext.PROFILE_EVENTS = (e0, e1, k % 3)  # staged gate convolution (the first with none of it)
             step()
             torch.cuda.synchronize()
-            tot += e0.elapsed_time(e1)
+            per_iter[k % 3] += e0.elapsed_time(e1) / n
+        tot = sum(per_iter) / 3.0
     finally:
         slam_ext.PROFILE_EVENTS = None
-    out["ba_accum_mfma_kernel"] = entry("ba_accum_mfma_kernel<0,0>", tot / n, E * P * (2 * 8 + 4) + 48 * P * 16,
+    out["ba_accum_mfma_kernel"] = entry("ba_accum_mfma_kernel<0,0>", tot, E * P * (2 * 8 + 4) + 48 * P * 16,
                                         "ba_accum_mfma_kernel",
                                         "0.061 MB per edge and iteration (target, weight, disparity) + 4 node-side maps per "
-                                        "keyframe; latency- / reduction-bound by construction (SURVEY F5)")
+                                        "keyframe; latency- / reduction-bound by construction (SURVEY F5); avg_launch_ms = mean over "
+                                        "the three Gauss-Newton iterations' launches")
+    out["ba_accum_mfma_kernel"]["avg_launch_ms_per_gn_iteration"] = per_iter
     # (iii) pyramid build of all edges, into the slots they already own
     V = graph.buffer.n_views
     pi, qi, pj, qj = (plan[k] for k in ("pi", "qi", "pj", "qj"))

@@ -277,7 +277,9 @@ typedef struct {
                                   validating the specialised kernels against them (tests/test_gpu_parity.py) */
   void* profile_ev0;           /* optional pair of hipEvent_t (created with timing enabled by the caller): recorded on the BA */
   void* profile_ev1;           /* stream right before / right after the accumulate kernels (ba_accum_mfma_kernel, or the walk +
-                                  Schur pair) of the LAST Gauss-Newton iteration - bench.py times that launch with them; NULL: none */
+                                  Schur pair) of Gauss-Newton iteration `profile_iter` - bench.py times that launch with them;
+                                  NULL: none */
+  int profile_iter;            /* 0 .. n_iters - 1; negative: the last iteration */
 } vipe_ba_params;
 #define VIPE_BA_OPT_ONE_CHAIN 1           /* band solve: eliminate the pose chain from one end (default: both ends at once) */
 #define VIPE_BA_OPT_GENERAL_ACCUMULATE 2  /* accumulate: the walk + Schur kernel pair for every source-frame degree */

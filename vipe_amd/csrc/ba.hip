@@ -3510,7 +3510,8 @@ int run_iters(const BAArgs& a, hipStream_t s, int* pieces_done) {
     }
     // path_hint (vipe_ba_params): what the caller learnt from an earlier call with this plan; 0 launches everything
     const int hint = a.force_general ? 0 : a.p.path_hint;
-    const bool prof = a.p.profile_ev0 && a.p.profile_ev1 && it == a.p.n_iters - 1;
+    const bool prof = a.p.profile_ev0 && a.p.profile_ev1 &&
+                      it == (a.p.profile_iter < 0 || a.p.profile_iter >= a.p.n_iters ? a.p.n_iters - 1 : a.p.profile_iter);
     if (prof && hipEventRecord((hipEvent_t)a.p.profile_ev0, s) != hipSuccess) return VIPE_EINVAL;
     if (!(hint & 2)) ba_accum_mfma_kernel<CAM, F><<<dim3(tiles, a.nF), TILE, accum_mfma_lds(), s>>>(a);
     if (!(hint & 1)) {

@@ -88,7 +88,7 @@ def update_finish(coords1, dw, mask, target, weight, eta, du, damping):
 
 
 BA_OPT_ONE_CHAIN, BA_OPT_GENERAL_ACCUMULATE = 1, 2  # VIPE_BA_OPT_* (include/vipe_amd.h)
-PROFILE_EVENTS = None  # measurement aid (bench.py): a pair of timing events every dense_ba call records around its last accumulate launch
+PROFILE_EVENTS = None  # measurement aid (bench.py): (event, event[, iteration]) every dense_ba call records around that iteration's accumulate launch
 PLAN_REUSE = True  # False: rebuild the edge plan on every call and launch every kernel of both paths (validation aid)
 
 
@@ -126,7 +126,8 @@ def dense_ba(poses, disps, disps_sens, intrinsics, rig, target, weight, disp_dam
     if profile_events is None:
         profile_events = PROFILE_EVENTS
     if profile_events is not None:  # two torch.cuda.Event(enable_timing=True), each recorded once before (so that they exist)
-        p.profile_ev0, p.profile_ev1 = (int(e.cuda_event) for e in profile_events)
+        p.profile_ev0, p.profile_ev1 = (int(e.cuda_event) for e in profile_events[:2])
+        p.profile_iter = int(profile_events[2]) if len(profile_events) > 2 else -1
     L = lib()
     nbytes = L.vipe_dense_ba_workspace_bytes(ctypes.byref(p))
     require(nbytes > 0, "bad BA parameters")
