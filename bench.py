@@ -259,10 +259,10 @@ def make_clip_runner(device, pipelined=True, height=384, width=512):
     torch.manual_seed(0)
     dn = DroidNet()
 
-    def run_clip(seed, n_frames, keep_every=1, frames=None, release_cached_memory=False, backend_lock=None):
+    def run_clip(seed, n_frames, keep_every=1, frames=None, release_cached_memory=False, backend_lock=None, depth=True):
         from vipe_amd.slam.motion_filter import MotionFilter
         if frames is None:
-            frames = synthetic_frames(device, seed, n_frames, height, width)
+            frames = synthetic_frames(device, seed, n_frames, height, width, depth=depth)
         # keyframe_thresh = 0: the frontend never drops the second newest keyframe (random-weight flow would otherwise
         # make its distance test drop about half of them and the window would hold ~16 instead of <= 48 edges);
         # filter_thresh = 0: every frame becomes a keyframe (the stress case); keep_every = k: every k-th (scripted_filter)
@@ -863,6 +863,12 @@ def secondary_figures(args, device, graph, step, headline_px_rate=None):
                     "frame f+1 on a side stream under keyframe f's frontend step; backend.run(7) + backend.run(24); pass 2: "
                     "every frame encoded again, chunks of 16 through the InnerFiller; extract_slam_map); pass1 / "
                     "through_global_ba / through_pass2 = the same clip up to that phase boundary (SLAMSystem.timings)"})
+        r0 = run_clip(seed=0, n_frames=args.frames, depth=False)
+        fps["without_sensor_depth"] = dict(clip_figures(r0),
+                                           what="the same clip without sensor depth on the frames - the conditions of round 3's "
+                                                "hand-driven clip (117.7 frontend only / 73.3 with global BA / 65.5 with infill in "
+                                                "BENCH_r03): without the prior the random-weight system drifts further, the global "
+                                                "BA's proximity graph holds ~1700 instead of ~3000 edges")
         r4 = run_clip(seed=1, n_frames=2 * args.frames, keep_every=4)
         fps["keep_one_in_four"] = dict(clip_figures(r4), keep_rate=r4["keyframes"] / r4["frames"],
                                        what="the same with the filter's decision scripted to keep every 4th frame "
