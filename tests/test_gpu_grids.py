@@ -555,6 +555,45 @@ def test_bench_two_ranks_on_one_card_as_a_child_process():
     assert cfg["result_gather"]["backend"] == "gloo" and cfg["launch"].startswith("hipgraph")
 
 
+def test_clips_per_gpu_workers_share_the_card():
+    """`bench.py --mode clips-per-gpu` as the default bench line runs it: a parent that never touches the GPU starts K
+    clip-worker processes (one `SLAMSystem.run` each: READY -> go -> one JSON line), their global-BA phases take turns on
+    the file lock, the trajectories come back through files.  Two workers, short clips: covers the protocol, the lock and
+    the release path on a GPU box (no throughput is read off this)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    import types
+    args = types.SimpleNamespace(frames=20, height=128, width=512, keep_every=1)
+    out = bench.clips_per_gpu_figure(args, ks=(1, 2))
+    assert set(out["by_K"]) == {"1", "2"} and out["frames"] == 20
+    for k, v in out["by_K"].items():
+        assert v["all_finite"] and len(v["per_clip_seconds"]) == int(k) and v["frames_per_s"] > 0
+        assert all(a < b <= c for a, b, c in v["phase_ends_seconds"])
+    two = out["by_K"]["2"]
+    assert sum(w is not None and w >= 0 for w in two["backend_lock_wait_seconds"]) == 2  # both workers took the lock
+    # a worker with the release path on (what three and more workers per card run)
+    env = dict(os.environ)
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    pr = subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--mode", "clip-worker", "--seed", "3", "--frames", "12",
+                           "--height", "128", "--width", "512", "--release-cache", "--share-card", os.path.join(root, "gpurun_out", ".lock_test")],
+                          stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env, cwd=root)
+    try:
+        assert pr.stdout.readline().strip() == "READY"
+        pr.stdin.write("go\n")
+        pr.stdin.flush()
+        res = json.loads(pr.stdout.readline())
+        assert res["finite"] and res["frames"] == 12 and res["keyframes"] == 12
+        assert pr.wait(timeout=120) == 0
+    finally:
+        if pr.poll() is None:
+            pr.kill()
+
+
 def test_staged_gate_state_survives_only_while_its_scratch_is_untouched():
     """One UpdateEngine serves every FactorGraph of an UpdateModule, and a staged gate state (the hidden-state part of the
     next iteration's gates, computed under the BA) lives in that engine's scratch buffers: when ANOTHER graph runs the
